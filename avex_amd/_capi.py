@@ -1,0 +1,134 @@
+"""ctypes binding of include/avexhip.h (the C-ABI shared library built by avex_amd.build).
+
+The product path has NO CPU fallback: if the library is missing or no GPU is visible the
+callers raise ``AvexHipError`` loudly instead of silently computing somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libavexhip.so")
+
+F16, BF16 = 0, 1
+DTYPE_NAMES = {"f16": F16, "fp16": F16, "float16": F16, "bf16": BF16, "bfloat16": BF16}
+
+
+class AvexHipError(RuntimeError):
+    """Raised for any failure of the HIP extension (missing library, no GPU, bad arguments)."""
+
+
+class FbankConfig(C.Structure):
+    _fields_ = [("win_length", C.c_int32), ("hop_length", C.c_int32), ("n_mels", C.c_int32),
+                ("input_scale", C.c_float), ("preemph", C.c_float), ("remove_dc", C.c_int32),
+                ("log_floor", C.c_float), ("norm_mean", C.c_float), ("norm_div", C.c_float)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64), ("alpha", C.c_float),
+                ("gelu", C.c_int32), ("out_f32", C.c_void_p), ("ldo", C.c_int64),
+                ("out_half", C.c_void_p), ("ldh", C.c_int64), ("out_raw", C.c_void_p), ("ldraw", C.c_int64),
+                ("variant", C.c_int32)]
+
+
+class BeatsConfig(C.Structure):
+    _fields_ = [("input_patch_size", C.c_int32), ("embed_dim", C.c_int32), ("encoder_layers", C.c_int32),
+                ("encoder_embed_dim", C.c_int32), ("encoder_ffn_embed_dim", C.c_int32),
+                ("encoder_attention_heads", C.c_int32), ("conv_pos", C.c_int32), ("conv_pos_groups", C.c_int32),
+                ("num_buckets", C.c_int32), ("max_distance", C.c_int32), ("gru_rel_pos", C.c_int32),
+                ("deep_norm", C.c_int32), ("num_mel_bins", C.c_int32), ("sample_frequency", C.c_float),
+                ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float), ("fbank_mean", C.c_float),
+                ("fbank_std", C.c_float), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+# every symbol include/avexhip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "avexhip_last_error": (C.c_char_p, []),
+    "avexhip_abi_version": (C.c_int, []),
+    "avexhip_device_count": (C.c_int, []),
+    "avexhip_fbank_plan_create": (_P, [C.POINTER(FbankConfig), _P, _P]),
+    "avexhip_fbank_plan_destroy": (None, [_P]),
+    "avexhip_fbank_num_frames": (C.c_int, [_P, C.c_int64]),
+    "avexhip_fbank_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
+    "avexhip_cast_f32_to_half": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "avexhip_cast_half_to_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "avexhip_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _P]),
+    "avexhip_layernorm": (C.c_int, [_P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P,
+                                    C.c_int64, C.c_int, _P]),
+    "avexhip_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "avexhip_posconv_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "avexhip_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "avexhip_mean_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "avexhip_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "avexhip_beats_create": (_P, [C.POINTER(BeatsConfig), C.POINTER(Tensor), C.c_int]),
+    "avexhip_beats_destroy": (None, [_P]),
+    "avexhip_beats_num_tokens": (C.c_int, [_P, C.c_int64]),
+    "avexhip_beats_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int64]),
+    "avexhip_beats_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_uint32, C.POINTER(_P),
+                                        C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_beats_forward_fbank": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint32, C.POINTER(_P), C.c_int,
+                                              _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_beats_set_profiling": (C.c_int, [_P, C.c_int]),
+    "avexhip_beats_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
+                                             C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libavexhip.so (once).  Raises AvexHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AvexHipError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -m avex_amd.build` "
+            "(needs hipcc). There is no CPU fallback for this path."
+        )
+    try:
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise AvexHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise AvexHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return handle
+
+
+def last_error() -> str:
+    msg = lib().avexhip_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise AvexHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def require_gpu() -> None:
+    if lib().avexhip_device_count() <= 0:
+        raise AvexHipError("no HIP device visible: the avex_amd compute path runs on MI355X only (no CPU fallback)")
+
+
+def dtype_code(name) -> int:
+    if isinstance(name, int):
+        return name
+    try:
+        return DTYPE_NAMES[str(name).lower()]
+    except KeyError as e:
+        raise ValueError(f"unknown operand dtype {name!r} (use 'f16' or 'bf16')") from e

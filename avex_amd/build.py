@@ -1,0 +1,81 @@
+"""Build the HIP extension (libavexhip.so) in-tree for gfx950.
+
+    python -m avex_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects land in avex_amd/_build/, the shared library in
+avex_amd/lib/libavexhip.so (git-ignored, but it travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libavexhip.so")
+SOURCES = ["api.cpp", "gemm.hip", "elementwise.hip", "fbank.hip", "attention.hip", "posconv.hip"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
+
+
+def _deps_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".hpp")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    cc = hipcc()
+    hdr = _deps_mtime()
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-Wno-unused-result",
+             "-fno-gpu-rdc", "-ffp-contract=off"]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        stale = force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr)
+        if stale:
+            jobs.append((s, o))
+
+    def run(job):
+        s, o = job
+        cmd = [cc] + flags + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
+        return s
+
+    if jobs:
+        if verbose:
+            print(f"[avex_amd.build] compiling {len(jobs)} file(s) for {ARCH}", flush=True)
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, os.path.splitext(src)[0] + ".o") for src in SOURCES]
+    if jobs or force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[avex_amd.build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,686 @@
+// C-ABI surface (include/avexhip.h): error plumbing, thin wrappers over the kernel launchers and the
+// BEATs encoder handle that orchestrates one forward as a fixed sequence of launches on the caller's
+// stream.  Compiled with hipcc (host code only in this file).
+#include <math.h>
+#include <stdarg.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void avexhip_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* avexhip_last_error(void) { return g_err; }
+extern "C" int avexhip_abi_version(void) { return AVEXHIP_ABI_VERSION; }
+extern "C" int avexhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// building blocks
+// ---------------------------------------------------------------------------------------------
+extern "C" int avexhip_cast_f32_to_half(const float* in, void* out, int64_t n, int dtype, void* stream) {
+    return avx::cast_to_half(in, out, n, dtype, (hipStream_t)stream);
+}
+extern "C" int avexhip_cast_half_to_f32(const void* in, float* out, int64_t n, int dtype, void* stream) {
+    return avx::cast_to_f32(in, out, n, dtype, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream) {
+    AVX_REQUIRE(a, "gemm: null args");
+    avx::GemmArgs g;
+    g.A = a->A; g.lda = a->lda; g.W = a->W; g.ldw = a->ldw;
+    g.M = a->M; g.N = a->N; g.K = a->K;
+    g.bias = a->bias; g.resid = a->resid; g.ldr = a->ldr; g.alpha = a->alpha; g.gelu = a->gelu;
+    g.out_f32 = a->out_f32; g.ldo = a->ldo; g.out_half = a->out_half; g.ldh = a->ldh;
+    g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
+    return avx::gemm(g, dtype, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_layernorm(const float* in, int64_t ld_in, const float* w, const float* b, float eps, int M,
+                                 int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype,
+                                 void* stream) {
+    return avx::layernorm(in, ld_in, w, b, eps, M, C, out_f32, ldo, out_half, ldh, dtype, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
+                                 const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out,
+                                 int dtype, void* stream) {
+    return avx::attention(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, dtype, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed,
+                                    int dtype, void* stream) {
+    return avx::posconv_pack(g, v, E, groups, K, w_packed, dtype, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_posconv(const void* x_half, const float* x_f32, const void* w_packed, const float* bias, int B,
+                               int T, int E, int groups, int K, float* out, int dtype, void* stream) {
+    return avx::posconv(x_half, x_f32, w_packed, bias, B, T, E, groups, K, out, dtype, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_mean_pool(const float* in, int B, int T, int C, float* out, void* stream) {
+    return avx::mean_pool(in, B, T, C, nullptr, out, (hipStream_t)stream);
+}
+
+// T5 bidirectional bucket, fp32 arithmetic exactly as the reference writes it (backbone.py:438-473):
+//   nb = num_buckets/2; out = (rel > 0) * nb; a = |rel|; max_exact = nb/2;
+//   large = max_exact + trunc( log(float(a)/max_exact) / log(max_distance/max_exact) * (nb - max_exact) )
+extern "C" int avexhip_rel_bucket(int rel, int num_buckets, int max_distance) {
+    const int nb = num_buckets / 2;
+    int out = rel > 0 ? nb : 0;
+    const int a = rel < 0 ? -rel : rel;
+    const int max_exact = nb / 2;
+    if (a < max_exact) return out + a;
+    const float num = logf((float)a / (float)max_exact);
+    const float den = (float)log((double)max_distance / (double)max_exact);
+    const float val = num / den * (float)(nb - max_exact);
+    int big = max_exact + (int)val;
+    if (big > nb - 1) big = nb - 1;
+    return out + big;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BEATs handle
+// ---------------------------------------------------------------------------------------------
+const avx::FbankDev* avexhip_fbank_plan_dev(const avexhip_fbank_plan* plan);
+
+namespace {
+
+struct Layer {
+    void* w_qkv = nullptr; float* b_qkv = nullptr;
+    void* w_o = nullptr;   float* b_o = nullptr;
+    float* grep_w = nullptr; float* grep_b = nullptr; float* grep_a = nullptr;
+    float* ln1_w = nullptr; float* ln1_b = nullptr;
+    void* w_fc1 = nullptr; float* b_fc1 = nullptr;
+    void* w_fc2 = nullptr; float* b_fc2 = nullptr;
+    float* ln2_w = nullptr; float* ln2_b = nullptr;
+};
+
+struct StageRec {
+    std::string name;
+    double flops;
+    hipEvent_t e0, e1;
+};
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// window / mel bank as the reference builds them (beats.py:75,82-118), fp32 arithmetic
+void default_window(int win, std::vector<float>& w) {
+    w.resize(win);
+    for (int n = 0; n < win; ++n) {
+        const float hann = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(win - 1)));
+        w[n] = powf(hann, 0.85f);
+    }
+}
+void default_mel(int n_fft, int n_mels, float sr, float low, float high, std::vector<float>& fb) {
+    const int nb = n_fft / 2;
+    const float bin_w = sr / (float)n_fft;
+    const float mel_low = (float)(1127.0 * log(1.0 + (double)low / 700.0));
+    const float mel_high = (float)(1127.0 * log(1.0 + (double)high / 700.0));
+    const float delta = (float)(((double)mel_high - (double)mel_low) / (double)(n_mels + 1));
+    fb.assign((size_t)(nb + 1) * n_mels, 0.f);
+    for (int m = 0; m < n_mels; ++m) {
+        const float left = mel_low + (float)m * delta;
+        const float center = mel_low + ((float)m + 1.0f) * delta;
+        const float right = mel_low + ((float)m + 2.0f) * delta;
+        for (int k = 0; k < nb; ++k) {
+            const float f = bin_w * (float)k;
+            const float mel = 1127.0f * logf(1.0f + f / 700.0f);
+            const float up = (mel - left) / (center - left);
+            const float down = (right - mel) / (right - center);
+            const float v = fmaxf(0.f, fminf(up, down));
+            fb[(size_t)k * n_mels + m] = v;
+        }
+    }
+}
+
+}  // namespace
+
+struct avexhip_beats {
+    avexhip_beats_config cfg;
+    int dtype = AVEXHIP_F16;
+    int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 64;
+    float alpha = 1.f;
+    avexhip_fbank_plan* fb = nullptr;
+    void* w_patch = nullptr;
+    float* ln0_w = nullptr; float* ln0_b = nullptr;
+    void* w_post = nullptr; float* b_post = nullptr;
+    void* w_pc = nullptr; float* b_pc = nullptr;
+    float* lnE_w = nullptr; float* lnE_b = nullptr;
+    std::vector<Layer> layers;
+    std::vector<float> rel_table;  // host [num_buckets, H]; empty if no relative position embedding
+    std::map<int, float*> bias_tabs;
+    std::vector<void*> allocs;
+    bool profiling = false;
+    std::vector<StageRec> recs;
+    std::vector<std::string> prof_names;
+    std::vector<const char*> prof_name_ptrs;
+    std::vector<float> prof_ms;
+    std::vector<double> prof_flops;
+
+    ~avexhip_beats() {
+        for (void* p : allocs) (void)hipFree(p);
+        for (auto& kv : bias_tabs) (void)hipFree(kv.second);
+        if (fb) avexhip_fbank_plan_destroy(fb);
+        for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    }
+};
+
+namespace {
+
+struct Table {
+    const avexhip_tensor* t;
+    int n;
+    const avexhip_tensor* find(const std::string& name) const {
+        for (int i = 0; i < n; ++i) {
+            if (!t[i].name) continue;
+            const char* nm = t[i].name;
+            if (strncmp(nm, "backbone.", 9) == 0) nm += 9;
+            if (name == nm) return &t[i];
+        }
+        return nullptr;
+    }
+};
+
+// copy an fp32 tensor to the device (source may be host or device memory)
+int dev_f32(avexhip_beats* h, const Table& tb, const std::string& name, int64_t numel, float** out, bool required = true) {
+    const avexhip_tensor* t = tb.find(name);
+    if (!t) {
+        if (!required) { *out = nullptr; return AVEXHIP_OK; }
+        avexhip_set_error("beats_create: tensor '%s' missing from the weight table", name.c_str());
+        return AVEXHIP_ERR_MISSING;
+    }
+    if (t->numel != numel || !t->data) {
+        avexhip_set_error("beats_create: tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)t->numel, (long long)numel);
+        return AVEXHIP_ERR_INVALID;
+    }
+    float* d = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * (size_t)numel));
+    h->allocs.push_back(d);
+    AVX_HIP_CHECK(hipMemcpy(d, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
+    *out = d;
+    return AVEXHIP_OK;
+}
+
+// fp32 tensor -> half copy at dst (device), via a temporary fp32 device staging buffer
+int dev_half_into(avexhip_beats* h, const Table& tb, const std::string& name, int64_t numel, void* dst) {
+    const avexhip_tensor* t = tb.find(name);
+    if (!t) {
+        avexhip_set_error("beats_create: tensor '%s' missing from the weight table", name.c_str());
+        return AVEXHIP_ERR_MISSING;
+    }
+    if (t->numel != numel || !t->data) {
+        avexhip_set_error("beats_create: tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)t->numel, (long long)numel);
+        return AVEXHIP_ERR_INVALID;
+    }
+    float* tmp = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)numel));
+    hipError_t e = hipMemcpy(tmp, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault);
+    int rc = AVEXHIP_OK;
+    if (e != hipSuccess) {
+        avexhip_set_error("beats_create: copy of '%s' failed: %s", name.c_str(), hipGetErrorString(e));
+        rc = AVEXHIP_ERR_HIP;
+    } else {
+        rc = avx::cast_to_half(tmp, dst, numel, h->dtype, nullptr);
+        if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) {
+            avexhip_set_error("beats_create: cast of '%s' failed", name.c_str());
+            rc = AVEXHIP_ERR_HIP;
+        }
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int dev_half(avexhip_beats* h, const Table& tb, const std::string& name, int64_t numel, void** out) {
+    void* d = nullptr;
+    AVX_HIP_CHECK(hipMalloc(&d, 2 * (size_t)numel));
+    h->allocs.push_back(d);
+    *out = d;
+    return dev_half_into(h, tb, name, numel, d);
+}
+
+int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
+    const avexhip_beats_config& c = h->cfg;
+    const Table tb{tensors, n};
+    const int E = h->E, F = h->F, H = h->H, D = h->D, P = h->P;
+    int rc;
+#define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
+
+    // frontend plan: the checkpoint's persistent buffers when present, else the reference's formulas
+    {
+        const int win = (int)(c.sample_frequency * c.frame_length_ms / 1000.0f);
+        const int hop = (int)(c.sample_frequency * c.frame_shift_ms / 1000.0f);
+        AVX_REQUIRE(win > 0 && win <= 512, "beats_create: frame length %d samples unsupported (n_fft fixed at 512)", win);
+        std::vector<float> hw, hm;
+        const avexhip_tensor* tw = tb.find("fbank.window");
+        const avexhip_tensor* tm = tb.find("fbank.mel_fb");
+        if (tw && tw->numel == win && tw->data) {
+            hw.resize(win);
+            AVX_HIP_CHECK(hipMemcpy(hw.data(), tw->data, sizeof(float) * win, hipMemcpyDefault));
+        } else {
+            default_window(win, hw);
+        }
+        if (tm && tm->numel == (int64_t)257 * c.num_mel_bins && tm->data) {
+            hm.resize((size_t)257 * c.num_mel_bins);
+            AVX_HIP_CHECK(hipMemcpy(hm.data(), tm->data, sizeof(float) * hm.size(), hipMemcpyDefault));
+        } else {
+            default_mel(512, c.num_mel_bins, c.sample_frequency, 20.0f, c.sample_frequency / 2.0f, hm);
+        }
+        avexhip_fbank_config fc;
+        fc.win_length = win; fc.hop_length = hop; fc.n_mels = c.num_mel_bins;
+        fc.input_scale = 32768.0f; fc.preemph = 0.97f; fc.remove_dc = 1; fc.log_floor = 1.1920929e-07f;
+        fc.norm_mean = c.fbank_mean; fc.norm_div = 2.0f * c.fbank_std;
+        h->fb = avexhip_fbank_plan_create(&fc, hw.data(), hm.data());
+        if (!h->fb) return AVEXHIP_ERR_HIP;
+    }
+
+    RC(dev_half(h, tb, "patch_embedding.weight", (int64_t)D * P * P, &h->w_patch));
+    RC(dev_f32(h, tb, "layer_norm.weight", D, &h->ln0_w));
+    RC(dev_f32(h, tb, "layer_norm.bias", D, &h->ln0_b));
+    if (D != E || tb.find("post_extract_proj.weight")) {
+        RC(dev_half(h, tb, "post_extract_proj.weight", (int64_t)E * D, &h->w_post));
+        RC(dev_f32(h, tb, "post_extract_proj.bias", E, &h->b_post));
+    }
+    // positional conv: fold weight-norm and repack
+    {
+        const int K = c.conv_pos, G = c.conv_pos_groups, cg = E / G;
+        float *g = nullptr, *v = nullptr;
+        RC(dev_f32(h, tb, "encoder.pos_conv.0.parametrizations.weight.original0", K, &g));
+        RC(dev_f32(h, tb, "encoder.pos_conv.0.parametrizations.weight.original1", (int64_t)E * cg * K, &v));
+        AVX_HIP_CHECK(hipMalloc(&h->w_pc, 2 * (size_t)E * cg * K));
+        h->allocs.push_back(h->w_pc);
+        RC(avx::posconv_pack(g, v, E, G, K, h->w_pc, h->dtype, nullptr));
+        RC(dev_f32(h, tb, "encoder.pos_conv.0.bias", E, &h->b_pc));
+    }
+    RC(dev_f32(h, tb, "encoder.layer_norm.weight", E, &h->lnE_w));
+    RC(dev_f32(h, tb, "encoder.layer_norm.bias", E, &h->lnE_b));
+
+    h->layers.resize(h->L);
+    for (int i = 0; i < h->L; ++i) {
+        Layer& ly = h->layers[i];
+        const std::string p = "encoder.layers." + std::to_string(i) + ".";
+        const std::string sa = p + "self_attn.";
+        // fused QKV weight [3E, E] and bias [3E]
+        AVX_HIP_CHECK(hipMalloc(&ly.w_qkv, 2 * (size_t)3 * E * E));
+        h->allocs.push_back(ly.w_qkv);
+        RC(dev_half_into(h, tb, sa + "q_proj.weight", (int64_t)E * E, ly.w_qkv));
+        RC(dev_half_into(h, tb, sa + "k_proj.weight", (int64_t)E * E, (char*)ly.w_qkv + 2 * (size_t)E * E));
+        RC(dev_half_into(h, tb, sa + "v_proj.weight", (int64_t)E * E, (char*)ly.w_qkv + 4 * (size_t)E * E));
+        AVX_HIP_CHECK(hipMalloc((void**)&ly.b_qkv, sizeof(float) * 3 * E));
+        h->allocs.push_back(ly.b_qkv);
+        const char* bn[3] = {"q_proj.bias", "k_proj.bias", "v_proj.bias"};
+        for (int j = 0; j < 3; ++j) {
+            const avexhip_tensor* t = tb.find(sa + bn[j]);
+            if (!t || t->numel != E) {
+                avexhip_set_error("beats_create: tensor '%s%s' missing or mis-sized", sa.c_str(), bn[j]);
+                return AVEXHIP_ERR_MISSING;
+            }
+            AVX_HIP_CHECK(hipMemcpy(ly.b_qkv + (size_t)j * E, t->data, sizeof(float) * E, hipMemcpyDefault));
+        }
+        RC(dev_half(h, tb, sa + "out_proj.weight", (int64_t)E * E, &ly.w_o));
+        RC(dev_f32(h, tb, sa + "out_proj.bias", E, &ly.b_o));
+        if (c.gru_rel_pos) {
+            RC(dev_f32(h, tb, sa + "grep_linear.weight", 8 * (E / H), &ly.grep_w));
+            RC(dev_f32(h, tb, sa + "grep_linear.bias", 8, &ly.grep_b));
+            RC(dev_f32(h, tb, sa + "grep_a", H, &ly.grep_a));
+        }
+        RC(dev_f32(h, tb, p + "self_attn_layer_norm.weight", E, &ly.ln1_w));
+        RC(dev_f32(h, tb, p + "self_attn_layer_norm.bias", E, &ly.ln1_b));
+        RC(dev_half(h, tb, p + "fc1.weight", (int64_t)F * E, &ly.w_fc1));
+        RC(dev_f32(h, tb, p + "fc1.bias", F, &ly.b_fc1));
+        RC(dev_half(h, tb, p + "fc2.weight", (int64_t)E * F, &ly.w_fc2));
+        RC(dev_f32(h, tb, p + "fc2.bias", E, &ly.b_fc2));
+        RC(dev_f32(h, tb, p + "final_layer_norm.weight", E, &ly.ln2_w));
+        RC(dev_f32(h, tb, p + "final_layer_norm.bias", E, &ly.ln2_b));
+    }
+    // shared relative-position table (owned by layer 0, backbone.py:100-103)
+    if (c.num_buckets > 0) {
+        const avexhip_tensor* t = tb.find("encoder.layers.0.self_attn.relative_attention_bias.weight");
+        if (!t || t->numel != (int64_t)c.num_buckets * H) {
+            avexhip_set_error("beats_create: relative_attention_bias.weight missing or mis-sized");
+            return AVEXHIP_ERR_MISSING;
+        }
+        h->rel_table.resize((size_t)c.num_buckets * H);
+        AVX_HIP_CHECK(hipMemcpy(h->rel_table.data(), t->data, sizeof(float) * h->rel_table.size(), hipMemcpyDefault));
+    }
+#undef RC
+    AVX_HIP_CHECK(hipDeviceSynchronize());
+    return AVEXHIP_OK;
+}
+
+// [H, 2T-1] Toeplitz rows of compute_bias (backbone.py:475-492), cached per T
+int bias_tab_for(avexhip_beats* h, int T, float** out) {
+    *out = nullptr;
+    if (h->rel_table.empty()) return AVEXHIP_OK;
+    auto it = h->bias_tabs.find(T);
+    if (it != h->bias_tabs.end()) { *out = it->second; return AVEXHIP_OK; }
+    const int H = h->H, W = 2 * T - 1;
+    std::vector<float> host((size_t)H * W);
+    for (int r = 0; r < W; ++r) {
+        const int bucket = avexhip_rel_bucket(r - (T - 1), h->cfg.num_buckets, h->cfg.max_distance);
+        for (int hh = 0; hh < H; ++hh) host[(size_t)hh * W + r] = h->rel_table[(size_t)bucket * H + hh];
+    }
+    float* d = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * host.size()));
+    AVX_HIP_CHECK(hipMemcpy(d, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+    h->bias_tabs[T] = d;
+    *out = d;
+    return AVEXHIP_OK;
+}
+
+struct Ws {
+    char* patches; float* f0; char* h0; float* x; char* xh; float* pre; char* qkv; char* ah; char* hh; float* raw;
+    size_t total;
+};
+
+Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
+    const size_t M = (size_t)Bc * Tt;
+    const size_t PP = (size_t)h->P * h->P;
+    Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    w.patches = take(M * PP * 2);
+    w.f0 = (float*)take(M * h->D * 4);
+    w.h0 = take(M * h->D * 2);
+    w.x = (float*)take(M * h->E * 4);
+    w.xh = take(M * h->E * 2);
+    w.pre = (float*)take(M * h->E * 4);
+    w.qkv = take(M * 3 * h->E * 2);
+    w.ah = take(M * h->E * 2);
+    w.hh = take(M * h->F * 2);
+    w.raw = (float*)take(M * h->E * 4);
+    w.total = off;
+    return w;
+}
+
+struct Prof {
+    avexhip_beats* h;
+    hipStream_t s;
+    size_t next = 0;
+    void begin(const char* name, double flops) {
+        if (!h->profiling) return;
+        if (next == h->recs.size()) {
+            StageRec r;
+            (void)hipEventCreate(&r.e0);
+            (void)hipEventCreate(&r.e1);
+            h->recs.push_back(r);
+        }
+        h->recs[next].name = name;
+        h->recs[next].flops = flops;
+        (void)hipEventRecord(h->recs[next].e0, s);
+    }
+    void end() {
+        if (!h->profiling) return;
+        (void)hipEventRecord(h->recs[next].e1, s);
+        ++next;
+    }
+};
+
+int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int B, int64_t T, int64_t stride, int frames,
+                 const uint8_t* frame_pad, uint32_t hook_mask, float* const* hook_out, int hook_pooled,
+                 float* features_out, float* pooled_out, void* workspace, size_t ws_bytes, hipStream_t s) {
+    const int E = h->E, F = h->F, H = h->H, D = h->D, P = h->P, L = h->L, NM = h->NM, dt = h->dtype;
+    const int nt = frames / P, nf = NM / P;
+    const int Tt = nt * nf;
+    AVX_REQUIRE(Tt >= 1, "beats_forward: input too short (%d frames -> 0 tokens)", frames);
+    AVX_REQUIRE(Tt <= 512, "beats_forward: %d tokens per clip unsupported (max 512, ~10.3 s of audio)", Tt);
+    AVX_REQUIRE(hook_mask == 0 || hook_out, "beats_forward: hook_mask set but hook_out is NULL");
+    AVX_REQUIRE((hook_mask >> (L + 1)) == 0, "beats_forward: hook_mask has bits beyond layer %d", L);
+    for (int i = 0; i <= L; ++i)
+        AVX_REQUIRE(!((hook_mask >> i) & 1u) || hook_out[i], "beats_forward: hook %d selected but hook_out[%d] is NULL", i, i);
+    const int chunk = B < h->chunk ? B : h->chunk;
+    const Ws need = carve(h, nullptr, chunk, Tt);
+    if (!workspace || ws_bytes < need.total) {
+        avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total);
+        return AVEXHIP_ERR_WORKSPACE;
+    }
+    float* bias_tab = nullptr;
+    int rc = bias_tab_for(h, Tt, &bias_tab);
+    if (rc != AVEXHIP_OK) return rc;
+    const avx::FbankDev* fbd = avexhip_fbank_plan_dev(h->fb);
+    Prof prof{h, s};
+#define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
+
+    for (int c0 = 0; c0 < B; c0 += chunk) {
+        const int Bc = (B - c0) < chunk ? (B - c0) : chunk;
+        const int M = Bc * Tt;
+        const Ws w = carve(h, (char*)workspace, chunk, Tt);
+        const uint8_t* pad = frame_pad ? frame_pad + (size_t)c0 * Tt : nullptr;
+        const double Md = (double)M;
+
+        // 1. frontend -> patch-major half tokens [M, P*P]
+        if (wav) {
+            prof.begin("fbank", Md / Tt * frames * (5.0 * 512 * 9 + 2.0 * 504));
+            RC(avx::fbank(*fbd, wav + (size_t)c0 * stride, Bc, T, stride, frames, nullptr, w.patches, P, dt, s));
+            prof.end();
+        } else {
+            prof.begin("patchify", 0.0);
+            RC(avx::patchify(fbank_in + (size_t)c0 * frames * NM, Bc, frames, NM, P, w.patches, dt, s));
+            prof.end();
+        }
+        // 2. patch embedding (Conv2d as GEMM) -> LayerNorm(D) -> post_extract_proj
+        avx::GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = w.patches; g.lda = P * P; g.W = h->w_patch; g.ldw = P * P; g.M = M; g.N = D; g.K = P * P;
+        g.out_f32 = w.f0; g.ldo = D;
+        prof.begin("gemm.patch_embed", 2.0 * Md * D * P * P);
+        RC(avx::gemm(g, dt, s));
+        prof.end();
+        prof.begin("layernorm", 0.0);
+        RC(avx::layernorm(w.f0, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, h->w_post ? nullptr : w.x, E, h->w_post ? w.h0 : w.xh,
+                          h->w_post ? D : E, dt, s));
+        prof.end();
+        if (h->w_post) {
+            memset(&g, 0, sizeof(g));
+            g.A = w.h0; g.lda = D; g.W = h->w_post; g.ldw = D; g.M = M; g.N = E; g.K = D; g.bias = h->b_post;
+            g.out_f32 = w.x; g.ldo = E; g.out_half = w.xh; g.ldh = E; g.row_zero = pad;
+            prof.begin("gemm.post_extract_proj", 2.0 * Md * E * D);
+            RC(avx::gemm(g, dt, s));
+            prof.end();
+        }
+        if ((hook_mask & 1u) && h->w_post) {
+            // the reference's hook holds the tensor that the encoder then zeroes in place at padded tokens
+            // (beats.py:359-361 + backbone.py:169-170), so the tap equals x after masking
+            if (hook_pooled) RC(avx::mean_pool(w.x, Bc, Tt, E, nullptr, hook_out[0] + (size_t)c0 * E, s));
+            else AVX_HIP_CHECK(hipMemcpyAsync(hook_out[0] + (size_t)c0 * Tt * E, w.x, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, s));
+        }
+        // 3. convolutional positional embedding + residual, encoder LayerNorm
+        prof.begin("posconv", 2.0 * Md * E * (E / h->cfg.conv_pos_groups) * h->cfg.conv_pos);
+        RC(avx::posconv(w.xh, w.x, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, w.pre, dt, s));
+        prof.end();
+        prof.begin("layernorm", 0.0);
+        RC(avx::layernorm(w.pre, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, w.x, E, w.xh, E, dt, s));
+        prof.end();
+
+        // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375)
+        for (int i = 0; i < L; ++i) {
+            const Layer& ly = h->layers[i];
+            memset(&g, 0, sizeof(g));
+            g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
+            g.out_half = w.qkv; g.ldh = 3 * E;
+            prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
+            RC(avx::gemm(g, dt, s));
+            prof.end();
+            prof.begin("attention", 4.0 * Md * Tt * E + 2.0 * Md * 8 * (E / H) * H);
+            RC(avx::attention(w.qkv, Bc, Tt, H, bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, pad, w.ah, dt, s));
+            prof.end();
+            memset(&g, 0, sizeof(g));
+            g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o;
+            g.resid = w.x; g.ldr = E; g.alpha = h->alpha; g.out_f32 = w.pre; g.ldo = E;
+            prof.begin("gemm.out_proj", 2.0 * Md * E * E);
+            RC(avx::gemm(g, dt, s));
+            prof.end();
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(w.pre, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, w.x, E, w.xh, E, dt, s));
+            prof.end();
+            memset(&g, 0, sizeof(g));
+            g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
+            g.out_half = w.hh; g.ldh = F;
+            prof.begin("gemm.fc1", 2.0 * Md * F * E);
+            RC(avx::gemm(g, dt, s));
+            prof.end();
+            const bool hooked = (hook_mask >> (i + 1)) & 1u;
+            memset(&g, 0, sizeof(g));
+            g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2;
+            g.resid = w.x; g.ldr = E; g.alpha = h->alpha; g.out_f32 = w.pre; g.ldo = E;
+            if (hooked) {
+                g.out_raw = hook_pooled ? w.raw : hook_out[i + 1] + (size_t)c0 * Tt * E;
+                g.ldraw = E;
+            }
+            prof.begin("gemm.fc2", 2.0 * Md * E * F);
+            RC(avx::gemm(g, dt, s));
+            prof.end();
+            if (hooked && hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, hook_out[i + 1] + (size_t)c0 * E, s));
+            const bool last = i == L - 1;
+            float* xo = (last && features_out) ? features_out + (size_t)c0 * Tt * E : w.x;
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(w.pre, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, s));
+            prof.end();
+            if (last && pooled_out) {
+                prof.begin("mean_pool", 0.0);
+                RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, s));
+                prof.end();
+            }
+        }
+        if (L == 0) {
+            if (features_out) AVX_HIP_CHECK(hipMemcpyAsync(features_out + (size_t)c0 * Tt * E, w.x, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, s));
+            if (pooled_out) RC(avx::mean_pool(w.x, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, s));
+        }
+    }
+#undef RC
+    if (h->profiling) {
+        AVX_HIP_CHECK(hipStreamSynchronize(s));
+        std::map<std::string, std::pair<double, double>> agg;  // name -> (ms, flops)
+        std::vector<std::string> order;
+        for (size_t i = 0; i < prof.next; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, h->recs[i].e0, h->recs[i].e1);
+            if (!agg.count(h->recs[i].name)) order.push_back(h->recs[i].name);
+            agg[h->recs[i].name].first += ms;
+            agg[h->recs[i].name].second += h->recs[i].flops;
+        }
+        h->prof_names = order;
+        h->prof_ms.clear(); h->prof_flops.clear(); h->prof_name_ptrs.clear();
+        for (auto& nm : h->prof_names) {
+            h->prof_ms.push_back((float)agg[nm].first);
+            h->prof_flops.push_back(agg[nm].second);
+        }
+        for (auto& nm : h->prof_names) h->prof_name_ptrs.push_back(nm.c_str());
+    }
+    return AVEXHIP_OK;
+}
+
+}  // namespace
+
+extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, const avexhip_tensor* tensors, int n_tensors) {
+    if (!cfg || !tensors || n_tensors <= 0) {
+        avexhip_set_error("beats_create: null config or empty weight table");
+        return nullptr;
+    }
+    if (avexhip_device_count() <= 0) {
+        avexhip_set_error("beats_create: no HIP device visible (this path has no CPU fallback)");
+        return nullptr;
+    }
+    const avexhip_beats_config& c = *cfg;
+    if (c.encoder_attention_heads <= 0 || c.encoder_embed_dim != 64 * c.encoder_attention_heads) {
+        avexhip_set_error("beats_create: head_dim must be 64 (E=%d, H=%d)", c.encoder_embed_dim, c.encoder_attention_heads);
+        return nullptr;
+    }
+    if (c.encoder_embed_dim % 128 || c.encoder_ffn_embed_dim % 128 || c.embed_dim % 128 ||
+        (c.input_patch_size * c.input_patch_size) % 64 || c.num_mel_bins % c.input_patch_size) {
+        avexhip_set_error("beats_create: dims must be MFMA-tile multiples (E=%d F=%d D=%d P=%d mel=%d)", c.encoder_embed_dim,
+                          c.encoder_ffn_embed_dim, c.embed_dim, c.input_patch_size, c.num_mel_bins);
+        return nullptr;
+    }
+    if (c.conv_pos != 128 || c.encoder_embed_dim / (c.conv_pos_groups > 0 ? c.conv_pos_groups : 1) != 48) {
+        avexhip_set_error("beats_create: positional conv must be k=128 with 48 channels/group (k=%d groups=%d)", c.conv_pos, c.conv_pos_groups);
+        return nullptr;
+    }
+    if (c.encoder_layers < 0 || c.encoder_layers > 31) {
+        avexhip_set_error("beats_create: encoder_layers=%d out of range", c.encoder_layers);
+        return nullptr;
+    }
+    if (c.operand_dtype != AVEXHIP_F16 && c.operand_dtype != AVEXHIP_BF16) {
+        avexhip_set_error("beats_create: unknown operand dtype %d", c.operand_dtype);
+        return nullptr;
+    }
+    avexhip_beats* h = new avexhip_beats();
+    h->cfg = c;
+    h->dtype = c.operand_dtype;
+    h->E = c.encoder_embed_dim; h->F = c.encoder_ffn_embed_dim; h->H = c.encoder_attention_heads;
+    h->L = c.encoder_layers; h->D = c.embed_dim; h->P = c.input_patch_size; h->NM = c.num_mel_bins;
+    h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 64;
+    h->alpha = c.deep_norm ? powf(2.0f * (float)c.encoder_layers, 0.25f) : 1.0f;
+    if (build(h, tensors, n_tensors) != AVEXHIP_OK) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" void avexhip_beats_destroy(avexhip_beats* h) { delete h; }
+
+extern "C" int avexhip_beats_num_tokens(const avexhip_beats* h, int64_t T) {
+    if (!h) return 0;
+    const int frames = avexhip_fbank_num_frames(h->fb, T);
+    return (frames / h->P) * (h->NM / h->P);
+}
+
+extern "C" size_t avexhip_beats_workspace_bytes(const avexhip_beats* h, int B, int64_t T) {
+    if (!h || B <= 0) return 0;
+    const int Tt = avexhip_beats_num_tokens(h, T);
+    if (Tt <= 0) return 0;
+    const int chunk = B < h->chunk ? B : h->chunk;
+    return carve(h, nullptr, chunk, Tt).total;
+}
+
+extern "C" int avexhip_beats_forward(avexhip_beats* h, const float* wav, int B, int64_t T, int64_t wav_stride,
+                                     const uint8_t* frame_pad, uint32_t hook_mask, float* const* hook_out, int hook_pooled,
+                                     float* features_out, float* pooled_out, void* workspace, size_t ws_bytes, void* stream) {
+    AVX_REQUIRE(h && wav, "beats_forward: null handle or input");
+    AVX_REQUIRE(B > 0 && T > 0, "beats_forward: empty input B=%d T=%lld", B, (long long)T);
+    if (wav_stride <= 0) wav_stride = T;
+    const int frames = avexhip_fbank_num_frames(h->fb, T);
+    return forward_impl(h, wav, nullptr, B, T, wav_stride, frames, frame_pad, hook_mask, hook_out, hook_pooled, features_out,
+                        pooled_out, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank, int B, int frames, const uint8_t* frame_pad,
+                                           uint32_t hook_mask, float* const* hook_out, int hook_pooled, float* features_out,
+                                           float* pooled_out, void* workspace, size_t ws_bytes, void* stream) {
+    AVX_REQUIRE(h && fbank, "beats_forward_fbank: null handle or input");
+    AVX_REQUIRE(B > 0 && frames > 0, "beats_forward_fbank: empty input");
+    return forward_impl(h, nullptr, fbank, B, 0, 0, frames, frame_pad, hook_mask, hook_out, hook_pooled, features_out, pooled_out,
+                        workspace, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_beats_set_profiling(avexhip_beats* h, int enabled) {
+    AVX_REQUIRE(h, "set_profiling: null handle");
+    h->profiling = enabled != 0;
+    return AVEXHIP_OK;
+}
+
+extern "C" int avexhip_beats_last_profile(const avexhip_beats* h, const char* const** names, const float** ms,
+                                          const double** flops, int* count) {
+    AVX_REQUIRE(h && names && ms && flops && count, "last_profile: null argument");
+    *names = h->prof_name_ptrs.data();
+    *ms = h->prof_ms.data();
+    *flops = h->prof_flops.data();
+    *count = (int)h->prof_name_ptrs.size();
+    return AVEXHIP_OK;
+}

@@ -1,0 +1,154 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA, LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/avexhip.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Operand-type traits: the same kernels are instantiated for f16 and bf16 MFMA operands.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Half;
+template <> struct Half<_Float16> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ _Float16 from(float x) {
+        // saturate instead of producing inf: activations are O(1..1e3), this only guards outliers
+        return (_Float16)__builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
+    }
+};
+template <> struct Half<__bf16> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ __bf16 from(float x) { return (__bf16)x; }
+};
+
+static __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// exact-erf GELU (reference: torch.nn.functional.gelu default, modules.py:191-200)
+static __device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware, bijective block remap: blocks that share blockIdx % 8 share an XCD (and its L2);
+// give each XCD a contiguous range of logical tiles (cdna guide T1).
+static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side error plumbing
+// ---------------------------------------------------------------------------------------------
+void avexhip_set_error(const char* fmt, ...);
+
+#define AVX_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            avexhip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                      \
+            return AVEXHIP_ERR_HIP;                                                           \
+        }                                                                                     \
+    } while (0)
+
+#define AVX_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            avexhip_set_error(__VA_ARGS__);    \
+            return AVEXHIP_ERR_INVALID;        \
+        }                                      \
+    } while (0)
+
+#define AVX_LAUNCH_CHECK()                                                                   \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            avexhip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),     \
+                              __FILE__, __LINE__);                                           \
+            return AVEXHIP_ERR_HIP;                                                          \
+        }                                                                                    \
+    } while (0)
+
+// Internal launchers shared between translation units (all return AVEXHIP_* codes).
+namespace avx {
+
+struct GemmArgs {
+    const void* A; int64_t lda;
+    const void* W; int64_t ldw;
+    int M, N, K;
+    const float* bias;
+    const float* resid; int64_t ldr; float alpha;
+    int gelu;
+    float* out_f32; int64_t ldo;
+    void* out_half; int64_t ldh;
+    float* out_raw; int64_t ldraw;
+    const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to out_f32/out_half
+    int variant;
+};
+int gemm(const GemmArgs& a, int dtype, hipStream_t s);
+int layernorm(const float* in, int64_t ld_in, const float* w, const float* b, float eps, int M, int C,
+              float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s);
+int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s);
+int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s);
+int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s);
+int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
+              const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
+              hipStream_t s);
+int posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed, int dtype,
+                 hipStream_t s);
+int posconv(const void* x_half, const float* x_f32, const void* w_packed, const float* bias, int B, int T,
+            int E, int groups, int K, float* out, int dtype, hipStream_t s);
+
+struct FbankDev {
+    int win, hop, n_mels;
+    float input_scale, preemph, log_floor, norm_mean, norm_div;
+    int remove_dc;
+    const float* window;      // [win]
+    const float2* twiddle;    // [512] (cos, -sin)(2 pi k / 512)
+    const int* mel_start;     // [n_mels] first FFT bin with non-zero weight
+    const int* mel_len;       // [n_mels]
+    const int* mel_off;       // [n_mels] offset into mel_w
+    const float* mel_w;       // packed non-zero weights
+};
+// out_f32: [B, frames, n_mels] or NULL; out_patch: half patch-major [B, frames/P, n_mels/P, P*P] or NULL
+int fbank(const FbankDev& fb, const float* wav, int B, int64_t T, int64_t stride, int frames,
+          float* out_f32, void* out_patch, int patch, int dtype, hipStream_t s);
+// fbank [B, frames, n_mels] fp32 -> half patch-major (used by forward_fbank)
+int patchify(const float* fbank, int B, int frames, int n_mels, int patch, void* out_patch, int dtype,
+             hipStream_t s);
+
+}  // namespace avx

@@ -1,0 +1,225 @@
+// HBM-bound helpers of the BEATs path: dtype casts, LayerNorm (fp32 stats, fp32 + half outputs),
+// mean pooling over tokens, fbank -> patch-major half layout.
+//
+// Reference call sites: nn.LayerNorm at beats.py:275,353 (512-wide, patch features) and
+// backbone.py:106,176-177 / :294,362 / :302,373 (768-wide); features.mean(dim=1) at README:80 and
+// beats_model.py:275; Conv2d patch geometry at beats.py:263-269,350-352.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void cast_to_half_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        const f32x4 v = *(const f32x4*)(in + i);
+        typename Half<T>::v4 h;
+        h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]);
+        h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+        *(typename Half<T>::v4*)(out + i) = h;
+    }
+    // tail (n % 4) handled by the first threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t j = (n & ~(int64_t)3) + threadIdx.x;
+        out[j] = Half<T>::from(in[j]);
+    }
+}
+
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (float)in[i];
+}
+
+// One wave per row; lanes hold float4 slices lane, lane+64, ... (C <= 1024).  Two-pass statistics in
+// registers (mean, then centred variance) like torch's CPU LayerNorm.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int64_t ld_in,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, int M,
+                                                        int C, float* __restrict__ out_f32, int64_t ldo,
+                                                        T* __restrict__ out_h, int64_t ldh) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;  // float4 per row
+    const float* x = in + (int64_t)row * ld_in;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            v[i] = *(const f32x4*)(x + idx * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            v[i] -= mean;
+            q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const f32x4 ww = *(const f32x4*)(w + idx * 4);
+            const f32x4 bb = *(const f32x4*)(b + idx * 4);
+            const f32x4 y = v[i] * rstd * ww + bb;
+            if (out_f32) *(f32x4*)(out_f32 + (int64_t)row * ldo + idx * 4) = y;
+            if (out_h) {
+                typename Half<T>::v4 h;
+                h[0] = Half<T>::from(y[0]); h[1] = Half<T>::from(y[1]);
+                h[2] = Half<T>::from(y[2]); h[3] = Half<T>::from(y[3]);
+                *(typename Half<T>::v4*)(out_h + (int64_t)row * ldh + idx * 4) = h;
+            }
+        }
+    }
+}
+
+// in [B,T,C] -> out [B,C]; block (64 columns x 4 token phases), grid (C/64, B).
+// With frame_pad: masked mean over non-padded tokens (beats_model.py:269-273).
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ in, int T, int C,
+                                                        const uint8_t* __restrict__ frame_pad,
+                                                        float* __restrict__ out) {
+    __shared__ float part[4][64];
+    __shared__ int cnt[4];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    float s = 0.f;
+    int n = 0;
+    if (c < C) {
+        for (int t = ph; t < T; t += 4) {
+            const bool pad = frame_pad && frame_pad[(int64_t)b * T + t];
+            if (!pad) {
+                s += in[((int64_t)b * T + t) * C + c];
+                ++n;
+            }
+        }
+    }
+    part[ph][threadIdx.x & 63] = s;
+    if ((threadIdx.x & 63) == 0) cnt[ph] = n;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+        const float tot = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        int nn = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (nn < 1) nn = 1;
+        out[(int64_t)b * C + c] = tot / (float)nn;
+    }
+}
+
+// fbank [B, frames, n_mels] fp32 -> patches [B, nt*nf, P*P] half with token = tp*nf + fq,
+// element = (frame % P) * P + (mel % P)   (Conv2d(1,D,P,stride=P) im2col, beats.py:349-352).
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ fb, int frames, int n_mels, int P, int nt,
+                                int nf, T* __restrict__ out, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pp = P * P;
+    const int e = (int)(i % pp);
+    const int64_t tok = i / pp;
+    const int fq = (int)(tok % nf);
+    const int tp = (int)((tok / nf) % nt);
+    const int64_t b = tok / ((int64_t)nf * nt);
+    const int fr = tp * P + e / P, mel = fq * P + e % P;
+    out[i] = Half<T>::from(fb[(b * frames + fr) * n_mels + mel]);
+}
+
+}  // namespace
+
+namespace avx {
+
+int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && out && n >= 0, "cast_to_half: bad arguments");
+    if (n == 0) return AVEXHIP_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == AVEXHIP_F16)
+        hipLaunchKernelGGL(cast_to_half_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, in, (_Float16*)out, n);
+    else if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(cast_to_half_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, in, (__bf16*)out, n);
+    else {
+        avexhip_set_error("cast_to_half: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && out && n >= 0, "cast_to_f32: bad arguments");
+    if (n == 0) return AVEXHIP_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == AVEXHIP_F16)
+        hipLaunchKernelGGL(cast_to_f32_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16*)in, out, n);
+    else if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(cast_to_f32_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)in, out, n);
+    else {
+        avexhip_set_error("cast_to_f32: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int layernorm(const float* in, int64_t ld_in, const float* w, const float* b, float eps, int M, int C,
+              float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && w && b, "layernorm: null input");
+    AVX_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "layernorm: C=%d must be a multiple of 4 and <= 1024", C);
+    AVX_REQUIRE(ld_in % 4 == 0 && (!out_f32 || ldo % 4 == 0) && (!out_half || ldh % 4 == 0),
+                "layernorm: leading dims must be multiples of 4");
+    AVX_REQUIRE(out_f32 || out_half, "layernorm: no output");
+    if (M <= 0) return AVEXHIP_OK;
+    const dim3 grid((M + 3) / 4);
+    if (dtype == AVEXHIP_F16)
+        hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, s, in, ld_in, w, b, eps, M, C, out_f32, ldo, (_Float16*)out_half, ldh);
+    else if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, s, in, ld_in, w, b, eps, M, C, out_f32, ldo, (__bf16*)out_half, ldh);
+    else {
+        avexhip_set_error("layernorm: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s) {
+    AVX_REQUIRE(in && out && B > 0 && T > 0 && C > 0, "mean_pool: bad arguments");
+    hipLaunchKernelGGL(mean_pool_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, in, T, C, frame_pad, out);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int patchify(const float* fbank, int B, int frames, int n_mels, int patch, void* out_patch, int dtype,
+             hipStream_t s) {
+    AVX_REQUIRE(fbank && out_patch && patch > 0, "patchify: bad arguments");
+    const int nt = frames / patch, nf = n_mels / patch;
+    const int64_t total = (int64_t)B * nt * nf * patch * patch;
+    if (total == 0) return AVEXHIP_OK;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == AVEXHIP_F16)
+        hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, dim3(256), 0, s, fbank, frames, n_mels, patch, nt, nf, (_Float16*)out_patch, total);
+    else if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(patchify_kernel<__bf16>, grid, dim3(256), 0, s, fbank, frames, n_mels, patch, nt, nf, (__bf16*)out_patch, total);
+    else {
+        avexhip_set_error("patchify: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+}  // namespace avx

@@ -1,0 +1,199 @@
+// Convolutional positional embedding of the BEATs encoder as an implicit-GEMM MFMA kernel (gfx950).
+//
+// Restates backbone.py:52-68 (weight-normed grouped Conv1d(768, 768, k=128, pad=64, groups=16),
+// SamePad drops the last output, nn.GELU) and :172-174 (x = x + pos_conv(x)).
+// Per (clip, group): out[t, o] = sum_{tap<128, c<48} X[t + tap - 64, c] * W[o, tap, c], i.e. a
+// [T x 6144] x [6144 x 48] product whose A-matrix is a sliding window over a (T+127) x 48 slab.
+//
+// One 512-thread workgroup per (clip, group): the group's slab (zero-padded, 96-byte rows — the
+// 16x16x32 fragment reads are bank-conflict free at that stride) is staged in LDS once; each wave
+// owns 64 tokens x 48 channels = 12 accumulators.  The MFMA "A" operand is the WEIGHT fragment
+// (rows = output channel, streamed from L2 with a register double buffer), the "B" operand the slab
+// fragment, so each lane ends with 4 consecutive channels of one token and the epilogue
+// (bias, exact GELU, residual add) is float4 traffic.  K is ordered (tap, c) with c fastest: 48 is a
+// multiple of 8, so an 8-element operand fragment never straddles a tap and is one 16-byte LDS read;
+// the (tap, c) offsets of the three 32-wide chunks of a tap PAIR (96 = 3 x 32) are per-lane constants.
+#include "common.h"
+
+namespace {
+
+constexpr int CG = 48;            // channels per group
+constexpr int KT = 128;           // taps
+constexpr int PAD = KT / 2;
+constexpr int TMAX = 512;
+constexpr int SLAB_ROWS = TMAX + KT;              // 640
+constexpr int SLAB_BYTES = SLAB_ROWS * CG * 2;    // 61440
+constexpr int KTOT = KT * CG;                     // 6144
+
+template <typename T>
+__global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf,
+                                                      const T* __restrict__ wp, const float* __restrict__ bias,
+                                                      int Tn, int E, int G, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char slab[];
+    typedef typename Half<T>::v8 v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x % G, b = blockIdx.x / G;
+    const T* xg = xh + (int64_t)b * Tn * E + g * CG;
+
+    // ---- stage the zero-padded slab: slab row r <-> token r - 64 -------------------------------
+    for (int idx = tid; idx < SLAB_ROWS * 6; idx += 512) {
+        const int r = idx / 6, c = idx - r * 6;
+        const int t = r - PAD;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < Tn) v = *(const uint4*)(xg + (int64_t)t * E + c * 8);
+        *(uint4*)(slab + r * (CG * 2) + c * 16) = v;
+    }
+    __syncthreads();
+
+    const int t16 = lane & 15, g4 = lane >> 4;
+    const int tw0 = wave * 64;
+    if (tw0 >= Tn) return;  // whole wave beyond the sequence (no further barriers below)
+
+    // per-lane constants for the three chunks of a tap pair
+    int xoff[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const int off = 32 * v + 8 * g4;
+        xoff[v] = (off / CG) * (CG * 2) + (off % CG) * 2;
+    }
+    const char* xbase = slab + (tw0 + t16) * (CG * 2);
+    // weight rows: group g, out channel ot*16 + t16(lane&15 = row of A operand)
+    const T* wbase = wp + ((int64_t)g * CG + t16) * KTOT + 8 * g4;
+
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[ot][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    v8 wcur[3][3], wnext[3][3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) wcur[v][ot] = *(const v8*)(wbase + (int64_t)ot * 16 * KTOT + 32 * v);
+
+    for (int u = 0; u < KT / 2; ++u) {
+        if (u + 1 < KT / 2) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int ot = 0; ot < 3; ++ot)
+                    wnext[v][ot] = *(const v8*)(wbase + (int64_t)ot * 16 * KTOT + 96 * (u + 1) + 32 * v);
+        }
+        const char* xu = xbase + u * (2 * CG * 2);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            v8 xfr[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) xfr[tt] = *(const v8*)(xu + tt * 16 * (CG * 2) + xoff[v]);
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[ot][tt] = mfma16(wcur[v][ot], xfr[tt], acc[ot][tt]);
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot) wcur[v][ot] = wnext[v][ot];
+    }
+
+    // ---- epilogue: + bias, exact GELU, + residual (backbone.py:68,174) --------------------------
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int t = tw0 + tt * 16 + t16;
+        if (t >= Tn) continue;
+        const int64_t rowoff = ((int64_t)b * Tn + t) * E + g * CG;
+#pragma unroll
+        for (int ot = 0; ot < 3; ++ot) {
+            const int n = ot * 16 + 4 * g4;
+            f32x4 v = acc[ot][tt] + *(const f32x4*)(bias + g * CG + n);
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+            const f32x4 r = *(const f32x4*)(xf + rowoff + n);
+            *(f32x4*)(out + rowoff + n) = r + v;
+        }
+    }
+}
+
+// norm[k] = || v[:, :, k] ||_2 over (out, in)   (weight_norm dim=2, backbone.py:67)
+__global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restrict__ v, int n_rows, int K,
+                                                           float* __restrict__ norm) {
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+        const float x = v[(int64_t)r * K + k];
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) norm[k] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// out[g][o][tap][c] = half( v[g*cg+o][c][tap] * (gk[tap] / norm[tap]) )
+template <typename T>
+__global__ void posconv_pack_kernel(const float* __restrict__ v, const float* __restrict__ gk,
+                                    const float* __restrict__ norm, int E, int cg, int K, T* __restrict__ out) {
+    const int64_t total = (int64_t)E * cg * K;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int tap = (int)((i / cg) % K);
+    const int64_t o = i / ((int64_t)cg * K);  // global out channel = g*cg + o_local
+    const float w = v[(o * cg + c) * K + tap] * (gk[tap] / norm[tap]);
+    out[i] = Half<T>::from(w);
+}
+
+}  // namespace
+
+namespace avx {
+
+int posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed, int dtype,
+                 hipStream_t s) {
+    AVX_REQUIRE(g && v && w_packed, "posconv_pack: null argument");
+    AVX_REQUIRE(groups > 0 && E % groups == 0 && K > 0, "posconv_pack: bad shape E=%d groups=%d K=%d", E, groups, K);
+    const int cg = E / groups;
+    float* norm = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&norm, sizeof(float) * K));
+    hipLaunchKernelGGL(posconv_norm_kernel, dim3(K), dim3(256), 0, s, v, E * cg, K, norm);
+    const int64_t total = (int64_t)E * cg * K;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(posconv_pack_kernel<__bf16>, grid, dim3(256), 0, s, v, g, norm, E, cg, K, (__bf16*)w_packed);
+    else
+        hipLaunchKernelGGL(posconv_pack_kernel<_Float16>, grid, dim3(256), 0, s, v, g, norm, E, cg, K, (_Float16*)w_packed);
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(norm);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        avexhip_set_error("posconv_pack: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        return AVEXHIP_ERR_HIP;
+    }
+    return AVEXHIP_OK;
+}
+
+int posconv(const void* x_half, const float* x_f32, const void* w_packed, const float* bias, int B, int T,
+            int E, int groups, int K, float* out, int dtype, hipStream_t s) {
+    AVX_REQUIRE(x_half && x_f32 && w_packed && bias && out, "posconv: null argument");
+    AVX_REQUIRE(groups > 0 && E % groups == 0 && E / groups == CG && K == KT,
+                "posconv: only %d channels/group and %d taps are built (got E=%d groups=%d K=%d)", CG, KT, E, groups, K);
+    AVX_REQUIRE(B > 0 && T > 0 && T <= TMAX, "posconv: T=%d tokens unsupported (1..%d)", T, TMAX);
+    if (dtype == AVEXHIP_BF16) {
+        static bool set = false;
+        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES)); set = true; }
+        hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * groups), dim3(512), SLAB_BYTES, s, (const __bf16*)x_half, x_f32,
+                           (const __bf16*)w_packed, bias, T, E, groups, out);
+    } else if (dtype == AVEXHIP_F16) {
+        static bool set = false;
+        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES)); set = true; }
+        hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * groups), dim3(512), SLAB_BYTES, s, (const _Float16*)x_half, x_f32,
+                           (const _Float16*)w_packed, bias, T, E, groups, out);
+    } else {
+        avexhip_set_error("posconv: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+}  // namespace avx

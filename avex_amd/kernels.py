@@ -1,0 +1,368 @@
+"""Thin torch-tensor front ends over the C ABI (device pointers + current stream in, tensors out).
+
+PyTorch is plumbing here: it owns HBM allocations and streams; all arithmetic happens in
+libavexhip.so.  Every function raises ``AvexHipError`` if the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import AvexHipError, BeatsConfig, FbankConfig, GemmArgs, Tensor, check, dtype_code, lib
+
+F32_EPS = 1.1920929e-07
+
+
+def _stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else int(t.data_ptr())
+
+
+def half_torch_dtype(code: int) -> torch.dtype:
+    return torch.float16 if code == _capi.F16 else torch.bfloat16
+
+
+def _need_cuda(*ts: Optional[torch.Tensor]) -> None:
+    _capi.require_gpu()
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise AvexHipError("avex_amd kernels need CUDA(HIP) tensors; got a CPU tensor (no CPU fallback)")
+
+
+# ---------------------------------------------------------------------------------------
+# Frontend
+# ---------------------------------------------------------------------------------------
+def povey_window(win_length: int = 400) -> np.ndarray:
+    """``hann(win, periodic=False) ** 0.85`` (reference: beats.py:75), fp32."""
+    n = np.arange(win_length, dtype=np.float64)
+    hann = (0.5 - 0.5 * np.cos(2.0 * math.pi * n / (win_length - 1))).astype(np.float32)
+    return np.power(hann, np.float32(0.85)).astype(np.float32)
+
+
+def hann_window(win_length: int = 400) -> np.ndarray:
+    n = np.arange(win_length, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * math.pi * n / (win_length - 1))).astype(np.float32)
+
+
+def kaldi_mel_filterbank(n_mels: int = 128, n_fft: int = 512, sample_rate: float = 16000.0,
+                         low_freq: float = 20.0, high_freq: float = 0.0) -> np.ndarray:
+    """Triangular kaldi mel bank ``[n_fft//2+1, n_mels]`` (reference: beats.py:82-118), fp32."""
+    if high_freq <= 0.0:
+        high_freq = sample_rate / 2.0 + high_freq
+    nb = n_fft // 2
+    mel_low = 1127.0 * math.log(1.0 + low_freq / 700.0)
+    mel_high = 1127.0 * math.log(1.0 + high_freq / 700.0)
+    delta = np.float32((mel_high - mel_low) / (n_mels + 1))
+    idx = np.arange(n_mels, dtype=np.float32)[:, None]
+    left = np.float32(mel_low) + idx * delta
+    center = np.float32(mel_low) + (idx + np.float32(1.0)) * delta
+    right = np.float32(mel_low) + (idx + np.float32(2.0)) * delta
+    freqs = np.float32(sample_rate / n_fft) * np.arange(nb, dtype=np.float32)
+    mel = (np.float32(1127.0) * np.log(np.float32(1.0) + freqs / np.float32(700.0)))[None, :].astype(np.float32)
+    fb = np.maximum(np.float32(0.0), np.minimum((mel - left) / (center - left), (right - mel) / (right - center)))
+    fb = np.pad(fb.astype(np.float32), ((0, 0), (0, 1)))
+    return np.ascontiguousarray(fb.T)
+
+
+class FbankPlan:
+    """Fused log-mel frontend (reference: ``_BatchedFbank`` + ``BEATs.preprocess``)."""
+
+    def __init__(self, *, win_length: int = 400, hop_length: int = 160, n_mels: int = 128,
+                 input_scale: float = 32768.0, preemph: float = 0.97, remove_dc: bool = True,
+                 log_floor: float = F32_EPS, norm_mean: float = 0.0, norm_div: float = 1.0,
+                 window: Optional[np.ndarray] = None, mel_fb: Optional[np.ndarray] = None) -> None:
+        _capi.require_gpu()
+        self.win_length, self.hop_length, self.n_mels = win_length, hop_length, n_mels
+        window = povey_window(win_length) if window is None else np.ascontiguousarray(window, np.float32)
+        mel_fb = kaldi_mel_filterbank(n_mels) if mel_fb is None else np.ascontiguousarray(mel_fb, np.float32)
+        if window.shape != (win_length,) or mel_fb.shape != (257, n_mels):
+            raise ValueError(f"window must be [{win_length}] and mel_fb [257,{n_mels}]")
+        cfg = FbankConfig(win_length, hop_length, n_mels, input_scale, preemph, int(remove_dc), log_floor,
+                          norm_mean, norm_div)
+        self._h = lib().avexhip_fbank_plan_create(C.byref(cfg), window.ctypes.data, mel_fb.ctypes.data)
+        if not self._h:
+            raise AvexHipError(f"fbank_plan_create failed: {_capi.last_error()}")
+
+    def num_frames(self, T: int) -> int:
+        return int(lib().avexhip_fbank_num_frames(self._h, T))
+
+    def __call__(self, wav: torch.Tensor) -> torch.Tensor:
+        _need_cuda(wav)
+        if wav.dim() != 2 or wav.dtype != torch.float32:
+            raise ValueError("wav must be a [B, T] float32 tensor")
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, T = wav.shape
+        frames = self.num_frames(T)
+        out = torch.empty((B, frames, self.n_mels), dtype=torch.float32, device=wav.device)
+        if B == 0 or frames == 0:
+            return out
+        check(lib().avexhip_fbank_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(out), _stream()), "fbank_forward")
+        return out
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().avexhip_fbank_plan_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ---------------------------------------------------------------------------------------
+# Building blocks (used by the parity tests; the encoder handle calls the same launchers in C++)
+# ---------------------------------------------------------------------------------------
+def to_half(x: torch.Tensor, dtype="f16") -> torch.Tensor:
+    _need_cuda(x)
+    code = dtype_code(dtype)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=half_torch_dtype(code), device=x.device)
+    check(lib().avexhip_cast_f32_to_half(_ptr(x), _ptr(out), x.numel(), code, _stream()), "cast_f32_to_half")
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    code = _capi.F16 if x.dtype == torch.float16 else _capi.BF16
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().avexhip_cast_half_to_f32(_ptr(x), _ptr(out), x.numel(), code, _stream()), "cast_half_to_f32")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+         resid: Optional[torch.Tensor] = None, alpha: float = 1.0, gelu: bool = False,
+         out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0
+         ) -> Dict[str, torch.Tensor]:
+    """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm)."""
+    _need_cuda(a, w)
+    if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("a and w must both be float16 or bfloat16")
+    code = _capi.F16 if a.dtype == torch.float16 else _capi.BF16
+    a, w = a.contiguous(), w.contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    res: Dict[str, torch.Tensor] = {}
+    args = GemmArgs()
+    args.A, args.lda, args.W, args.ldw = _ptr(a), K, _ptr(w), K
+    args.M, args.N, args.K = M, N, K
+    args.bias = _ptr(bias)
+    if resid is not None:
+        resid = resid.contiguous()
+        args.resid, args.ldr = _ptr(resid), N
+    args.alpha, args.gelu, args.variant = alpha, int(gelu), variant
+    if out_f32:
+        res["f32"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        args.out_f32, args.ldo = _ptr(res["f32"]), N
+    if out_half:
+        res["half"] = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        args.out_half, args.ldh = _ptr(res["half"]), N
+    if out_raw:
+        res["raw"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        args.out_raw, args.ldraw = _ptr(res["raw"]), N
+    check(lib().avexhip_gemm(C.byref(args), code, _stream()), "gemm")
+    return res
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, half_dtype="f16"
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_cuda(x, weight, bias)
+    code = dtype_code(half_dtype)
+    x = x.contiguous()
+    M, Cc = x.shape
+    o32 = torch.empty_like(x)
+    oh = torch.empty((M, Cc), dtype=half_torch_dtype(code), device=x.device)
+    check(lib().avexhip_layernorm(_ptr(x), Cc, _ptr(weight), _ptr(bias), eps, M, Cc, _ptr(o32), Cc, _ptr(oh), Cc,
+                                  code, _stream()), "layernorm")
+    return o32, oh
+
+
+def attention(qkv: torch.Tensor, B: int, T: int, H: int, bias_tab: Optional[torch.Tensor],
+              grep_w: Optional[torch.Tensor], grep_b: Optional[torch.Tensor], grep_a: Optional[torch.Tensor],
+              key_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(qkv)
+    code = _capi.F16 if qkv.dtype == torch.float16 else _capi.BF16
+    qkv = qkv.contiguous()
+    out = torch.empty((B * T, H * 64), dtype=qkv.dtype, device=qkv.device)
+    check(lib().avexhip_attention(_ptr(qkv), B, T, H, _ptr(bias_tab), _ptr(grep_w), _ptr(grep_b), _ptr(grep_a),
+                                  _ptr(key_pad), _ptr(out), code, _stream()), "attention")
+    return out
+
+
+def posconv_pack(g: torch.Tensor, v: torch.Tensor, groups: int, half_dtype="f16") -> torch.Tensor:
+    _need_cuda(g, v)
+    code = dtype_code(half_dtype)
+    E, cg, K = v.shape
+    out = torch.empty((E * cg * K,), dtype=half_torch_dtype(code), device=v.device)
+    check(lib().avexhip_posconv_pack(_ptr(g.contiguous()), _ptr(v.contiguous()), E, groups, K, _ptr(out), code,
+                                     _stream()), "posconv_pack")
+    return out
+
+
+def posconv(x_half: torch.Tensor, x_f32: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, groups: int,
+            K: int = 128) -> torch.Tensor:
+    _need_cuda(x_half, x_f32, w_packed, bias)
+    code = _capi.F16 if x_half.dtype == torch.float16 else _capi.BF16
+    B, T, E = x_f32.shape
+    out = torch.empty_like(x_f32)
+    check(lib().avexhip_posconv(_ptr(x_half.contiguous()), _ptr(x_f32.contiguous()), _ptr(w_packed), _ptr(bias), B, T, E,
+                                groups, K, _ptr(out), code, _stream()), "posconv")
+    return out
+
+
+def mean_pool(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    B, T, Cc = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    check(lib().avexhip_mean_pool(_ptr(x.contiguous()), B, T, Cc, _ptr(out), _stream()), "mean_pool")
+    return out
+
+
+def rel_bucket(rel: int, num_buckets: int = 320, max_distance: int = 800) -> int:
+    """Host-only helper (no GPU needed)."""
+    return int(lib().avexhip_rel_bucket(int(rel), int(num_buckets), int(max_distance)))
+
+
+# ---------------------------------------------------------------------------------------
+# Encoder handle
+# ---------------------------------------------------------------------------------------
+_CFG_FIELDS = ("input_patch_size", "embed_dim", "encoder_layers", "encoder_embed_dim", "encoder_ffn_embed_dim",
+               "encoder_attention_heads", "conv_pos", "conv_pos_groups", "num_buckets", "max_distance")
+
+
+def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0) -> BeatsConfig:
+    if bool(cfg.get("layer_norm_first", False)):
+        raise AvexHipError("layer_norm_first=True (pre-LN) BEATs variants are not built; only the post-LN/DeepNorm branch")
+    if str(cfg.get("activation_fn", "gelu")) != "gelu":
+        raise AvexHipError(f"activation_fn={cfg.get('activation_fn')!r} is not built; only exact-erf gelu")
+    if bool(cfg.get("conv_bias", False)):
+        raise AvexHipError("conv_bias=True patch embedding is not built")
+    c = BeatsConfig()
+    for f in _CFG_FIELDS:
+        setattr(c, f, int(cfg[f]))
+    if not bool(cfg.get("relative_position_embedding", True)):
+        c.num_buckets = 0
+    c.gru_rel_pos = int(bool(cfg.get("gru_rel_pos", True)))
+    c.deep_norm = int(bool(cfg.get("deep_norm", True)))
+    c.num_mel_bins = int(cfg.get("num_mel_bins", 128))
+    c.sample_frequency = float(cfg.get("sample_frequency", 16000.0))
+    c.frame_length_ms = float(cfg.get("frame_length", 25.0))
+    c.frame_shift_ms = float(cfg.get("frame_shift", 10.0))
+    c.fbank_mean = float(cfg.get("fbank_mean", 15.41663))
+    c.fbank_std = float(cfg.get("fbank_std", 6.55582))
+    c.operand_dtype = dtype_code(operand_dtype)
+    c.max_chunk_clips = int(max_chunk_clips)
+    return c
+
+
+class BeatsEncoder:
+    """Owns an ``avexhip_beats`` handle built from an fp32 state dict (torch tensors or numpy arrays,
+    host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
+
+    def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype="f16",
+                 max_chunk_clips: int = 0) -> None:
+        _capi.require_gpu()
+        self.cfg = dict(cfg)
+        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips)
+        self.E = int(cfg["encoder_embed_dim"])
+        self.L = int(cfg["encoder_layers"])
+        keep = []  # keep arrays alive during the call
+        entries = []
+        for name, val in state.items():
+            if isinstance(val, torch.Tensor):
+                t = val.detach()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    t = t.float().contiguous()
+                keep.append(t)
+                entries.append((name.encode(), int(t.data_ptr()), t.numel()))
+            else:
+                a = np.ascontiguousarray(val, np.float32)
+                keep.append(a)
+                entries.append((name.encode(), int(a.ctypes.data), a.size))
+        arr = (Tensor * len(entries))()
+        for i, (n, p, k) in enumerate(entries):
+            arr[i].name, arr[i].data, arr[i].numel = n, p, k
+        self._h = lib().avexhip_beats_create(C.byref(self.ccfg), arr, len(entries))
+        del keep
+        if not self._h:
+            raise AvexHipError(f"beats_create failed: {_capi.last_error()}")
+        self._ws: Optional[torch.Tensor] = None
+
+    def num_tokens(self, T: int) -> int:
+        return int(lib().avexhip_beats_num_tokens(self._h, T))
+
+    def _workspace(self, B: int, T: int, device) -> torch.Tensor:
+        need = int(lib().avexhip_beats_workspace_bytes(self._h, B, T))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward(self, wav: torch.Tensor, *, hook_layers: Sequence[int] = (), hook_pooled: bool = False,
+                want_features: bool = True, want_pooled: bool = False, frame_pad: Optional[torch.Tensor] = None
+                ) -> Dict[str, object]:
+        _need_cuda(wav)
+        if wav.dim() != 2:
+            raise ValueError("wav must be [B, T]")
+        if wav.dtype != torch.float32:
+            wav = wav.float()
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, T = wav.shape
+        Tt = self.num_tokens(T)
+        if B == 0 or Tt <= 0:
+            raise AvexHipError(f"input too short: {T} samples give {Tt} tokens")
+        dev = wav.device
+        ws = self._workspace(B, T, dev)
+        hooks: Dict[int, torch.Tensor] = {}
+        ptrs = (C.c_void_p * (self.L + 1))()
+        mask = 0
+        for i in sorted(set(int(x) for x in hook_layers)):
+            if not 0 <= i <= self.L:
+                raise ValueError(f"hook layer {i} out of range 0..{self.L}")
+            shape = (B, self.E) if hook_pooled else (B, Tt, self.E)
+            hooks[i] = torch.empty(shape, dtype=torch.float32, device=dev)
+            ptrs[i] = int(hooks[i].data_ptr())
+            mask |= 1 << i
+        feats = torch.empty((B, Tt, self.E), dtype=torch.float32, device=dev) if want_features else None
+        pooled = torch.empty((B, self.E), dtype=torch.float32, device=dev) if want_pooled else None
+        pad = None
+        if frame_pad is not None:
+            pad = frame_pad.to(device=dev, dtype=torch.uint8).contiguous()
+            if pad.shape != (B, Tt):
+                raise ValueError(f"frame_pad must be [B={B}, T'={Tt}], got {tuple(pad.shape)}")
+        check(lib().avexhip_beats_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(pad), mask, ptrs,
+                                          int(hook_pooled), _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
+              "beats_forward")
+        return {"features": feats, "pooled": pooled, "hooks": hooks, "tokens": Tt}
+
+    def set_profiling(self, enabled: bool) -> None:
+        check(lib().avexhip_beats_set_profiling(self._h, int(enabled)), "set_profiling")
+
+    def last_profile(self) -> List[Tuple[str, float, float]]:
+        names = C.POINTER(C.c_char_p)()
+        ms = C.POINTER(C.c_float)()
+        fl = C.POINTER(C.c_double)()
+        n = C.c_int(0)
+        check(lib().avexhip_beats_last_profile(self._h, C.byref(names), C.byref(ms), C.byref(fl), C.byref(n)), "last_profile")
+        return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().avexhip_beats_destroy(self._h)
+            self._h = None
+        self._ws = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -1,0 +1,185 @@
+"""Deterministic synthetic weights and clips (no dependence on torch/numpy RNG streams).
+
+There is no network on either box, so neither the official checkpoints
+(``hf://EarthSpeciesProject/...``) nor real audio are reachable.  Everything that
+needs "a BEATs checkpoint" (bench, smoke, parity tests, golden generation) uses the
+closed-form generator below: a counter-based PRNG (splitmix64 keyed by tensor name
+and flat element index, Box-Muller to N(0,1)) scaled per tensor to the reference's
+own init statistics (reference init code:
+``avex/models/beats/backbone.py:59-62,109-122,577-600``).  The same generator runs
+in this container (to load the reference for goldens) and on the GPU box.
+
+State-dict keys follow the reference wrapper exactly (``backbone.`` prefix,
+``avex/models/beats_model.py:160,189`` and SURVEY.md §8 a13).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _uniform01(key: int, n: int, stream: int) -> np.ndarray:
+    """n doubles in (0,1): element i depends only on (key, stream, i)."""
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = np.uint64(key) ^ (np.uint64(stream) * np.uint64(0xD1B54A32D192ED03))
+        bits = _splitmix64(_splitmix64(idx + base) ^ np.uint64(stream + 1))
+    return ((bits >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def normal(name: str, shape, std: float = 1.0, seed: int = 0) -> np.ndarray:
+    """N(0, std^2) float32 tensor keyed by (name, seed, flat index)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    key = _fnv1a64(f"{seed}:{name}")
+    u1 = _uniform01(key, n, 0)
+    u2 = _uniform01(key, n, 1)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+    return (z * std).astype(np.float32).reshape(shape)
+
+
+def uniform(name: str, shape, bound: float, seed: int = 0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    key = _fnv1a64(f"{seed}:{name}")
+    u = _uniform01(key, n, 0)
+    return ((2.0 * u - 1.0) * bound).astype(np.float32).reshape(shape)
+
+
+# ----------------------------------------------------------------------------------
+# BEATs configuration (defaults = reference BEATsConfig, avex/models/beats/beats.py:166-228)
+# ----------------------------------------------------------------------------------
+BEATS_BASE_CFG: Dict[str, object] = dict(
+    input_patch_size=16, embed_dim=512, conv_bias=False,
+    encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
+    encoder_attention_heads=12, activation_fn="gelu",
+    layer_norm_first=False, deep_norm=True,
+    conv_pos=128, conv_pos_groups=16,
+    relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True,
+    sample_frequency=16000.0, num_mel_bins=128, frame_length=25.0, frame_shift=10.0,
+    fbank_mean=15.41663, fbank_std=6.55582,
+    finetuned_model=True, predictor_class=527,
+)
+
+# tiny config used for per-stage goldens (verified to run in the reference)
+BEATS_TINY_CFG: Dict[str, object] = dict(
+    BEATS_BASE_CFG,
+    encoder_layers=2, encoder_embed_dim=64, encoder_ffn_embed_dim=128,
+    encoder_attention_heads=4, embed_dim=32, conv_pos=16, conv_pos_groups=4,
+    num_buckets=32, max_distance=64, finetuned_model=False,
+)
+
+
+def beats_state_dict(cfg: Mapping[str, object] = BEATS_BASE_CFG, seed: int = 0,
+                     include_predictor: bool = True, nontrivial_affine: bool = True
+                     ) -> Dict[str, np.ndarray]:
+    """Synthetic BEATs wrapper state dict (fp32 numpy), reference key names.
+
+    Scales follow the reference's init.  ``nontrivial_affine``
+    perturbs LayerNorm weight/bias, Linear biases and ``grep_a`` away from their
+    1/0 init so that parity tests exercise every term (a trained checkpoint has
+    non-trivial values there).
+    """
+    E = int(cfg["encoder_embed_dim"]); F = int(cfg["encoder_ffn_embed_dim"])
+    H = int(cfg["encoder_attention_heads"]); L = int(cfg["encoder_layers"])
+    D = int(cfg["embed_dim"]); P = int(cfg["input_patch_size"])
+    KP = int(cfg["conv_pos"]); G = int(cfg["conv_pos_groups"])
+    NB = int(cfg["num_buckets"]); hd = E // H
+    beta = (8.0 * L) ** -0.25
+    sd: Dict[str, np.ndarray] = {}
+    pre = "backbone."
+
+    def n(name, shape, std):
+        sd[pre + name] = normal(name, shape, std, seed)
+
+    def aff(name, dim, is_weight):
+        if nontrivial_affine:
+            v = normal(name, (dim,), 0.1 if is_weight else 0.05, seed)
+            sd[pre + name] = (v + 1.0).astype(np.float32) if is_weight else v
+        else:
+            sd[pre + name] = (np.ones if is_weight else np.zeros)((dim,), np.float32)
+
+    def bias(name, dim, std=0.02):
+        sd[pre + name] = normal(name, (dim,), std, seed) if nontrivial_affine else np.zeros((dim,), np.float32)
+
+    if D != E:
+        n("post_extract_proj.weight", (E, D), 1.0 / math.sqrt(3.0 * D))      # U(+-1/sqrt(D)) std
+        sd[pre + "post_extract_proj.bias"] = uniform("post_extract_proj.bias", (E,), 1.0 / math.sqrt(D), seed)
+    sd[pre + "patch_embedding.weight"] = uniform("patch_embedding.weight", (D, 1, P, P), 1.0 / P, seed)
+    aff("layer_norm.weight", D, True); aff("layer_norm.bias", D, False)
+
+    std_pc = math.sqrt(4.0 / (KP * E))
+    v = normal("encoder.pos_conv.0.parametrizations.weight.original1", (E, E // G, KP), std_pc, seed)
+    sd[pre + "encoder.pos_conv.0.parametrizations.weight.original1"] = v
+    g = np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
+    if nontrivial_affine:
+        g = (g * (1.0 + normal("encoder.pos_conv.0.parametrizations.weight.original0", (1, 1, KP), 0.1, seed))).astype(np.float32)
+    sd[pre + "encoder.pos_conv.0.parametrizations.weight.original0"] = g
+    bias("encoder.pos_conv.0.bias", E)
+    aff("encoder.layer_norm.weight", E, True); aff("encoder.layer_norm.bias", E, False)
+
+    xav = math.sqrt(2.0 / (E + E))
+    rel = normal("encoder.layers.0.self_attn.relative_attention_bias.weight", (NB, H), 0.02 if not nontrivial_affine else 0.3, seed)
+    for i in range(L):
+        p = f"encoder.layers.{i}."
+        n(p + "self_attn.q_proj.weight", (E, E), xav); bias(p + "self_attn.q_proj.bias", E)
+        n(p + "self_attn.k_proj.weight", (E, E), xav); bias(p + "self_attn.k_proj.bias", E)
+        n(p + "self_attn.v_proj.weight", (E, E), xav * beta); bias(p + "self_attn.v_proj.bias", E)
+        n(p + "self_attn.out_proj.weight", (E, E), xav * beta); bias(p + "self_attn.out_proj.bias", E)
+        n(p + "self_attn.grep_linear.weight", (8, hd), 0.02 if not nontrivial_affine else 0.1)
+        bias(p + "self_attn.grep_linear.bias", 8, 0.1)
+        ga = np.ones((1, H, 1, 1), np.float32)
+        if nontrivial_affine:
+            ga = (ga + normal(p + "self_attn.grep_a", (1, H, 1, 1), 0.2, seed)).astype(np.float32)
+        sd[pre + p + "self_attn.grep_a"] = ga
+        # the table is one shared Parameter (backbone.py:100-103); state_dict lists it per layer
+        sd[pre + p + "self_attn.relative_attention_bias.weight"] = rel
+        aff(p + "self_attn_layer_norm.weight", E, True); aff(p + "self_attn_layer_norm.bias", E, False)
+        n(p + "fc1.weight", (F, E), math.sqrt(2.0 / (E + F)) * beta); bias(p + "fc1.bias", F)
+        n(p + "fc2.weight", (E, F), math.sqrt(2.0 / (E + F)) * beta); bias(p + "fc2.bias", E)
+        aff(p + "final_layer_norm.weight", E, True); aff(p + "final_layer_norm.bias", E, False)
+    if include_predictor and bool(cfg.get("finetuned_model", False)):
+        n("predictor.weight", (int(cfg["predictor_class"]), E), 0.02)
+        sd[pre + "predictor.bias"] = np.zeros((int(cfg["predictor_class"]),), np.float32)
+    return sd
+
+
+# ----------------------------------------------------------------------------------
+# Synthetic clips (BASELINE.md §3 "Inputs")
+# ----------------------------------------------------------------------------------
+def noise_clips(batch: int, samples: int, seed: int = 0, first_clip: int = 0, amp: float = 0.1) -> np.ndarray:
+    """``amp * N(0,1)`` clips keyed by global clip index (shards are reproducible)."""
+    out = np.empty((batch, samples), np.float32)
+    for b in range(batch):
+        out[b] = normal(f"clip{first_clip + b}", (samples,), amp, seed)
+    return out
+
+
+def tone_clips(samples: int, sr: int = 16000) -> np.ndarray:
+    """6 deterministic sines 220/440/880 Hz x amp 0.8/0.9 (mirrors the reference's
+    regression inputs, tests/integration/test_official_models_output_regression.py:135-156)."""
+    t = np.arange(samples, dtype=np.float64) / sr
+    rows = []
+    for f in (220.0, 440.0, 880.0):
+        for a in (0.8, 0.9):
+            rows.append((a * np.sin(2 * math.pi * f * t)).astype(np.float32))
+    return np.stack(rows)

@@ -1,0 +1,210 @@
+/*
+ * avexhip.h — C ABI of the MI355X (gfx950) embedding-extraction path for the AVEX plugin API.
+ *
+ * The reference (earthspecies/avex v1.2.0) is 100 % Python and has NO FFI of its own for this
+ * path: the boundary it exposes is a Python class contract (ModelBase subclass registered in the
+ * model registry).  This library is what a reference-side binding for the hot path would bind
+ * (ctypes stub shown in INTEGRATION.md).  Every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch/HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*; NULL = the null stream).
+ *   - all "dev" pointers are device (HBM) pointers owned by the caller; the library never frees
+ *     them and never synchronises the stream (no hidden hipDeviceSynchronize in any *_forward).
+ *   - return value: 0 on success, <0 on error; avexhip_last_error() gives a thread-local message.
+ *   - "half" buffers hold the operand type chosen at handle creation (AVEXHIP_F16 or AVEXHIP_BF16).
+ */
+#ifndef AVEXHIP_H
+#define AVEXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVEXHIP_ABI_VERSION 1
+
+enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
+
+enum {
+    AVEXHIP_OK = 0,
+    AVEXHIP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    AVEXHIP_ERR_HIP = -2,       /* a HIP runtime call failed */
+    AVEXHIP_ERR_MISSING = -3,   /* a required tensor is missing from the weight table */
+    AVEXHIP_ERR_WORKSPACE = -4  /* workspace too small */
+};
+
+const char* avexhip_last_error(void);
+int avexhip_abi_version(void);
+/* Number of visible HIP devices (does not initialise a device context beyond the count query). */
+int avexhip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Frontend: kaldi-compatible batched log-mel filterbank.
+ * Replaces avex/models/beats/beats.py:39-163 (_BatchedFbank) + :304-323 (BEATs.preprocess).
+ * One fused kernel: frame (win/hop) -> per-frame DC removal -> pre-emphasis -> window ->
+ * zero-pad to 512 -> LDS radix-8 FFT -> |.|^2 -> sparse triangular mel -> log(max(.,eps)) -> affine.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_fbank_plan avexhip_fbank_plan;
+
+typedef struct {
+    int32_t win_length;      /* 400  (beats.py:60)   must be <= 512 */
+    int32_t hop_length;      /* 160  (beats.py:61) */
+    int32_t n_mels;          /* 128 */
+    float   input_scale;     /* 32768.0 for BEATs (beats.py:322); 1.0 for EAT */
+    float   preemph;         /* 0.97 (beats.py:53) */
+    int32_t remove_dc;       /* 1: per-frame mean subtraction (beats.py:140) */
+    float   log_floor;       /* 1.1920929e-07 = fp32 eps (beats.py:36,163) */
+    float   norm_mean;       /* 15.41663; output = (logmel - norm_mean) / norm_div (beats.py:323) */
+    float   norm_div;        /* 2 * 6.55582; use mean 0 / div 1 for raw log-mel */
+} avexhip_fbank_config;
+
+/* window: [win_length] fp32, mel_fb: [257, n_mels] fp32 row-major (the reference's persistent
+ * buffers backbone.fbank.window / backbone.fbank.mel_fb, beats.py:76,80).  Host or device pointers. */
+avexhip_fbank_plan* avexhip_fbank_plan_create(const avexhip_fbank_config* cfg,
+                                              const float* window, const float* mel_fb);
+void avexhip_fbank_plan_destroy(avexhip_fbank_plan* plan);
+/* frames produced for T samples: 1 + (T - win)/hop (snip_edges), 0 if T < win (beats.py:136). */
+int avexhip_fbank_num_frames(const avexhip_fbank_plan* plan, int64_t T);
+/* wav_dev: [B, T] fp32 (row stride = wav_stride elements).  out_dev: [B, frames, n_mels] fp32. */
+int avexhip_fbank_forward(const avexhip_fbank_plan* plan, const float* wav_dev, int B, int64_t T,
+                          int64_t wav_stride, float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks (exported so every kernel can be parity-tested in isolation through the ABI).
+ * `dtype` selects the half operand type of the half buffers.
+ * ------------------------------------------------------------------------------------------ */
+int avexhip_cast_f32_to_half(const float* in_dev, void* out_dev, int64_t n, int dtype, void* stream);
+int avexhip_cast_half_to_f32(const void* in_dev, float* out_dev, int64_t n, int dtype, void* stream);
+
+/* out[m, n] = epilogue( sum_k A[m,k] * W[n,k] )      (torch.nn.Linear layout: W is [N, K])
+ *   acc' = acc + bias[n]                               (bias may be NULL)
+ *   if out_raw:  out_raw[m,n] = acc'                   (fp32 "hook tap", e.g. fc2 raw output)
+ *   if resid:    acc' = resid[m,n] * alpha + acc'      (DeepNorm residual, backbone.py:360,372)
+ *   if gelu:     acc' = gelu_erf(acc')                 (backbone.py:368)
+ *   out_f32 / out_half (either may be NULL) receive acc'.
+ * Requirements: N % 128 == 0, K % 64 == 0, all leading dims in elements, 16-byte aligned rows. */
+typedef struct {
+    const void*  A;  int64_t lda;      /* [M, K] half */
+    const void*  W;  int64_t ldw;      /* [N, K] half */
+    int32_t M, N, K;
+    const float* bias;
+    const float* resid; int64_t ldr; float alpha;
+    int32_t gelu;
+    float* out_f32;  int64_t ldo;
+    void*  out_half; int64_t ldh;
+    float* out_raw;  int64_t ldraw;
+    int32_t variant;                   /* 0 = default (LDS-DMA staging), 1 = register staging */
+} avexhip_gemm_args;
+int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
+
+/* torch.nn.LayerNorm over the last dim C (C % 4 == 0, C <= 1024), eps inside sqrt; writes fp32
+ * and/or half copies.  Replaces beats.py:353, backbone.py:176-177,362,373. */
+int avexhip_layernorm(const float* in_dev, int64_t ld_in, const float* weight, const float* bias,
+                      float eps, int M, int C, float* out_f32, int64_t ldo, void* out_half,
+                      int64_t ldh, int dtype, void* stream);
+
+/* Gated relative-position-bias attention (backbone.py:494-574) for head_dim 64, T <= 512.
+ *   qkv: [B*T, 3*E] half rows (q | k | v, head h at columns h*64..h*64+63 of each third)
+ *   bias_tab: [H, 2T-1] fp32 Toeplitz table, entry r <-> relative position (j - i) = r - (T-1)
+ *   grep_w: [8, 64], grep_b: [8], grep_a: [H]   (backbone.py:421-422,543-551); gate applied iff
+ *   grep_w != NULL.  key_pad: optional [B, T] uint8 (1 = padded key -> -inf, backbone.py:555-558).
+ *   out: [B*T, E] half. */
+int avexhip_attention(const void* qkv_dev, int B, int T, int H, const float* bias_tab,
+                      const float* grep_w, const float* grep_b, const float* grep_a,
+                      const uint8_t* key_pad, void* out_dev, int dtype, void* stream);
+
+/* Convolutional positional embedding (backbone.py:52-68,172-174): grouped Conv1d(E,E,k=128,
+ * pad=64,groups=16) + drop-last + GELU, fused with the residual add:
+ *   out[b,t,:] = x_f32[b,t,:] + gelu(conv(x_half)[b,t,:] + bias)
+ * w_packed: [G][E/G out][128 taps][E/G in] half, weight-norm already folded (see
+ * avexhip_posconv_pack).  Only E/G == 48, K == 128 is built. */
+int avexhip_posconv_pack(const float* g_dev, const float* v_dev, int E, int groups, int K,
+                         void* w_packed_dev, int dtype, void* stream);
+int avexhip_posconv(const void* x_half_dev, const float* x_f32_dev, const void* w_packed_dev,
+                    const float* bias_dev, int B, int T, int E, int groups, int K,
+                    float* out_dev, int dtype, void* stream);
+
+/* mean over T: in [B, T, C] fp32 -> out [B, C] fp32 (features.mean(dim=1), README:80). */
+int avexhip_mean_pool(const float* in_dev, int B, int T, int C, float* out_dev, void* stream);
+
+/* T5 bidirectional bucket of a relative position (backbone.py:438-473).  Pure host function. */
+int avexhip_rel_bucket(int rel, int num_buckets, int max_distance);
+
+/* ------------------------------------------------------------------------------------------
+ * BEATs encoder handle.  Replaces BEATs.extract_features (beats.py:325-382) +
+ * TransformerEncoder.extract_features (backbone.py:151-221) + 12 x layer (backbone.py:350-375)
+ * + hook capture (base_model.py:77-99) + mean pooling.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_beats avexhip_beats;
+
+typedef struct {
+    int32_t input_patch_size;        /* 16 */
+    int32_t embed_dim;               /* 512 */
+    int32_t encoder_layers;          /* 12 */
+    int32_t encoder_embed_dim;       /* 768 */
+    int32_t encoder_ffn_embed_dim;   /* 3072 */
+    int32_t encoder_attention_heads; /* 12 */
+    int32_t conv_pos;                /* 128 */
+    int32_t conv_pos_groups;         /* 16 */
+    int32_t num_buckets;             /* 320 */
+    int32_t max_distance;            /* 800 */
+    int32_t gru_rel_pos;             /* 1 */
+    int32_t deep_norm;               /* 1: alpha = (2 L)^(1/4) */
+    int32_t num_mel_bins;            /* 128 */
+    float   sample_frequency;        /* 16000 */
+    float   frame_length_ms;         /* 25 */
+    float   frame_shift_ms;          /* 10 */
+    float   fbank_mean;              /* 15.41663 */
+    float   fbank_std;               /* 6.55582 */
+    int32_t operand_dtype;           /* AVEXHIP_F16 (default; parity 3e-4) or AVEXHIP_BF16 (2e-3) */
+    int32_t max_chunk_clips;         /* clips processed per internal pass (0 = default 64) */
+} avexhip_beats_config;
+
+/* Weight table entry: reference state-dict key ("backbone." prefix optional), fp32 data
+ * (host or device pointer), element count.  (avex/models/utils/load.py:521-570 ingest.) */
+typedef struct {
+    const char*  name;
+    const float* data;
+    int64_t      numel;
+} avexhip_tensor;
+
+avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, const avexhip_tensor* tensors,
+                                    int n_tensors);
+void avexhip_beats_destroy(avexhip_beats* h);
+
+/* Tokens produced for T samples: (frames/16) * (mel/16)  (beats.py:350-352). */
+int avexhip_beats_num_tokens(const avexhip_beats* h, int64_t T);
+/* Bytes of caller-provided workspace needed for a forward of B clips of T samples. */
+size_t avexhip_beats_workspace_bytes(const avexhip_beats* h, int B, int64_t T);
+
+/* hook_mask bit i (i = 0..L) selects layer i of the reference's layer map
+ * (0 = backbone.post_extract_proj, i = backbone.encoder.layers.{i-1}.fc2, beats_model.py:206-227).
+ * hook_out[i] receives the raw module output, batch-first [B, T', E] fp32 (hook_pooled == 0) or
+ * its mean over T' [B, E] (hook_pooled == 1).  features_out: [B, T', E] fp32 or NULL.
+ * pooled_out: [B, E] fp32 (features.mean(dim=1)) or NULL.  frame_pad: optional [B, T'] uint8
+ * token padding mask (1 = padded; beats.py:283-302 geometry is applied by the caller). */
+int avexhip_beats_forward(avexhip_beats* h, const float* wav_dev, int B, int64_t T,
+                          int64_t wav_stride, const uint8_t* frame_pad, uint32_t hook_mask,
+                          float* const* hook_out, int hook_pooled, float* features_out,
+                          float* pooled_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same, but starting from normalised fbank features [B, frames, n_mels] fp32 (skips the frontend). */
+int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank_dev, int B, int frames,
+                                const uint8_t* frame_pad, uint32_t hook_mask, float* const* hook_out,
+                                int hook_pooled, float* features_out, float* pooled_out,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-stage timing of the most recent forward on this handle is available when the handle was put
+ * in profiling mode (HIP events on the launch stream; forces a stream sync at the end of forward).
+ * names/ms arrays are library-owned and valid until the next forward. */
+int avexhip_beats_set_profiling(avexhip_beats* h, int enabled);
+int avexhip_beats_last_profile(const avexhip_beats* h, const char* const** names, const float** ms,
+                               const double** flops, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVEXHIP_H */

@@ -1,0 +1,233 @@
+"""GPU parity tests, one HIP kernel at a time, through the C ABI (`-m gpu`).
+
+Each kernel is compared with the CPU oracle (oracle/beats_oracle.py, pinned against the real
+reference by tests/test_oracle_golden.py) on the same seeded inputs.  MFMA kernels see inputs
+rounded to the operand type, so the CPU side rounds the same inputs first: the remaining
+difference is fp32 accumulation order (tolerances are written next to each check).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import max_abs, rel_l2, round_half
+from avex_amd import synth
+from oracle import beats_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["f16", "bf16"]
+
+
+def _dev(x, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda", dtype)
+
+
+def _tdt(name):
+    return torch.float16 if name == "f16" else torch.bfloat16
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cast_roundtrip(built_lib, dtype):
+    from avex_amd import kernels as K
+    x = synth.normal("cast", (4099,), 3.0)
+    h = K.to_half(_dev(x), dtype)
+    assert h.dtype == _tdt(dtype)
+    ref = round_half(x, dtype)
+    assert np.array_equal(h.float().cpu().numpy(), ref)          # RNE cast is bit-exact
+    assert np.array_equal(K.to_f32(h).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("shape", [(300, 256, 192), (1984, 768, 768), (128, 128, 64), (77, 3072, 768)])
+def test_gemm_epilogues(built_lib, dtype, variant, shape):
+    from avex_amd import kernels as K
+    M, N, Kd = shape
+    a = round_half(synth.normal(f"A{shape}", (M, Kd), 1.0), dtype)
+    w = round_half(synth.normal(f"W{shape}", (N, Kd), 0.05), dtype)
+    bias = synth.normal("bias", (N,), 0.1)
+    resid = synth.normal("resid", (M, N), 1.0)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    ad, wd = _dev(a, _tdt(dtype)), _dev(w, _tdt(dtype))
+    # plain + bias
+    r = K.gemm(ad, wd, bias=_dev(bias), variant=variant)
+    assert rel_l2(r["f32"].cpu().numpy(), ref) < 2e-6        # fp32 accumulate vs fp64
+    # residual (DeepNorm) + raw tap + half copy
+    alpha = 2.2133638
+    r = K.gemm(ad, wd, bias=_dev(bias), resid=_dev(resid), alpha=alpha, out_half=True, out_raw=True, variant=variant)
+    assert rel_l2(r["raw"].cpu().numpy(), ref) < 2e-6
+    assert rel_l2(r["f32"].cpu().numpy(), resid * alpha + ref) < 2e-6
+    assert np.array_equal(r["half"].float().cpu().numpy(), round_half(r["f32"].cpu().numpy(), dtype))
+    # exact-erf GELU
+    r = K.gemm(ad, wd, bias=_dev(bias), gelu=True, variant=variant)
+    assert rel_l2(r["f32"].cpu().numpy(), O.gelu_erf(ref.astype(np.float32))) < 5e-6
+
+
+def test_gemm_rejects_bad_shapes(built_lib):
+    from avex_amd import kernels as K
+    from avex_amd._capi import AvexHipError
+    a = torch.zeros((8, 64), dtype=torch.float16, device="cuda")
+    with pytest.raises(AvexHipError):
+        K.gemm(a, torch.zeros((100, 64), dtype=torch.float16, device="cuda"))    # N % 128
+    with pytest.raises(AvexHipError):
+        K.gemm(torch.zeros((8, 40), dtype=torch.float16, device="cuda"),
+               torch.zeros((128, 40), dtype=torch.float16, device="cuda"))       # K % 64
+
+
+@pytest.mark.parametrize("C", [768, 512, 64])
+def test_layernorm(built_lib, C):
+    from avex_amd import kernels as K
+    x = synth.normal(f"ln{C}", (333, C), 2.0) + 0.5
+    w = 1.0 + synth.normal("lnw", (C,), 0.1)
+    b = synth.normal("lnb", (C,), 0.1)
+    o32, oh = K.layernorm(_dev(x), _dev(w), _dev(b))
+    ref = O.layer_norm(x, w.astype(np.float32), b.astype(np.float32))
+    assert max_abs(o32.cpu().numpy(), ref) < 5e-6
+    assert np.array_equal(oh.float().cpu().numpy(), round_half(o32.cpu().numpy(), "f16"))
+
+
+def test_mean_pool(built_lib):
+    from avex_amd import kernels as K
+    x = synth.normal("pool", (3, 496, 768), 1.0)
+    out = K.mean_pool(_dev(x)).cpu().numpy()
+    assert max_abs(out, x.mean(axis=1, dtype=np.float64)) < 1e-6
+
+
+def _attention_ref(qkv, B, T, H, table, gw, gb, ga, key_pad=None):
+    E = H * 64
+    q, k, v = [qkv[:, i * E:(i + 1) * E].reshape(B, T, H, 64).transpose(0, 2, 1, 3).astype(np.float64) for i in range(3)]
+    s = q @ k.transpose(0, 1, 3, 2) * 0.125
+    if table is not None:
+        bias = O.position_bias(table, T, table.shape[0], 800 if table.shape[0] == 320 else 64).astype(np.float64)
+        if gw is not None:
+            g8 = q @ gw.T.astype(np.float64) + gb
+            g2 = g8.reshape(B, H, T, 2, 4).sum(-1)
+            sg = 1.0 / (1.0 + np.exp(-g2))
+            gate = sg[..., 0:1] * (sg[..., 1:2] * ga.reshape(1, H, 1, 1) - 1.0) + 2.0
+            s = s + gate * bias[None]
+        else:
+            s = s + bias[None]
+    if key_pad is not None:
+        s = np.where(key_pad[:, None, None, :], -np.inf, s)
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    o = (e / e.sum(-1, keepdims=True)) @ v
+    return o.transpose(0, 2, 1, 3).reshape(B * T, E)
+
+
+def _toeplitz(table, T, nb, md):
+    from avex_amd import kernels as K
+    H = table.shape[1]
+    tab = np.empty((H, 2 * T - 1), np.float32)
+    for r in range(2 * T - 1):
+        tab[:, r] = table[K.rel_bucket(r - (T - 1), nb, md)]
+    return tab
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [496, 48, 384, 33, 512])
+def test_attention(built_lib, dtype, T):
+    from avex_amd import kernels as K
+    B, H = 2, 12
+    E = H * 64
+    qkv = round_half(synth.normal(f"qkv{T}", (B * T, 3 * E), 1.0), dtype)
+    table = synth.normal("rel", (320, H), 0.5)
+    gw = synth.normal("gw", (8, 64), 0.1); gb = synth.normal("gb", (8,), 0.1); ga = 1.0 + synth.normal("ga", (H,), 0.2)
+    tab = _toeplitz(table, T, 320, 800)
+    out = K.attention(_dev(qkv, _tdt(dtype)), B, T, H, _dev(tab), _dev(gw), _dev(gb), _dev(ga))
+    ref = _attention_ref(qkv, B, T, H, table, gw, gb, ga)
+    # P is rounded to the operand type before P@V and the output is stored in it:
+    # f16 ~ 2^-11 per element, bf16 ~ 2^-8
+    tol = 1.5e-3 if dtype == "f16" else 1.2e-2
+    assert rel_l2(out.float().cpu().numpy(), ref) < tol
+
+
+def test_attention_key_padding_and_plain_bias(built_lib):
+    from avex_amd import kernels as K
+    B, H, T = 2, 12, 96
+    E = H * 64
+    qkv = round_half(synth.normal("qkvpad", (B * T, 3 * E), 1.0), "f16")
+    table = synth.normal("rel", (320, H), 0.5)
+    tab = _toeplitz(table, T, 320, 800)
+    pad = np.zeros((B, T), bool); pad[1, 40:] = True
+    out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), None, None, None,
+                      key_pad=_dev(pad.astype(np.uint8), torch.uint8))
+    ref = _attention_ref(qkv, B, T, H, table, None, None, None, key_pad=pad)
+    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [496, 48, 130])
+def test_posconv(built_lib, dtype, T):
+    from avex_amd import kernels as K
+    B, E, G, Kt = 2, 768, 16, 128
+    x = synth.normal(f"pcx{T}", (B, T, E), 1.0)
+    v = synth.normal("pcv", (E, E // G, Kt), math.sqrt(4.0 / (Kt * E)))
+    g = (np.sqrt((v.astype(np.float64) ** 2).sum((0, 1), keepdims=True)) * (1.0 + synth.normal("pcg", (1, 1, Kt), 0.1))).astype(np.float32)
+    bias = synth.normal("pcb", (E,), 0.05)
+    wp = K.posconv_pack(_dev(g), _dev(v), G, dtype)
+    # packed layout [g][o][tap][c] and folded weight-norm
+    w = O.pos_conv_weight(g, v)
+    wp_ref = w.reshape(G, E // G, E // G, Kt).transpose(0, 1, 3, 2).reshape(-1)
+    assert rel_l2(wp.float().cpu().numpy(), wp_ref) < (6e-4 if dtype == "f16" else 4e-3)
+    xh = round_half(x, dtype)
+    out = K.posconv(_dev(xh, _tdt(dtype)), _dev(x), wp, _dev(bias), G, Kt).cpu().numpy()
+    wq = wp.float().cpu().numpy().reshape(G, E // G, Kt, E // G).transpose(0, 1, 3, 2).reshape(E, E // G, Kt)
+    ref = x + O.pos_conv(xh, wq, bias.astype(np.float32), G)
+    assert rel_l2(out - x, ref - x) < 2e-5       # same rounded operands: fp32 accumulation order only
+    assert out.shape == (B, T, E)
+
+
+def _fbank_close(a, b, what):
+    """log-mel comparison that is meaningful for tonal inputs: bins whose energy sits at the fp32 FFT
+    noise floor of the frame (1e-6 of the frame's peak mel energy... the reference's own CPU/GPU test
+    uses atol 2e-2) are compared in the energy domain."""
+    ea, eb = np.exp(a.astype(np.float64)), np.exp(b.astype(np.float64))
+    peak = eb.max(axis=-1, keepdims=True)
+    err = np.abs(ea - eb) / (eb + 3e-6 * peak)
+    assert err.max() < 2e-3, f"{what}: energy-domain error {err.max():.3e}"
+
+
+def test_fbank_golden(built_lib, golden_dir):
+    from avex_amd import kernels as K
+    g = np.load(f"{golden_dir}/fbank.npz")
+    plan = K.FbankPlan()
+    y = plan(_dev(synth.noise_clips(2, 16000, seed=0))).cpu().numpy()
+    assert y.shape == g["noise16k"].shape == (2, 98, 128)
+    assert max_abs(y, g["noise16k"]) < 1e-3          # reference CPU-vs-kaldi tolerance is 1e-4 rel+abs on ~20
+    _fbank_close(y, g["noise16k"], "noise16k")
+    y = plan(_dev(synth.tone_clips(16000))).cpu().numpy()
+    _fbank_close(y, g["tone16k"], "tone16k")
+    y = plan(_dev(synth.noise_clips(2, 160000, seed=0))).cpu().numpy()
+    assert y.shape == (2, 998, 128)
+    assert max_abs(y[:, ::37], g["noise160k_rows37"]) < 1e-3
+    assert max_abs(y.sum(-1), g["noise160k_framesum"]) < 2e-2
+    imp = np.zeros((1, 16000), np.float32); imp[0, 200] = 1.0
+    y = plan(_dev(imp)).cpu().numpy()
+    _fbank_close(y[:, :3], g["impulse200"], "impulse")
+    # DC / silence -> log(eps) everywhere
+    y = plan(_dev(np.full((1, 16000), 0.25, np.float32))).cpu().numpy()
+    assert np.allclose(y, math.log(1.1920929e-07), atol=1e-5)
+
+
+@pytest.mark.parametrize("n_mels", [64, 256])
+def test_fbank_other_mel_sizes(built_lib, golden_dir, n_mels):
+    from avex_amd import kernels as K
+    g = np.load(f"{golden_dir}/fbank.npz")
+    plan = K.FbankPlan(n_mels=n_mels, mel_fb=K.kaldi_mel_filterbank(n_mels))
+    y = plan(_dev(synth.noise_clips(1, 4000, seed=7))).cpu().numpy()
+    assert y.shape == g[f"noise4k_mel{n_mels}"].shape == (1, 23, n_mels)
+    assert max_abs(y, g[f"noise4k_mel{n_mels}"]) < 1e-3
+
+
+def test_fbank_edge_lengths(built_lib):
+    from avex_amd import kernels as K
+    plan = K.FbankPlan()
+    for T, frames in ((399, 0), (400, 1), (559, 1), (560, 2), (4000, 23)):
+        y = plan(_dev(synth.noise_clips(1, T, seed=1)))
+        assert y.shape == (1, frames, 128)
+        if frames:
+            ref = O.fbank(synth.noise_clips(1, T, seed=1) * np.float32(2 ** 15))
+            assert max_abs(y.cpu().numpy(), ref) < 1e-3
