@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s (10 s @ 16 kHz) embedding extraction, BEATs-base, on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--dtype f16|bf16]
+
+One "step" = one pass of the hot path (wav resident in HBM -> fbank -> BEATs-base encoder ->
+mean-pooled 768-d embedding) over one batch of synthetic clips per GPU; with N > 1 the batch is
+sharded data-parallel (one process per GPU, launched by torch.distributed.run) and the step ends
+with one RCCL all-gather of the pooled [B_local, 768] embeddings.  Weak scaling:
+per-GPU batch is fixed, `value` is whole-job clips/s.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      dominant kernel (the MFMA GEMM): algorithmic FLOPs / HIP-event time on the launch stream
+  cpu_baseline  the CPU oracle (NumPy restatement of the reference, "port") timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLES = 160000            # 10 s @ 16 kHz
+FLOP_PER_CLIP = 98.7e9      # SURVEY.md §8d (FFN 56.17, QKV/out 28.09, SDPA 9.07, pos-conv 4.69, ...)
+PEAK_TFLOPS = 2500.0        # dense bf16/f16 MFMA peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline(sd, cfg, seconds_budget=20.0):
+    """Time the oracle (checker, never shipped) on a bounded sample of the same workload."""
+    import numpy as np
+    from avex_amd import synth
+    from oracle import beats_oracle as O
+    n = 2
+    x = synth.noise_clips(n, SAMPLES, seed=0)
+    O.beats_forward(x[:1], sd, cfg)                      # warm-up (BLAS threads, page-in)
+    t0 = time.time()
+    done = 0
+    while True:
+        f, _ = O.beats_forward(x, sd, cfg)
+        O.pooled(f)
+        done += n
+        el = time.time() - t0
+        if el > seconds_budget or done >= 64:
+            break
+    return {"value": round(done / el, 3), "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{done} clips x 10 s through oracle/beats_oracle.py (NumPy fp32, OpenBLAS threads={os.cpu_count()}), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--dtype", default=os.environ.get("AVEX_AMD_OPERAND", "f16"))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("AVEX_AMD_CHUNK", "64")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
+              f"(--nproc-per-node {args.gpus}); see the module docstring", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (no CPU fallback for the product path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from avex_amd import build, synth
+    from avex_amd import kernels as K
+    build.build(verbose=False)
+    cfg = synth.BEATS_BASE_CFG
+    sd = synth.beats_state_dict(cfg, seed=0)
+    enc = K.BeatsEncoder(cfg, sd, operand_dtype=args.dtype, max_chunk_clips=args.chunk)
+
+    B = args.batch
+    # synthetic clips keyed by global clip index (rank r owns clips [r*B, (r+1)*B))
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    wav = (0.1 * torch.randn((B, SAMPLES), generator=gen, dtype=torch.float32)).to(dev)
+    gathered = torch.empty((world * B, 768), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        r = enc.forward(wav, want_features=False, want_pooled=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, r["pooled"])
+            return gathered
+        return r["pooled"]
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # ---- roofline of the dominant kernel (rank 0): HIP events around every launch, same stream ----
+    roof = None
+    stages = None
+    if rank == 0:
+        enc.set_profiling(True)
+        enc.forward(wav, want_features=False, want_pooled=True)
+        prof = enc.last_profile()
+        enc.set_profiling(False)
+        gemm_ms = sum(ms for n, ms, fl in prof if n.startswith("gemm."))
+        gemm_fl = sum(fl for n, ms, fl in prof if n.startswith("gemm."))
+        n_gemm_launch = (2 + 4 * int(cfg["encoder_layers"])) * ((B + args.chunk - 1) // args.chunk)
+        total_ms = sum(ms for _, ms, _ in prof)
+        stages = {n: {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 and fl > 0 else None} for n, ms, fl in prof}
+        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n_gemm_launch, "avg_launch_ms": round(gemm_ms / n_gemm_launch, 4),
+                "gemm_share_of_step": round(gemm_ms / total_ms, 3)}
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        line = {
+            "metric": "clips/s (10 s @ 16 kHz) embedding extraction, BEATs-base",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BEATs-base (12L/768/3072/12H, 90.7 M params, synthetic weights), batch {B} x 10 s @ 16 kHz per GPU, "
+                                   f"wav resident in HBM -> mean-pooled 768-d embedding" + (", RCCL all-gather of pooled embeddings" if world > 1 else ""),
+                       "global_batch": world * B, "samples_per_clip": SAMPLES, "tokens_per_clip": 496,
+                       "parallelism": f"dp{world}", "chunk_clips": args.chunk,
+                       "model_tflops_per_s": round(value * FLOP_PER_CLIP / 1e12, 1),
+                       "model_frac_of_mfma_peak": round(value * FLOP_PER_CLIP / 1e12 / (PEAK_TFLOPS * world), 4)},
+            "roofline": roof, "stages_ms": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
