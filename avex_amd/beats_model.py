@@ -1,0 +1,320 @@
+"""BEATs model class for the plugin registry, backed by the HIP encoder (registry key ``"beats"``).
+
+Drop-in counterpart of the reference wrapper (avex/models/beats_model.py:72-435): same constructor
+keywords, ``forward(x, padding_mask)`` / ``extract_embeddings(...)`` semantics, hookable layer list
+(``backbone.post_extract_proj`` + ``backbone.encoder.layers.{i}.fc2``, beats_model.py:206-227) and
+``state_dict()`` key names (``backbone.*``, 254 entries for the fine-tuned config), so a reference
+checkpoint loads with ``load_state_dict`` unchanged.
+
+The sub-module tree below only HOLDS parameters under the reference's names (standard torch
+modules, never called); the arithmetic runs in libavexhip.so through one ``avexhip_beats`` handle
+that is (re)built lazily from the current parameter values.  There is no CPU fallback: calling
+``forward`` without a GPU raises ``AvexHipError``.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import kernels
+from ._capi import AvexHipError
+from .base_model import ModelBase
+from .configs import AudioConfig
+from .synth import BEATS_BASE_CFG
+
+logger = logging.getLogger(__name__)
+
+# BEATsConfig defaults (reference: avex/models/beats/beats.py:166-228): SSL iter3 variant
+_CFG_DEFAULTS: Dict[str, Any] = dict(
+    input_patch_size=16, embed_dim=512, conv_bias=False, encoder_layers=12, encoder_embed_dim=768,
+    encoder_ffn_embed_dim=3072, encoder_attention_heads=12, activation_fn="gelu",
+    layer_wise_gradient_decay_ratio=1.0, layer_norm_first=False, deep_norm=True, dropout=0.1,
+    attention_dropout=0.1, activation_dropout=0.0, encoder_layerdrop=0.05, dropout_input=0.0, conv_pos=128,
+    conv_pos_groups=16, relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True,
+    sample_frequency=16000.0, num_mel_bins=128, frame_length=25.0, frame_shift=10.0, fbank_mean=15.41663,
+    fbank_std=6.55582, finetuned_model=False, predictor_dropout=0.0, predictor_class=527,
+)
+
+
+def resolve_beats_config(init_config: Optional[Dict[str, Any]], fine_tuned: bool, use_naturelm: bool) -> Dict[str, Any]:
+    """``BEATsConfig(**init_config)`` with the reference defaults; without ``init_config`` the packaged
+    iter3+AS2M descriptors apply (fine-tuned: ``finetuned_model=True``; NatureLM forces it too,
+    beats_model.py:171-184)."""
+    cfg = dict(_CFG_DEFAULTS)
+    if init_config is not None:
+        cfg.update(init_config)
+    else:
+        if fine_tuned or use_naturelm:
+            cfg["finetuned_model"] = True
+    return cfg
+
+
+class _Parametrized(nn.Module):
+    """Holder giving ``...pos_conv.0.parametrizations.weight.original0/original1`` (weight_norm dim=2)."""
+
+    def __init__(self, E: int, cg: int, K: int) -> None:
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(E))
+        self.parametrizations = nn.Module()
+        self.parametrizations.weight = nn.Module()
+        self.parametrizations.weight.original0 = nn.Parameter(torch.ones(1, 1, K))
+        self.parametrizations.weight.original1 = nn.Parameter(torch.zeros(E, cg, K))
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, E: int, H: int, table: Optional[nn.Embedding], gru: bool) -> None:
+        super().__init__()
+        if gru:
+            self.grep_a = nn.Parameter(torch.ones(1, H, 1, 1))
+        if table is not None:
+            self.relative_attention_bias = table          # ONE shared table (backbone.py:100-103)
+        self.k_proj = nn.Linear(E, E)
+        self.v_proj = nn.Linear(E, E)
+        self.q_proj = nn.Linear(E, E)
+        self.out_proj = nn.Linear(E, E)
+        if gru:
+            self.grep_linear = nn.Linear(E // H, 8)
+
+
+class _Layer(nn.Module):
+    def __init__(self, E: int, F: int, H: int, table: Optional[nn.Embedding], gru: bool) -> None:
+        super().__init__()
+        self.self_attn = _SelfAttn(E, H, table, gru)
+        self.self_attn_layer_norm = nn.LayerNorm(E)
+        self.fc1 = nn.Linear(E, F)
+        self.fc2 = nn.Linear(F, E)
+        self.final_layer_norm = nn.LayerNorm(E)
+
+
+class _Fbank(nn.Module):
+    def __init__(self, cfg: Dict[str, Any]) -> None:
+        super().__init__()
+        win = int(float(cfg["sample_frequency"]) * float(cfg["frame_length"]) / 1000.0)
+        self.register_buffer("window", torch.from_numpy(kernels.povey_window(win)))
+        self.register_buffer("mel_fb", torch.from_numpy(kernels.kaldi_mel_filterbank(
+            int(cfg["num_mel_bins"]), 512, float(cfg["sample_frequency"]), 20.0, 0.0)))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg: Dict[str, Any]) -> None:
+        super().__init__()
+        E, F, H = int(cfg["encoder_embed_dim"]), int(cfg["encoder_ffn_embed_dim"]), int(cfg["encoder_attention_heads"])
+        self.pos_conv = nn.Sequential(_Parametrized(E, E // int(cfg["conv_pos_groups"]), int(cfg["conv_pos"])))
+        table = nn.Embedding(int(cfg["num_buckets"]), H) if cfg.get("relative_position_embedding", True) else None
+        self.layers = nn.ModuleList([_Layer(E, F, H, table, bool(cfg.get("gru_rel_pos", True)))
+                                     for _ in range(int(cfg["encoder_layers"]))])
+        self.layer_norm = nn.LayerNorm(E)
+
+
+class BeatsParameters(nn.Module):
+    """Parameter tree with the reference ``BEATs`` module's names, in its construction order
+    (beats.py:234-281) so ``named_modules()`` enumerates hookable layers identically."""
+
+    def __init__(self, cfg: Dict[str, Any]) -> None:
+        super().__init__()
+        D, E, P = int(cfg["embed_dim"]), int(cfg["encoder_embed_dim"]), int(cfg["input_patch_size"])
+        self.post_extract_proj = nn.Linear(D, E) if D != E else None
+        self.fbank = _Fbank(cfg)
+        self.patch_embedding = nn.Conv2d(1, D, kernel_size=P, stride=P, bias=bool(cfg.get("conv_bias", False)))
+        self.encoder = _Encoder(cfg)
+        self.layer_norm = nn.LayerNorm(D)
+        if cfg.get("finetuned_model", False):
+            self.predictor = nn.Linear(E, int(cfg["predictor_class"]))
+        else:
+            self.predictor = None
+
+
+class Model(ModelBase):
+    """BEATs backbone (+ optional linear classifier) running on the MI355X HIP path."""
+
+    name = "beats"
+
+    def __init__(self, *, num_classes: Optional[int] = None, pretrained: bool = False, device: str = "cuda",
+                 audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None, return_features_only: bool = False,
+                 use_naturelm: bool = False, fine_tuned: bool = False, disable_layerdrop: bool = False,
+                 init_config: Optional[Dict[str, Any]] = None, operand_dtype: Optional[str] = None,
+                 max_chunk_clips: int = 0) -> None:
+        super().__init__(device=device, audio_config=audio_config)
+        if num_classes is None:
+            return_features_only = True
+        self.num_classes = num_classes
+        self.disable_layerdrop = disable_layerdrop      # inference never drops layers; kept for API parity
+        self.use_naturelm = bool(use_naturelm)
+        self.fine_tuned = bool(fine_tuned)
+        if pretrained:
+            # the reference downloads gs:// / hf:// weights here (beats_model.py:132-163); neither box has a network
+            raise FileNotFoundError(
+                "pretrained=True needs the official BEATs checkpoint, which is not reachable offline; "
+                "build with pretrained=False and pass checkpoint_path= to load_model() or call load_state_dict()")
+        self.beats_cfg = resolve_beats_config(init_config, self.fine_tuned, self.use_naturelm)
+        self.operand_dtype = operand_dtype or os.environ.get("AVEX_AMD_OPERAND", "f16")
+        self.max_chunk_clips = int(max_chunk_clips or os.environ.get("AVEX_AMD_CHUNK", "0"))
+        kernels.make_beats_config(self.beats_cfg, self.operand_dtype)        # validates what the HIP path supports
+
+        self.backbone = BeatsParameters(self.beats_cfg)
+        self._return_features_only = return_features_only
+        if not return_features_only:
+            self.classifier = nn.Linear(int(self.beats_cfg["encoder_embed_dim"]), num_classes)
+        else:
+            self.register_module("classifier", None)
+        self._encoder: Optional[kernels.BeatsEncoder] = None
+        self._weights_dirty = True
+        self._pooled_taps = False
+        self._want_features = True
+        try:
+            self.to(device)
+        except (RuntimeError, AssertionError) as e:  # e.g. device="cuda" on a box without a GPU
+            logger.warning("could not move BEATs parameters to %s (%s); they stay on CPU until .to() succeeds", device, e)
+
+    # ------------------------------------------------------------------ parameter life cycle
+    def _apply(self, fn, *a, **k):
+        self._weights_dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self._weights_dirty = True
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def refresh_weights(self) -> None:
+        """Re-pack the HIP handle from the current parameter values (call after in-place edits)."""
+        self._weights_dirty = True
+
+    def _ensure_encoder(self) -> kernels.BeatsEncoder:
+        if self._encoder is None or self._weights_dirty:
+            p = next(self.parameters())
+            if not p.is_cuda:
+                raise AvexHipError(f"BEATs parameters live on {p.device}; the avex_amd path runs on a GPU only "
+                                   "(move the model with .to('cuda'); there is no CPU fallback)")
+            if self._encoder is not None:
+                self._encoder.close()
+            with torch.cuda.device(p.device):
+                state = {k: v for k, v in self.state_dict().items() if k.startswith("backbone.")}
+                self._encoder = kernels.BeatsEncoder(self.beats_cfg, state, operand_dtype=self.operand_dtype,
+                                                     max_chunk_clips=self.max_chunk_clips)
+            self._weights_dirty = False
+        return self._encoder
+
+    # ------------------------------------------------------------------ layers
+    def _discover_embedding_layers(self) -> None:
+        if not self._layer_names:
+            names = []
+            for name, _ in self.named_modules():
+                if name.endswith("post_extract_proj"):
+                    names.append(name)
+                elif name.endswith(".fc2") and "backbone.encoder.layers." in name:
+                    names.append(name)
+            self._layer_names = names
+
+    def _tap_modules(self) -> List[nn.Module]:
+        mods: List[nn.Module] = []
+        if self.backbone.post_extract_proj is not None:
+            mods.append(self.backbone.post_extract_proj)
+        else:
+            mods.append(nn.Identity())      # index 0 unused when embed_dim == encoder_embed_dim
+        mods += [layer.fc2 for layer in self.backbone.encoder.layers]
+        return mods
+
+    # ------------------------------------------------------------------ mask geometry
+    @staticmethod
+    def forward_padding_mask(n_features: int, padding_mask: torch.Tensor) -> torch.Tensor:
+        """Sample/frame mask -> coarser mask: drop the remainder, view ``(B, n, -1)``, ``all(-1)``
+        (reference: beats.py:283-302)."""
+        extra = padding_mask.size(1) % n_features
+        if extra > 0:
+            padding_mask = padding_mask[:, :-extra]
+        return padding_mask.reshape(padding_mask.size(0), n_features, -1).all(-1)
+
+    # ------------------------------------------------------------------ forward
+    def process_audio(self, x: torch.Tensor) -> torch.Tensor:
+        audio = super().process_audio(x)
+        if self.use_naturelm:
+            audio = torch.clamp(audio, -1.0, 1.0)
+        return audio
+
+    def forward(self, x: torch.Tensor, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``(B, T)`` waveform -> ``(B, T', 768)`` features (``return_features_only``) or ``(B, num_classes)`` logits."""
+        x = self.process_audio(x)
+        if x.dim() != 2:
+            raise ValueError(f"expected audio of shape (batch, time), got {tuple(x.shape)}")
+        enc = self._ensure_encoder()
+        cfg = self.beats_cfg
+        win = int(float(cfg["sample_frequency"]) * float(cfg["frame_length"]) / 1000.0)
+        hop = int(float(cfg["sample_frequency"]) * float(cfg["frame_shift"]) / 1000.0)
+        frames = 1 + (x.shape[1] - win) // hop if x.shape[1] >= win else 0
+        tokens = enc.num_tokens(x.shape[1])
+        frame_pad = None
+        if padding_mask is not None and tokens > 0:
+            pm = padding_mask.to(device=x.device, dtype=torch.bool)
+            frame_pad = self.forward_padding_mask(tokens, self.forward_padding_mask(frames, pm))
+        taps = self._tap_modules()
+        hooked = [i for i, m in enumerate(taps) if len(m._forward_hooks) > 0]
+        with torch.cuda.device(x.device):
+            r = enc.forward(x, hook_layers=hooked, hook_pooled=self._pooled_taps, want_features=self._want_features,
+                            frame_pad=frame_pad)
+        for i in hooked:
+            self._fire_forward_hooks(taps[i], r["hooks"][i])
+        features = r["features"]
+        if self._return_features_only or features is None:
+            return features
+        if frame_pad is not None and bool(frame_pad.any()):
+            keep = (~frame_pad).unsqueeze(-1).to(features.dtype)           # masked mean (beats_model.py:269-273)
+            pooled = (features * keep).sum(dim=1) / keep.sum(dim=1).clamp(min=1)
+        else:
+            pooled = features.mean(dim=1)
+        return self.classifier(pooled)
+
+    # ------------------------------------------------------------------ embeddings
+    def extract_embeddings(self, x: Union[torch.Tensor, Dict[str, torch.Tensor]], *,
+                           padding_mask: Optional[torch.Tensor] = None, aggregation: str = "none",
+                           freeze_backbone: bool = True) -> Union[torch.Tensor, List[torch.Tensor]]:
+        """Outputs of all hooked layers (reference: beats_model.py:279-429): a tensor/list of
+        ``(B, T', 768)`` for ``aggregation="none"``, else ``(B, 768 * n_layers)``."""
+        if x is None:
+            raise ValueError("Input tensor cannot be None")
+        wav = x["raw_wav"] if isinstance(x, dict) else x
+        if wav.numel() == 0 or wav.shape[-1] == 0:
+            raise ValueError("Audio tensor cannot be empty")
+        if not self._hooks:
+            raise ValueError("No hooks are registered in the model.")
+        if aggregation not in ("none", "mean", "max", "cls_token"):
+            raise ValueError(f"Unsupported aggregation method: {aggregation}")
+        if not freeze_backbone:
+            logger.warning("avex_amd BEATs is an inference path: freeze_backbone=False returns embeddings "
+                           "without an autograd graph")
+        was_training = self.training
+        if was_training:
+            self.eval()
+        # mean-aggregation lets the device reduce every tap to (B, 768) instead of writing (B, T', 768)
+        own_hooks_only = all(len(m._forward_hooks) <= 1 for m in self._tap_modules())
+        self._pooled_taps = aggregation == "mean" and own_hooks_only
+        self._want_features = False
+        try:
+            self._clear_hook_outputs()
+            mask = x.get("padding_mask") if isinstance(x, dict) else padding_mask
+            batch = wav.shape[0]
+            with torch.no_grad():
+                self.forward(wav, mask)
+            order = self._hook_layers or list(self._hook_outputs)
+            embs = [self._hook_outputs[n] for n in order if n in self._hook_outputs]
+            if not embs:
+                raise ValueError(f"No layers found matching: {list(self._hook_outputs)}")
+            embs = [e if e.shape[0] == batch else e.transpose(0, 1) for e in embs]
+            return self._aggregate(embs, aggregation)
+        finally:
+            self._pooled_taps = False
+            self._want_features = True
+            self._clear_hook_outputs()
+            if was_training:
+                self.train()
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_encoder", None) is not None:
+                self._encoder.close()
+        except Exception:  # noqa: BLE001
+            pass
+        super().__del__()

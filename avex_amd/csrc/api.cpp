@@ -123,7 +123,8 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 void default_window(int win, std::vector<float>& w) {
     w.resize(win);
     for (int n = 0; n < win; ++n) {
-        const float hann = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(win - 1)));
+        // torch.hann_window(periodic=False) op for op in fp32
+        const float hann = cosf((float)n * (float)(M_PI * 2.0 / (double)(win - 1))) * -0.5f + 0.5f;
         w[n] = powf(hann, 0.85f);
     }
 }

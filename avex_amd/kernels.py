@@ -42,14 +42,14 @@ def _need_cuda(*ts: Optional[torch.Tensor]) -> None:
 # ---------------------------------------------------------------------------------------
 def povey_window(win_length: int = 400) -> np.ndarray:
     """``hann(win, periodic=False) ** 0.85`` (reference: beats.py:75), fp32."""
-    n = np.arange(win_length, dtype=np.float64)
-    hann = (0.5 - 0.5 * np.cos(2.0 * math.pi * n / (win_length - 1))).astype(np.float32)
-    return np.power(hann, np.float32(0.85)).astype(np.float32)
+    return np.power(hann_window(win_length), np.float32(0.85)).astype(np.float32)
 
 
 def hann_window(win_length: int = 400) -> np.ndarray:
-    n = np.arange(win_length, dtype=np.float64)
-    return (0.5 - 0.5 * np.cos(2.0 * math.pi * n / (win_length - 1))).astype(np.float32)
+    """``torch.hann_window(win, periodic=False)`` op for op in fp32 (arange * 2pi/(N-1) -> cos -> * -0.5 + 0.5)."""
+    n = np.arange(win_length, dtype=np.float32)
+    c = np.cos(n * np.float32(math.pi * 2 / (win_length - 1))).astype(np.float32)
+    return (c * np.float32(-0.5) + np.float32(0.5)).astype(np.float32)
 
 
 def kaldi_mel_filterbank(n_mels: int = 128, n_fft: int = 512, sample_rate: float = 16000.0,

@@ -27,18 +27,17 @@ F32_EPS = np.float32(1.1920929e-07)  # torch.finfo(float32).eps, beats.py:36
 # --------------------------------------------------------------------------------------
 # Frontend: kaldi-compatible batched fbank  (avex/models/beats/beats.py:39-163)
 # --------------------------------------------------------------------------------------
-def povey_window(win_length: int = 400) -> np.ndarray:
-    """``hann(win, periodic=False) ** 0.85`` (beats.py:75)."""
-    n = np.arange(win_length, dtype=np.float64)
-    hann = 0.5 - 0.5 * np.cos(2.0 * math.pi * n / (win_length - 1))
-    # torch computes hann_window in fp32 then pow in fp32
-    return np.power(hann.astype(np.float32), np.float32(0.85)).astype(np.float32)
-
-
 def hann_window(win_length: int = 400) -> np.ndarray:
     """kaldi ``window_type="hanning"`` (EAT frontend, eat/audio_processor.py:110-119)."""
-    n = np.arange(win_length, dtype=np.float64)
-    return (0.5 - 0.5 * np.cos(2.0 * math.pi * n / (win_length - 1))).astype(np.float32)
+    # torch.hann_window(periodic=False) is all-fp32: arange * (2 pi / (N-1)) -> cos -> * -0.5 + 0.5
+    n = np.arange(win_length, dtype=np.float32)
+    c = np.cos(n * np.float32(math.pi * 2 / (win_length - 1))).astype(np.float32)
+    return (c * np.float32(-0.5) + np.float32(0.5)).astype(np.float32)
+
+
+def povey_window(win_length: int = 400) -> np.ndarray:
+    """``hann(win, periodic=False) ** 0.85`` (beats.py:75)."""
+    return np.power(hann_window(win_length), np.float32(0.85)).astype(np.float32)
 
 
 def mel_filterbank(n_fft: int = 512, n_mels: int = 128, sample_rate: float = 16000.0,

@@ -1,0 +1,52 @@
+"""The C-ABI library loads and exports every symbol include/avexhip.h declares (no GPU needed)."""
+import os
+import re
+
+from avex_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "avexhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(avexhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(built_lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(built_lib, name), f"libavexhip.so does not export {name}"
+    # the ctypes binding table covers the header exactly
+    assert sorted(_capi.SYMBOLS) == declared
+
+
+def test_host_only_entry_points(built_lib):
+    assert built_lib.avexhip_abi_version() == 1
+    assert built_lib.avexhip_device_count() >= 0
+    assert built_lib.avexhip_rel_bucket(0, 320, 800) == 0
+    assert built_lib.avexhip_rel_bucket(1, 320, 800) == 161
+    assert built_lib.avexhip_rel_bucket(-495, 320, 800) == 143
+    assert isinstance(_capi.last_error(), str)
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(_capi.FbankConfig) == 9 * 4
+    assert C.sizeof(_capi.BeatsConfig) == 20 * 4
+    assert C.sizeof(_capi.Tensor) == 24
+    # avexhip_gemm_args: pointers/int64 8-byte aligned
+    assert C.sizeof(_capi.GemmArgs) == 136
+
+
+def test_no_cpu_fallback_without_gpu(built_lib):
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from avex_amd import kernels
+    with pytest.raises(_capi.AvexHipError):
+        kernels.FbankPlan()
+    with pytest.raises(_capi.AvexHipError):
+        kernels.gemm(torch.zeros(8, 64, dtype=torch.float16), torch.zeros(128, 64, dtype=torch.float16))

@@ -1,0 +1,190 @@
+"""Plugin/registry API behaviour on CPU (no forward): mirrors the reference's own unit tests
+(tests/unittests/test_base_model.py, test_base_model_all_layers.py, test_api_load.py,
+test_api_registry.py) for the parts of the contract the hot path sits behind."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import avex_amd
+from avex_amd import ModelBase, ModelSpec, registry, synth
+from avex_amd._capi import AvexHipError
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    with open(f"{golden_dir}/base_api.json") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def beats_cpu():
+    spec = avex_amd.get_model_spec("esp_aves2_sl_beats_all").model_copy(deep=True)
+    return avex_amd.build_model_from_spec(spec, "cpu", return_features_only=True)
+
+
+def test_layer_map_is_bit_exact(beats_cpu, meta):
+    assert {str(k): v for k, v in beats_cpu.get_model_layer_map().items()} == meta["layer_map"]
+    assert beats_cpu.get_model_layers() == [meta["layer_map"][str(i)] for i in range(13)]
+
+
+def test_hook_resolution_matches_reference(beats_cpu, meta):
+    assert beats_cpu.register_hooks_for_layers([0, -1]) == meta["resolve_[0,-1]"]
+    assert beats_cpu.register_hooks_for_layers(["all"]) == meta["resolve_all"]
+    assert beats_cpu.register_hooks_for_layers(["last_layer"]) == meta["resolve_last_layer"]
+    assert beats_cpu.register_hooks_for_layers([3, "backbone.encoder.layers.2.fc2", "all", -1]) == meta["resolve_mixed"]
+    assert list(beats_cpu._hooks) == meta["resolve_mixed"] == beats_cpu._hook_layers
+    beats_cpu.deregister_all_hooks()
+    assert not beats_cpu._hooks and beats_cpu._hook_layers == meta["resolve_mixed"]
+    beats_cpu.ensure_hooks_registered()
+    assert list(beats_cpu._hooks) == meta["resolve_mixed"]
+    beats_cpu.deregister_all_hooks()
+
+
+def test_hook_errors_match_reference(beats_cpu, meta):
+    errs = {"ValueError": ValueError, "TypeError": TypeError}
+    with pytest.raises(errs[meta["errors"]["index_oob"]]):
+        beats_cpu.register_hooks_for_layers([13])
+    with pytest.raises(errs[meta["errors"]["neg_oob"]]):
+        beats_cpu.register_hooks_for_layers([-14])
+    with pytest.raises(errs[meta["errors"]["bool"]]):
+        beats_cpu.register_hooks_for_layers([True])
+    with pytest.raises(errs[meta["errors"]["unknown"]]):
+        beats_cpu.register_hooks_for_layers(["backbone.nope"])
+    beats_cpu.deregister_all_hooks()
+    beats_cpu._hook_layers = []
+    with pytest.raises(errs[meta["errors"]["no_hooks"]]):
+        beats_cpu.extract_embeddings(torch.zeros(1, 16000), aggregation="mean")
+    beats_cpu.register_hooks_for_layers([0])
+    with pytest.raises(ValueError):
+        beats_cpu.extract_embeddings(None)
+    with pytest.raises(ValueError):
+        beats_cpu.extract_embeddings(torch.zeros(1, 0))
+
+
+def test_state_dict_keys_and_checkpoint_roundtrip(beats_cpu, tmp_path):
+    ref = synth.beats_state_dict()
+    keys = set(beats_cpu.state_dict())
+    assert len(keys) == 254 and set(ref) <= keys
+    assert keys - set(ref) == {"backbone.fbank.window", "backbone.fbank.mel_fb"}
+    # shared relative-position table: one storage listed under every layer (backbone.py:100-103)
+    sd = beats_cpu.state_dict()
+    assert sd["backbone.encoder.layers.0.self_attn.relative_attention_bias.weight"].data_ptr() == \
+        sd["backbone.encoder.layers.7.self_attn.relative_attention_bias.weight"].data_ptr()
+    from safetensors.numpy import save_file
+    small = {k: v for k, v in ref.items()}
+    path = tmp_path / "ckpt.safetensors"
+    save_file({k: np.ascontiguousarray(v) for k, v in small.items()}, str(path))
+    m = avex_amd.load_model("esp_aves2_sl_beats_all", device="cpu", checkpoint_path=str(path), return_features_only=True)
+    assert m.device == "cpu" and m.classifier is None
+    for k in ("backbone.encoder.layers.5.fc2.weight", "backbone.post_extract_proj.bias",
+              "backbone.encoder.pos_conv.0.parametrizations.weight.original1"):
+        assert torch.equal(m.state_dict()[k], torch.from_numpy(ref[k]))
+    # checkpoints without the backbone. prefix / wrapped .pt files load too (load.py:553-562)
+    pt = tmp_path / "ckpt.pt"
+    torch.save({"model": {k[len("backbone."):]: torch.from_numpy(v) for k, v in small.items()}}, pt)
+    m2 = avex_amd.load_model("esp_aves2_sl_beats_all", device="cpu", checkpoint_path=str(pt), return_features_only=True)
+    assert torch.equal(m2.state_dict()["backbone.encoder.layers.5.fc2.weight"], torch.from_numpy(ref["backbone.encoder.layers.5.fc2.weight"]))
+
+
+def test_classifier_mode_recovers_num_classes(tmp_path):
+    sd = {k: torch.from_numpy(v) for k, v in synth.beats_state_dict().items()}
+    sd["classifier.weight"] = torch.zeros(37, 768)
+    sd["classifier.bias"] = torch.zeros(37)
+    pt = tmp_path / "clf.pt"
+    torch.save({"model_state_dict": sd}, pt)
+    m = avex_amd.load_model("esp_aves2_sl_beats_all", device="cpu", checkpoint_path=str(pt))
+    assert m.num_classes == 37 and isinstance(m.classifier, nn.Linear) and m.classifier.out_features == 37
+    m = avex_amd.load_model("esp_aves2_sl_beats_all", device="cpu", checkpoint_path=str(pt), return_features_only=True)
+    assert m.classifier is None and "classifier.weight" not in m.state_dict()
+
+
+def test_load_model_errors():
+    with pytest.raises(ValueError):
+        avex_amd.load_model("definitely_not_a_model")
+    with pytest.raises(TypeError):
+        avex_amd.load_model(123)
+    with pytest.raises(KeyError):
+        avex_amd.build_model_from_spec(ModelSpec(name="not_a_class", pretrained=False), "cpu")
+    with pytest.raises(FileNotFoundError):
+        avex_amd.load_model("esp_aves2_sl_beats_all", device="cpu", checkpoint_path="/nonexistent/x.safetensors")
+    with pytest.raises(FileNotFoundError):      # default checkpoint is an hf:// URI: unreachable offline
+        avex_amd.load_model("esp_aves2_sl_beats_all", device="cpu")
+    with pytest.raises(KeyError):
+        avex_amd.get_checkpoint_path("definitely_not_a_model")
+
+
+def test_registry_lists_the_official_ids():
+    ids = set(avex_amd.list_models())
+    assert len(ids) >= 10 and {"esp_aves2_sl_beats_all", "esp_aves2_sl_beats_bio", "esp_aves2_naturelm_audio_v1_beats",
+                               "esp_aves2_effnetb0_all", "esp_aves2_eat_all"} <= ids
+    spec = avex_amd.get_model_spec("esp_aves2_sl_beats_all")
+    assert spec.name == "beats" and spec.fine_tuned and spec.init_config["encoder_layers"] == 12
+    assert spec.audio_config.representation == "raw" and spec.audio_config.target_length_seconds == 10
+    assert avex_amd.get_model_spec("nope") is None
+    assert avex_amd.get_checkpoint_path("esp_aves2_sl_beats_all").startswith("hf://EarthSpeciesProject/")
+    d = avex_amd.describe_model("esp_aves2_naturelm_audio_v1_beats")
+    assert d["model_spec"]["use_naturelm"] is True
+    info = avex_amd.list_model_layers("esp_aves2_sl_beats_all")
+    assert info["last_layer"] == "backbone.encoder.layers.11.fc2" and len(info["layers"]) == 13
+
+
+def test_custom_model_class_plugin(tmp_path):
+    """docs/custom_model_registration.md flow: register a class, a spec, build through the factory,
+    use the generic hook machinery with an ordinary torch forward."""
+
+    @avex_amd.register_model_class
+    class TinyNet(ModelBase):
+        name = "tiny_net_test"
+
+        def __init__(self, device: str, audio_config=None, num_classes: int = 3, return_features_only: bool = False):
+            super().__init__(device=device, audio_config=audio_config)
+            self.body = nn.Sequential(nn.Linear(16, 8), nn.ReLU(), nn.Linear(8, 8))
+            self.classifier = nn.Linear(8, num_classes)
+
+        def forward(self, x, padding_mask=None):
+            return self.classifier(self.body(x))
+
+    assert "tiny_net_test" in avex_amd.list_model_classes()
+    avex_amd.register_model("tiny_spec", ModelSpec(name="tiny_net_test", pretrained=False, device="cpu", model_id=None))
+    m = avex_amd.build_model("tiny_spec", "cpu", num_classes=5, not_a_param=1)     # unknown kwargs are filtered
+    assert m.classifier.out_features == 5
+    assert m.get_model_layers() == ["body.0", "body.2", "classifier"]
+    assert m.register_hooks_for_layers(["last_layer"]) == ["body.2"]
+    x = torch.randn(4, 16)
+    e = m.extract_embeddings(x, aggregation="mean")
+    assert e.shape == (4, 8) and torch.allclose(e, m.body(x))
+    m.register_hooks_for_layers(["all"])
+    e = m.extract_embeddings({"raw_wav": x}, aggregation="none")
+    assert isinstance(e, list) and [tuple(t.shape) for t in e] == [(4, 8), (4, 8), (4, 5)]
+    assert m.extract_embeddings(x, aggregation="mean").shape == (4, 21)
+    assert not m._hook_outputs                       # cleared after extraction
+    yml = tmp_path / "my_tiny.yml"
+    yml.write_text("model_spec:\n  name: tiny_net_test\n  pretrained: false\n  device: cpu\n")
+    m2 = avex_amd.load_model(str(yml), device="cpu", return_features_only=True)
+    assert isinstance(m2, TinyNet) and avex_amd.get_model_spec("my_tiny") is not None
+
+
+def test_beats_forward_needs_gpu(beats_cpu):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(AvexHipError):
+        beats_cpu(torch.zeros(1, 16000))
+
+
+def test_padding_mask_geometry(beats_cpu):
+    """forward_padding_mask twice: 32000 samples -> 198 frames (drop 32000 % 198) -> 96 tokens (drop 198 % 96)."""
+    from oracle import beats_oracle as O
+    pm = torch.zeros(2, 32000, dtype=torch.bool); pm[1, 16000:] = True
+    a = beats_cpu.forward_padding_mask(96, beats_cpu.forward_padding_mask(198, pm))
+    b = O.forward_padding_mask(96, O.forward_padding_mask(198, pm.numpy()))
+    assert a.shape == (2, 96) and np.array_equal(a.numpy(), b) and a[1].sum() > 40 and not a[0].any()
+
+
+def test_unsupported_variants_fail_loudly():
+    with pytest.raises(AvexHipError):
+        avex_amd.beats_model.Model(device="cpu", init_config=dict(synth.BEATS_BASE_CFG, layer_norm_first=True, deep_norm=False))
+    with pytest.raises(FileNotFoundError):
+        avex_amd.beats_model.Model(device="cpu", pretrained=True)

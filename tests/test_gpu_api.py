@@ -1,0 +1,137 @@
+"""Drop-in API on the GPU (`-m gpu`): load_model -> forward / hooks / extract_embeddings, checked
+against the goldens the real reference produced through the same public calls."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import avex_amd
+from _util import rel_l2
+from avex_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3      # BASELINE.json: pooled 768-d embedding within 1e-3 relative of the reference CPU path
+
+
+@pytest.fixture(scope="module")
+def model(built_lib, tmp_path_factory):
+    from safetensors.numpy import save_file
+    path = tmp_path_factory.mktemp("ckpt") / "synthetic_beats.safetensors"
+    save_file({k: np.ascontiguousarray(v) for k, v in synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0).items()}, str(path))
+    m = avex_amd.load_model("esp_aves2_sl_beats_all", device="cuda", checkpoint_path=str(path), return_features_only=True)
+    return m.eval()
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(f"{golden_dir}/base_api.npz")
+
+
+def test_forward_features(model, g):
+    x = torch.from_numpy(synth.noise_clips(1, 160000, seed=0))          # CPU tensor in: process_audio moves it
+    f = model(x)
+    assert f.shape == (1, 496, 768) and f.is_cuda and f.dtype == torch.float32
+    assert rel_l2(f.mean(1).cpu().numpy(), g["b1.pooled"]) < TOL
+    assert model.device == "cuda"
+
+
+def test_extract_embeddings_aggregations(model, g, golden_dir):
+    with open(f"{golden_dir}/base_api.json") as fh:
+        meta = json.load(fh)
+    assert model.register_hooks_for_layers([0, -1]) == meta["resolve_[0,-1]"]
+    x = torch.from_numpy(synth.noise_clips(2, 32000, seed=5)).cuda()
+    for agg in ("mean", "max", "cls_token"):
+        e = model.extract_embeddings(x, aggregation=agg)
+        assert e.shape == (2, 1536)
+        assert rel_l2(e.cpu().numpy(), g[f"agg.{agg}"]) < (TOL if agg == "mean" else 4 * TOL)   # max/cls are frame-level
+    lst = model.extract_embeddings(x, aggregation="none")
+    assert [list(t.shape) for t in lst] == meta["agg_none_shapes"]
+    assert rel_l2(lst[0][:, ::8].cpu().numpy(), g["agg.none0_tok8"]) < 4 * TOL
+    assert rel_l2(lst[1][:, ::8].cpu().numpy(), g["agg.none1_tok8"]) < 4 * TOL
+    # one layer -> a tensor, not a list
+    model.register_hooks_for_layers(["last_layer"])
+    one = model.extract_embeddings(x, aggregation="none")
+    assert isinstance(one, torch.Tensor) and one.shape == (2, 96, 768)
+    assert not model._hook_outputs
+
+
+def test_all_layers_mean(model, g):
+    names = model.register_hooks_for_layers(["all"])
+    assert len(names) == 13
+    x = torch.from_numpy(synth.noise_clips(4, 160000, seed=0)).cuda()
+    e = model.extract_embeddings(x, aggregation="mean")
+    assert e.shape == (4, 13 * 768)
+    assert rel_l2(e.cpu().numpy(), g["b4.all_mean"]) < TOL
+
+
+def test_dict_input_with_padding_mask(model, g):
+    model.register_hooks_for_layers([0, -1])
+    x = torch.from_numpy(synth.noise_clips(2, 32000, seed=5)).cuda()
+    pm = torch.zeros(2, 32000, dtype=torch.bool); pm[1, 16000:] = True
+    e = model.extract_embeddings({"raw_wav": x, "padding_mask": pm.cuda()}, aggregation="mean")
+    assert rel_l2(e.cpu().numpy(), g["mask.mean"]) < TOL
+    f = model(x, pm)
+    assert rel_l2(f[:, ::8].cpu().numpy(), g["mask.features_tok8"]) < 4 * TOL
+
+
+def test_user_forward_hook_fires(model):
+    """A hook registered directly on a tap module (not via register_hooks_for_layers) is delivered too."""
+    model.deregister_all_hooks()
+    seen = {}
+    mod = model.get_submodule("backbone.encoder.layers.4.fc2")
+    h = mod.register_forward_hook(lambda m, i, o: seen.setdefault("out", o))
+    x = torch.from_numpy(synth.noise_clips(1, 16000, seed=2)).cuda()
+    model(x)
+    h.remove()
+    assert seen["out"].shape == (1, 48, 768)
+    model(x)                                    # no hooks -> no taps requested, still fine
+
+
+def test_tones_and_regression_inputs(model, g):
+    x = torch.from_numpy(synth.tone_clips(16000)).cuda()
+    f = model(x)
+    assert rel_l2(f.mean(1).cpu().numpy(), g["tone.pooled"]) < TOL
+
+
+def test_classifier_mode_and_reload(model, tmp_path):
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sd["classifier.weight"] = torch.from_numpy(synth.normal("clfw", (5, 768), 0.05))
+    sd["classifier.bias"] = torch.from_numpy(synth.normal("clfb", (5,), 0.05))
+    pt = tmp_path / "clf.pt"
+    torch.save({"model_state_dict": sd}, pt)
+    m = avex_amd.load_model("esp_aves2_sl_beats_all", device="cuda", checkpoint_path=str(pt)).eval()
+    x = torch.from_numpy(synth.noise_clips(2, 32000, seed=5)).cuda()
+    logits = m(x)
+    assert logits.shape == (2, 5)
+    feats = model(x)
+    ref = feats.mean(1) @ sd["classifier.weight"].cuda().T + sd["classifier.bias"].cuda()
+    assert torch.allclose(logits, ref, atol=1e-4)
+    # masked mean pooling when a padding mask is given (beats_model.py:269-273)
+    pm = torch.zeros(2, 32000, dtype=torch.bool); pm[1, 16000:] = True
+    lm = m(x, pm)
+    fm = model(x, pm)
+    fp = model.forward_padding_mask(96, model.forward_padding_mask(198, pm)).cuda()
+    keep = (~fp).unsqueeze(-1).float()
+    ref = ((fm * keep).sum(1) / keep.sum(1)) @ sd["classifier.weight"].cuda().T + sd["classifier.bias"].cuda()
+    assert torch.allclose(lm, ref, atol=1e-4)
+    # in-place weight edit + refresh is picked up by the HIP handle
+    with torch.no_grad():
+        m.backbone.encoder.layers[11].final_layer_norm.bias.add_(1.0)
+    m.refresh_weights()
+    assert not torch.allclose(m(x), logits)
+
+
+def test_frontend_namespace(g, golden_dir):
+    from avex_amd import preprocessing
+    fb = np.load(f"{golden_dir}/fbank.npz")
+    x = torch.from_numpy(synth.noise_clips(2, 16000, seed=0)).cuda()
+    y = preprocessing.BatchedFbank()(x * 2 ** 15)
+    assert y.shape == (2, 98, 128) and float(np.abs(y.cpu().numpy() - fb["noise16k"]).max()) < 1e-3
+    z = preprocessing.beats_preprocess(x)
+    assert torch.allclose(z, (y - 15.41663) / (2 * 6.55582), atol=2e-5)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
