@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64), ("alpha", C.c_float),
-                ("gelu", C.c_int32), ("out_f32", C.c_void_p), ("ldo", C.c_int64),
+                ("resid_half", C.c_void_p), ("ldrh", C.c_int64), ("gelu", C.c_int32), ("out_f32", C.c_void_p), ("ldo", C.c_int64),
                 ("out_half", C.c_void_p), ("ldh", C.c_int64), ("out_raw", C.c_void_p), ("ldraw", C.c_int64),
                 ("variant", C.c_int32)]
 
@@ -42,7 +42,8 @@ class BeatsConfig(C.Structure):
                 ("num_buckets", C.c_int32), ("max_distance", C.c_int32), ("gru_rel_pos", C.c_int32),
                 ("deep_norm", C.c_int32), ("num_mel_bins", C.c_int32), ("sample_frequency", C.c_float),
                 ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float), ("fbank_mean", C.c_float),
-                ("fbank_std", C.c_float), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32)]
+                ("fbank_std", C.c_float), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32),
+                ("residual_dtype", C.c_int32)]
 
 
 class Tensor(C.Structure):
@@ -62,11 +63,11 @@ SYMBOLS = {
     "avexhip_cast_f32_to_half": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_cast_half_to_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _P]),
-    "avexhip_layernorm": (C.c_int, [_P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P,
+    "avexhip_layernorm": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P,
                                     C.c_int64, C.c_int, _P]),
     "avexhip_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_posconv_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
-    "avexhip_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "avexhip_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "avexhip_mean_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "avexhip_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "avexhip_beats_create": (_P, [C.POINTER(BeatsConfig), C.POINTER(Tensor), C.c_int]),

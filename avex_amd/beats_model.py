@@ -137,7 +137,7 @@ class Model(ModelBase):
                  audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None, return_features_only: bool = False,
                  use_naturelm: bool = False, fine_tuned: bool = False, disable_layerdrop: bool = False,
                  init_config: Optional[Dict[str, Any]] = None, operand_dtype: Optional[str] = None,
-                 max_chunk_clips: int = 0) -> None:
+                 max_chunk_clips: int = 0, residual: Optional[str] = None) -> None:
         super().__init__(device=device, audio_config=audio_config)
         if num_classes is None:
             return_features_only = True
@@ -153,6 +153,8 @@ class Model(ModelBase):
         self.beats_cfg = resolve_beats_config(init_config, self.fine_tuned, self.use_naturelm)
         self.operand_dtype = operand_dtype or os.environ.get("AVEX_AMD_OPERAND", "f16")
         self.max_chunk_clips = int(max_chunk_clips or os.environ.get("AVEX_AMD_CHUNK", "0"))
+        # inter-kernel residual stream: "half" (operand type; default) or "f32" (4x lower frame-level error)
+        self.residual = residual or os.environ.get("AVEX_AMD_RESIDUAL", "half")
         kernels.make_beats_config(self.beats_cfg, self.operand_dtype)        # validates what the HIP path supports
 
         self.backbone = BeatsParameters(self.beats_cfg)
@@ -194,7 +196,7 @@ class Model(ModelBase):
             with torch.cuda.device(p.device):
                 state = {k: v for k, v in self.state_dict().items() if k.startswith("backbone.")}
                 self._encoder = kernels.BeatsEncoder(self.beats_cfg, state, operand_dtype=self.operand_dtype,
-                                                     max_chunk_clips=self.max_chunk_clips)
+                                                     max_chunk_clips=self.max_chunk_clips, residual=self.residual)
             self._weights_dirty = False
         return self._encoder
 

@@ -46,15 +46,16 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     g.A = a->A; g.lda = a->lda; g.W = a->W; g.ldw = a->ldw;
     g.M = a->M; g.N = a->N; g.K = a->K;
     g.bias = a->bias; g.resid = a->resid; g.ldr = a->ldr; g.alpha = a->alpha; g.gelu = a->gelu;
+    g.resid_half = a->resid_half; g.ldrh = a->ldrh;
     g.out_f32 = a->out_f32; g.ldo = a->ldo; g.out_half = a->out_half; g.ldh = a->ldh;
     g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
     return avx::gemm(g, dtype, (hipStream_t)stream);
 }
 
-extern "C" int avexhip_layernorm(const float* in, int64_t ld_in, const float* w, const float* b, float eps, int M,
-                                 int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype,
-                                 void* stream) {
-    return avx::layernorm(in, ld_in, w, b, eps, M, C, out_f32, ldo, out_half, ldh, dtype, (hipStream_t)stream);
+extern "C" int avexhip_layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b,
+                                 float eps, int M, int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh,
+                                 int dtype, void* stream) {
+    return avx::layernorm(in, in_half, ld_in, w, b, eps, M, C, out_f32, ldo, out_half, ldh, dtype, (hipStream_t)stream);
 }
 
 extern "C" int avexhip_attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
@@ -69,8 +70,8 @@ extern "C" int avexhip_posconv_pack(const float* g, const float* v, int E, int g
 }
 
 extern "C" int avexhip_posconv(const void* x_half, const float* x_f32, const void* w_packed, const float* bias, int B,
-                               int T, int E, int groups, int K, float* out, int dtype, void* stream) {
-    return avx::posconv(x_half, x_f32, w_packed, bias, B, T, E, groups, K, out, dtype, (hipStream_t)stream);
+                               int T, int E, int groups, int K, float* out_f32, void* out_half, int dtype, void* stream) {
+    return avx::posconv(x_half, x_f32, w_packed, bias, B, T, E, groups, K, out_f32, out_half, dtype, (hipStream_t)stream);
 }
 
 extern "C" int avexhip_mean_pool(const float* in, int B, int T, int C, float* out, void* stream) {
@@ -155,7 +156,8 @@ void default_mel(int n_fft, int n_mels, float sr, float low, float high, std::ve
 struct avexhip_beats {
     avexhip_beats_config cfg;
     int dtype = AVEXHIP_F16;
-    int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 64;
+    int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 256;
+    bool fast = false;   // residual stream / pre-LN sums in the operand type
     float alpha = 1.f;
     avexhip_fbank_plan* fb = nullptr;
     void* w_patch = nullptr;
@@ -385,7 +387,7 @@ int bias_tab_for(avexhip_beats* h, int T, float** out) {
 }
 
 struct Ws {
-    char* patches; float* f0; char* h0; float* x; char* xh; float* pre; char* qkv; char* ah; char* hh; float* raw;
+    char* patches; float* f0; char* h0; float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
     size_t total;
 };
 
@@ -400,7 +402,8 @@ Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
     w.h0 = take(M * h->D * 2);
     w.x = (float*)take(M * h->E * 4);
     w.xh = take(M * h->E * 2);
-    w.pre = (float*)take(M * h->E * 4);
+    w.pre = (float*)take(h->fast ? 256 : M * h->E * 4);
+    w.preh = take(h->fast ? M * h->E * 2 : 256);
     w.qkv = take(M * 3 * h->E * 2);
     w.ah = take(M * h->E * 2);
     w.hh = take(M * h->F * 2);
@@ -475,37 +478,48 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             prof.end();
         }
         // 2. patch embedding (Conv2d as GEMM) -> LayerNorm(D) -> post_extract_proj
+        // "fast" keeps the residual stream (post-LN x) and the pre-LN sums in the operand type between
+        // kernels; otherwise they are fp32.  x32 / pre32 / preh below are NULL when unused.
+        const bool fast = h->fast;
+        float* x32 = w.x;                       // fp32 x (precise mode; in fast mode only hook 0 / final output scratch)
+        float* pre32 = fast ? nullptr : w.pre;
+        void* preh = fast ? w.preh : nullptr;
+        const bool hook0 = (hook_mask & 1u) != 0;
         avx::GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.A = w.patches; g.lda = P * P; g.W = h->w_patch; g.ldw = P * P; g.M = M; g.N = D; g.K = P * P;
-        g.out_f32 = w.f0; g.ldo = D;
+        if (fast) { g.out_half = w.h0; g.ldh = D; } else { g.out_f32 = w.f0; g.ldo = D; }
         prof.begin("gemm.patch_embed", 2.0 * Md * D * P * P);
         RC(avx::gemm(g, dt, s));
         prof.end();
         prof.begin("layernorm", 0.0);
-        RC(avx::layernorm(w.f0, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, h->w_post ? nullptr : w.x, E, h->w_post ? w.h0 : w.xh,
-                          h->w_post ? D : E, dt, s));
+        if (h->w_post) {
+            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, nullptr, D, w.h0, D, dt, s));
+        } else {   // embed_dim == encoder_embed_dim: the LayerNorm output is x itself
+            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, fast ? nullptr : x32, E, w.xh, E, dt, s));
+        }
         prof.end();
         if (h->w_post) {
             memset(&g, 0, sizeof(g));
             g.A = w.h0; g.lda = D; g.W = h->w_post; g.ldw = D; g.M = M; g.N = E; g.K = D; g.bias = h->b_post;
-            g.out_f32 = w.x; g.ldo = E; g.out_half = w.xh; g.ldh = E; g.row_zero = pad;
+            g.out_half = w.xh; g.ldh = E; g.row_zero = pad;
+            if (!fast || hook0) { g.out_f32 = x32; g.ldo = E; }
             prof.begin("gemm.post_extract_proj", 2.0 * Md * E * D);
             RC(avx::gemm(g, dt, s));
             prof.end();
         }
-        if ((hook_mask & 1u) && h->w_post) {
+        if (hook0 && h->w_post) {
             // the reference's hook holds the tensor that the encoder then zeroes in place at padded tokens
             // (beats.py:359-361 + backbone.py:169-170), so the tap equals x after masking
-            if (hook_pooled) RC(avx::mean_pool(w.x, Bc, Tt, E, nullptr, hook_out[0] + (size_t)c0 * E, s));
-            else AVX_HIP_CHECK(hipMemcpyAsync(hook_out[0] + (size_t)c0 * Tt * E, w.x, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, s));
+            if (hook_pooled) RC(avx::mean_pool(x32, Bc, Tt, E, nullptr, hook_out[0] + (size_t)c0 * E, s));
+            else AVX_HIP_CHECK(hipMemcpyAsync(hook_out[0] + (size_t)c0 * Tt * E, x32, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, s));
         }
         // 3. convolutional positional embedding + residual, encoder LayerNorm
         prof.begin("posconv", 2.0 * Md * E * (E / h->cfg.conv_pos_groups) * h->cfg.conv_pos);
-        RC(avx::posconv(w.xh, w.x, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, w.pre, dt, s));
+        RC(avx::posconv(w.xh, fast ? nullptr : x32, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, pre32, preh, dt, s));
         prof.end();
         prof.begin("layernorm", 0.0);
-        RC(avx::layernorm(w.pre, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, w.x, E, w.xh, E, dt, s));
+        RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, s));
         prof.end();
 
         // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375)
@@ -521,13 +535,14 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             RC(avx::attention(w.qkv, Bc, Tt, H, bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, pad, w.ah, dt, s));
             prof.end();
             memset(&g, 0, sizeof(g));
-            g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o;
-            g.resid = w.x; g.ldr = E; g.alpha = h->alpha; g.out_f32 = w.pre; g.ldo = E;
+            g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = h->alpha;
+            if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
+            else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
             prof.begin("gemm.out_proj", 2.0 * Md * E * E);
             RC(avx::gemm(g, dt, s));
             prof.end();
             prof.begin("layernorm", 0.0);
-            RC(avx::layernorm(w.pre, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, w.x, E, w.xh, E, dt, s));
+            RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, s));
             prof.end();
             memset(&g, 0, sizeof(g));
             g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
@@ -537,8 +552,9 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             prof.end();
             const bool hooked = (hook_mask >> (i + 1)) & 1u;
             memset(&g, 0, sizeof(g));
-            g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2;
-            g.resid = w.x; g.ldr = E; g.alpha = h->alpha; g.out_f32 = w.pre; g.ldo = E;
+            g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = h->alpha;
+            if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
+            else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
             if (hooked) {
                 g.out_raw = hook_pooled ? w.raw : hook_out[i + 1] + (size_t)c0 * Tt * E;
                 g.ldraw = E;
@@ -548,9 +564,12 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             prof.end();
             if (hooked && hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, hook_out[i + 1] + (size_t)c0 * E, s));
             const bool last = i == L - 1;
-            float* xo = (last && features_out) ? features_out + (size_t)c0 * Tt * E : w.x;
+            // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
+            float* xo = nullptr;
+            if (last) xo = features_out ? features_out + (size_t)c0 * Tt * E : ((pooled_out || !fast) ? x32 : nullptr);
+            else if (!fast) xo = x32;
             prof.begin("layernorm", 0.0);
-            RC(avx::layernorm(w.pre, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, s));
+            if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, s));
             prof.end();
             if (last && pooled_out) {
                 prof.begin("mean_pool", 0.0);
@@ -559,8 +578,12 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             }
         }
         if (L == 0) {
-            if (features_out) AVX_HIP_CHECK(hipMemcpyAsync(features_out + (size_t)c0 * Tt * E, w.x, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, s));
-            if (pooled_out) RC(avx::mean_pool(w.x, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, s));
+            // no layers: features = encoder LayerNorm output; recompute it in fp32 for the outputs
+            if (features_out || pooled_out) {
+                float* xo = features_out ? features_out + (size_t)c0 * Tt * E : x32;
+                RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, xo, E, nullptr, E, dt, s));
+                if (pooled_out) RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, s));
+            }
         }
     }
 #undef RC
@@ -625,7 +648,8 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->dtype = c.operand_dtype;
     h->E = c.encoder_embed_dim; h->F = c.encoder_ffn_embed_dim; h->H = c.encoder_attention_heads;
     h->L = c.encoder_layers; h->D = c.embed_dim; h->P = c.input_patch_size; h->NM = c.num_mel_bins;
-    h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 64;
+    h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
+    h->fast = c.residual_dtype != 0;
     h->alpha = c.deep_norm ? powf(2.0f * (float)c.encoder_layers, 0.25f) : 1.0f;
     if (build(h, tensors, n_tensors) != AVEXHIP_OK) {
         delete h;

@@ -45,9 +45,37 @@ static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// exact-erf GELU (reference: torch.nn.functional.gelu default, modules.py:191-200)
+// erf-form GELU (reference: torch.nn.functional.gelu default, modules.py:191-200).  erf is evaluated
+// branch-free with Abramowitz-Stegun 7.1.26 (|error| <= 6e-7 in fp32, i.e. 3 orders below the f16
+// rounding of the stored activation): ~14 VALU ops instead of libm erff's ~45 with divergent branches,
+// which matters because this runs 3072 times per token in the fc1 epilogue.
+static __device__ __forceinline__ float fast_erf(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float p = 1.061405429f;
+    p = __builtin_fmaf(p, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float r = __builtin_fmaf(-p, __expf(-(ax * ax)), 1.0f);
+    return __builtin_copysignf(r, x);
+}
+// gelu(x) = x * Phi(x) = 0.5 x + |x| (0.5 - q),  q = 0.5 * poly(t) * exp(-x^2/2),  t = 1/(1 + p |x|/sqrt2)
+// (same A-S 7.1.26 polynomial with the 0.5 and the 1/sqrt2 folded into the constants; explicit FMAs
+// because the library is built with -ffp-contract=off)
 static __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = 0.5f * 1.061405429f;
+    p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
+    p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+    p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
+    const float u = __builtin_fmaf(-p, e, 0.5f);
+    return __builtin_fmaf(ax, u, 0.5f * x);
 }
 
 static __device__ __forceinline__ float wave_sum(float v) {
@@ -112,16 +140,18 @@ struct GemmArgs {
     int M, N, K;
     const float* bias;
     const float* resid; int64_t ldr; float alpha;
+    const void* resid_half; int64_t ldrh;   // residual in the operand type (used when resid == NULL)
     int gelu;
     float* out_f32; int64_t ldo;
     void* out_half; int64_t ldh;
     float* out_raw; int64_t ldraw;
-    const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to out_f32/out_half
+    const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to every output
     int variant;
 };
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
-int layernorm(const float* in, int64_t ld_in, const float* w, const float* b, float eps, int M, int C,
-              float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s);
+// exactly one of in / in_half is non-null
+int layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int M,
+              int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s);
 int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s);
 int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s);
 int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s);
@@ -130,8 +160,9 @@ int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const
               hipStream_t s);
 int posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed, int dtype,
                  hipStream_t s);
+// residual = x_f32 if non-null else x_half; writes out_f32 and/or out_half
 int posconv(const void* x_half, const float* x_f32, const void* w_packed, const float* bias, int B, int T,
-            int E, int groups, int K, float* out, int dtype, hipStream_t s);
+            int E, int groups, int K, float* out_f32, void* out_half, int dtype, hipStream_t s);
 
 struct FbankDev {
     int win, hop, n_mels;

@@ -36,8 +36,8 @@ __global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__
 // One wave per row; lanes hold float4 slices lane, lane+64, ... (C <= 1024).  Two-pass statistics in
 // registers (mean, then centred variance) like torch's CPU LayerNorm.
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int64_t ld_in,
-                                                        const float* __restrict__ w,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const T* __restrict__ in_h,
+                                                        int64_t ld_in, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, int M,
                                                         int C, float* __restrict__ out_f32, int64_t ldo,
                                                         T* __restrict__ out_h, int64_t ldh) {
@@ -45,14 +45,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nv = C >> 2;  // float4 per row
-    const float* x = in + (int64_t)row * ld_in;
     f32x4 v[4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
-            v[i] = *(const f32x4*)(x + idx * 4);
+            if (in_h) {
+                const typename Half<T>::v4 hv = *(const typename Half<T>::v4*)(in_h + (int64_t)row * ld_in + idx * 4);
+                v[i] = (f32x4){(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            } else {
+                v[i] = *(const f32x4*)(in + (int64_t)row * ld_in + idx * 4);
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         } else {
             v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -175,9 +179,9 @@ int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s)
     return AVEXHIP_OK;
 }
 
-int layernorm(const float* in, int64_t ld_in, const float* w, const float* b, float eps, int M, int C,
-              float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s) {
-    AVX_REQUIRE(in && w && b, "layernorm: null input");
+int layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int M,
+              int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s) {
+    AVX_REQUIRE((in != nullptr) != (in_half != nullptr) && w && b, "layernorm: exactly one of in / in_half, and weight/bias, must be given");
     AVX_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "layernorm: C=%d must be a multiple of 4 and <= 1024", C);
     AVX_REQUIRE(ld_in % 4 == 0 && (!out_f32 || ldo % 4 == 0) && (!out_half || ldh % 4 == 0),
                 "layernorm: leading dims must be multiples of 4");
@@ -185,9 +189,9 @@ int layernorm(const float* in, int64_t ld_in, const float* w, const float* b, fl
     if (M <= 0) return AVEXHIP_OK;
     const dim3 grid((M + 3) / 4);
     if (dtype == AVEXHIP_F16)
-        hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, s, in, ld_in, w, b, eps, M, C, out_f32, ldo, (_Float16*)out_half, ldh);
+        hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, dim3(256), 0, s, in, (const _Float16*)in_half, ld_in, w, b, eps, M, C, out_f32, ldo, (_Float16*)out_half, ldh);
     else if (dtype == AVEXHIP_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, s, in, ld_in, w, b, eps, M, C, out_f32, ldo, (__bf16*)out_half, ldh);
+        hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, dim3(256), 0, s, in, (const __bf16*)in_half, ld_in, w, b, eps, M, C, out_f32, ldo, (__bf16*)out_half, ldh);
     else {
         avexhip_set_error("layernorm: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;

@@ -147,16 +147,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
             const int n = n0 + wr * 64 + i * 16 + (lane >> 4) * 4;
             f32x4 v = acc[i][j];
             if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (zero_row) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (p.out_raw) *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + n) = v;
             if (p.resid) {
                 const f32x4 r = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
+                v = r * alpha + v;
+            } else if (p.resid_half) {
+                const v4 rh = *(const v4*)((const T*)p.resid_half + (int64_t)m * p.ldrh + n);
+                const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v = r * alpha + v;
             }
             if (p.gelu) {
                 v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]);
                 v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
             }
-            if (zero_row) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
                 v4 h;
@@ -168,11 +172,250 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Variant 2: 256x256x64 tile, 8 waves (2 along n x 4 along m, 128x64 outputs per wave), 128 KiB LDS
+// (2 stages), staged by LDS-DMA in HALF-tiles that follow the order in which the waves finish with
+// them, so three half-tiles are always in flight under the MFMAs (counted vmcnt, raw s_barrier).
+//
+// A K-tile is consumed in two phases of 32 MFMAs per wave:
+//     A: (W0 x X0,X1)      B: (W1 x X0,X1)
+// W0/W1 = the wave's first/second 64 weight rows, X0/X1 = its first/second 32 activation rows; a
+// half-tile is those rows of ALL waves (128 rows x 64 k = 16 KiB = 2 DMA instructions per wave).
+// Phase = [L: ds_read the fragments that change (A: 16 reads, B: 8), issue half-tile DMAs, retire my
+// LDS reads] barrier [M: 32 MFMAs = 512 cycles] barrier.  Waves 4-7 run one barrier behind waves 0-3,
+// so on every SIMD one wave is in its MFMA segment while its partner is in its (shorter) load segment.
+// Half-tile release/refill schedule (region: last read in phase -> refilled with tile t+2 in phase):
+//     W0, X0, X1: A(t) -> B(t)          W1: B(t) -> A(t+1)
+// All LDS reads are retired (lgkmcnt(0)) BEFORE the barrier that ends an L segment, so a refill
+// issued one phase later can never overtake a read (WAR), also across the one-barrier stagger.
+// Tile t+1 is complete when its last half-tile W1(t+1) (issued in A(t)) has landed: the three
+// half-tiles issued in B(t) = 6 DMA instructions are younger, hence vmcnt(6) in B(t), before the
+// barrier that every wave must pass before any wave reads tile t+1 (RAW).
+// ---------------------------------------------------------------------------------------------
+constexpr int T2 = 256;
+constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32 KiB)
+
+#define AVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define AVX_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half<T>::v8 v8;
+    typedef typename Half<T>::v4 v4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;   // wm also selects the stagger group (waves 4-7 lag)
+    const int tiles_n = p.N / T2;
+    const int tiles_m = (p.M + T2 - 1) / T2;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * T2, n0 = tn * T2;
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+    const int nk = p.K / BK;
+
+    // ---- per-lane DMA source pointers: [half][q] for W and X ------------------------------------
+    // W half h = rows 128q + 64h + 8*wid + (lane>>3); X half h = rows 128q + 64*(wid>>2) + 32h + 8*(wid&3) + (lane>>3)
+    const T* wsrc[2][2];
+    const T* xsrc[2][2];
+    int wdst[2][2], xdst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int wb = 128 * q + 64 * h + 8 * wid;
+            const int wr = wb + (lane >> 3);
+            wsrc[h][q] = W + (int64_t)(n0 + wr) * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3);
+            wdst[h][q] = wb * 128;
+            const int xb = 128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3);
+            const int xr = xb + (lane >> 3);
+            int arow = m0 + xr;
+            arow = arow < p.M ? arow : p.M - 1;
+            xsrc[h][q] = A + (int64_t)arow * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3);
+            xdst[h][q] = T2 * BK * 2 + xb * 128;
+        }
+    auto dma_w = [&](int h, int kt) __attribute__((always_inline)) {
+        char* base = smem + (kt & 1) * STAGE2;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, 0);
+    };
+    auto dma_x = [&](int h, int kt) __attribute__((always_inline)) {
+        char* base = smem + (kt & 1) * STAGE2;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, 0);
+    };
+
+    // ---- per-lane fragment read offsets (swizzle depends on lane only: rows start at multiples of 16)
+    const int sw = (lane >> 1) & 7;
+    const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);   // k-substep 0
+    const int foff1 = foff0 ^ 64;                                        // k-substep 1: chunk + 4
+    const int wfrag = (wm * 128) * 128;
+    const int xfrag = T2 * BK * 2 + (wn * 64) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v8 wf[4][2], xf[4][2];
+
+#define AVX_READ_W(h, st)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+        const char* r = smem + (st) * STAGE2 + wfrag + (64 * (h) + 16 * i) * 128;              \
+        wf[i][0] = *(const v8*)(r + foff0);                                                    \
+        wf[i][1] = *(const v8*)(r + foff1);                                                    \
+    }
+#define AVX_READ_X(st)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+        const char* r = smem + (st) * STAGE2 + xfrag + (16 * j) * 128;                         \
+        xf[j][0] = *(const v8*)(r + foff0);                                                    \
+        xf[j][1] = *(const v8*)(r + foff1);                                                    \
+    }
+#define AVX_HALF(hw)                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+        acc[4 * (hw) + i][j] = mfma16(wf[i][ks], xf[j][ks], acc[4 * (hw) + i][j]);             \
+    __builtin_amdgcn_s_setprio(0);
+#define AVX_BAR()                                   \
+    __builtin_amdgcn_sched_barrier(0);              \
+    __builtin_amdgcn_s_barrier();                   \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: tile 0 complete, W0/X0/X1 of tile 1 in flight --------------------------------
+    dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
+    if (nk > 1) {
+        dma_w(0, 1); dma_x(0, 1); dma_x(1, 1);
+        AVX_VMCNT(6);
+    } else {
+        AVX_VMCNT(0);
+    }
+    AVX_BAR();
+    if (wm == 1) { AVX_BAR(); }   // stagger: waves 4-7 run one barrier behind
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        // A: W0 x (X0, X1); refill W1 of tile kt+1 (other stage, last read in B of tile kt-1)
+        AVX_READ_X(st);
+        AVX_READ_W(0, st);
+        if (kt + 1 < nk) dma_w(1, kt + 1);
+        AVX_LGKM0();
+        AVX_BAR();
+        AVX_HALF(0);
+        AVX_BAR();
+        // B: W1 x (X0, X1); refill W0, X0, X1 with tile kt+2; make tile kt+1 visible
+        AVX_READ_W(1, st);
+        if (kt + 2 < nk) {
+            dma_w(0, kt + 2); dma_x(0, kt + 2); dma_x(1, kt + 2);
+            AVX_VMCNT(6);
+        } else {
+            AVX_VMCNT(0);
+        }
+        AVX_LGKM0();
+        AVX_BAR();
+        AVX_HALF(1);
+        AVX_BAR();
+    }
+    if (wm == 0) { AVX_BAR(); }   // re-align the two groups
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    // Each wave transposes its 128(n) x 64(m) accumulators through a private LDS slab (the stage
+    // buffers are free: every wave is past the last barrier) in four 64(n) x 32(m) chunks, so that
+    // global traffic is row-contiguous: a lane owns 8 consecutive n of one row (16-byte f16 / 2x16-byte
+    // fp32 vectors), 8 lanes cover a 128-byte line, a wave instruction writes 8 full lines.  The
+    // direct-from-accumulator form (8-byte stores, 32 B per row per instruction) ran the store path at
+    // ~2 TB/s and cost 16 us per tile; bias / residual / GELU / masking happen after the transpose.
+    {
+        constexpr int EP_LD = 68;   // floats per slab row (64 n + 4 pad: conflict-free 16-byte writes)
+        float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
+        const int er = lane >> 3, ec = lane & 7;
+        const float alpha = p.alpha;
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;   // this lane's 8 consecutive columns
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        *(f32x4*)(slab + (16 * j + (lane & 15)) * EP_LD + 16 * i + 4 * (lane >> 4)) = acc[4 * ih + i][2 * jh + j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my wave's slab writes are done (LDS is in-order per wave)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int ml = 8 * ps + er;
+                    const int m = m0 + wn * 64 + 32 * jh + ml;
+                    f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
+                    f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
+                    if (m >= p.M) continue;
+                    v0 += b0; v1 += b1;
+                    if (p.row_zero != nullptr && p.row_zero[m] != 0) {
+                        v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
+                    }
+                    if (p.out_raw) {
+                        *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb) = v0;
+                        *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4) = v1;
+                    }
+                    if (p.resid) {
+                        const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
+                        const f32x4 r1 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf(r0[e], alpha, v0[e]); v1[e] = __builtin_fmaf(r1[e], alpha, v1[e]); }
+                    } else if (p.resid_half) {
+                        const v8 rh = *(const v8*)((const T*)p.resid_half + (int64_t)m * p.ldrh + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rh[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rh[4 + e], alpha, v1[e]); }
+                    }
+                    if (p.gelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
+                    }
+                    if (p.out_f32) {
+                        *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb) = v0;
+                        *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4) = v1;
+                    }
+                    if (p.out_half) {
+                        v8 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
+                        *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+#undef AVX_READ_W
+#undef AVX_READ_X
+#undef AVX_HALF
+#undef AVX_BAR
+}
+
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
+    // variant: 0 = auto, 1 = 128-tile register staging, 2 = 256-tile half-tile pipeline, 3 = 128-tile LDS-DMA
+    int variant = a.variant;
+    if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 2 : 3;
+    if (variant == 2 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
+    if (variant == 2) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2));
+            attr_set = true;
+        }
+        const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
+        hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), 2 * STAGE2, s, a);
+        AVX_LAUNCH_CHECK();
+        return AVEXHIP_OK;
+    }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     const size_t lds = 2 * 2 * TILE_BYTES;
-    if (a.variant == 1) {
+    if (variant == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(tiles), dim3(256), lds, s, a);
     } else {
         hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(tiles), dim3(256), lds, s, a);
@@ -193,7 +436,8 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     AVX_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
     AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw, "gemm: no output buffer");
     AVX_REQUIRE((!a.out_f32 || a.ldo % 4 == 0) && (!a.out_half || a.ldh % 4 == 0) &&
-                    (!a.out_raw || a.ldraw % 4 == 0) && (!a.resid || a.ldr % 4 == 0),
+                    (!a.out_raw || a.ldraw % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&
+                    (!a.resid_half || a.ldrh % 4 == 0),
                 "gemm: output/residual leading dims must be multiples of 4 elements");
     if (dtype == AVEXHIP_F16) return launch<_Float16>(a, s);
     if (dtype == AVEXHIP_BF16) return launch<__bf16>(a, s);

@@ -28,7 +28,8 @@ constexpr int KTOT = KT * CG;                     // 6144
 template <typename T>
 __global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf,
                                                       const T* __restrict__ wp, const float* __restrict__ bias,
-                                                      int Tn, int E, int G, float* __restrict__ out) {
+                                                      int Tn, int E, int G, float* __restrict__ out,
+                                                      T* __restrict__ out_h) {
     extern __shared__ __attribute__((aligned(16))) char slab[];
     typedef typename Half<T>::v8 v8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,8 +109,21 @@ __global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, 
             const int n = ot * 16 + 4 * g4;
             f32x4 v = acc[ot][tt] + *(const f32x4*)(bias + g * CG + n);
             v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-            const f32x4 r = *(const f32x4*)(xf + rowoff + n);
-            *(f32x4*)(out + rowoff + n) = r + v;
+            f32x4 r;
+            if (xf) {
+                r = *(const f32x4*)(xf + rowoff + n);
+            } else {   // residual from the staged slab (operand precision)
+                const typename Half<T>::v4 rh = *(const typename Half<T>::v4*)(slab + (t + PAD) * (CG * 2) + n * 2);
+                r = (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+            }
+            r += v;
+            if (out) *(f32x4*)(out + rowoff + n) = r;
+            if (out_h) {
+                typename Half<T>::v4 h;
+                h[0] = Half<T>::from(r[0]); h[1] = Half<T>::from(r[1]);
+                h[2] = Half<T>::from(r[2]); h[3] = Half<T>::from(r[3]);
+                *(typename Half<T>::v4*)(out_h + rowoff + n) = h;
+            }
         }
     }
 }
@@ -173,8 +187,8 @@ int posconv_pack(const float* g, const float* v, int E, int groups, int K, void*
 }
 
 int posconv(const void* x_half, const float* x_f32, const void* w_packed, const float* bias, int B, int T,
-            int E, int groups, int K, float* out, int dtype, hipStream_t s) {
-    AVX_REQUIRE(x_half && x_f32 && w_packed && bias && out, "posconv: null argument");
+            int E, int groups, int K, float* out, void* out_half, int dtype, hipStream_t s) {
+    AVX_REQUIRE(x_half && w_packed && bias && (out || out_half), "posconv: null argument");
     AVX_REQUIRE(groups > 0 && E % groups == 0 && E / groups == CG && K == KT,
                 "posconv: only %d channels/group and %d taps are built (got E=%d groups=%d K=%d)", CG, KT, E, groups, K);
     AVX_REQUIRE(B > 0 && T > 0 && T <= TMAX, "posconv: T=%d tokens unsupported (1..%d)", T, TMAX);
@@ -182,12 +196,12 @@ int posconv(const void* x_half, const float* x_f32, const void* w_packed, const 
         static bool set = false;
         if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES)); set = true; }
         hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * groups), dim3(512), SLAB_BYTES, s, (const __bf16*)x_half, x_f32,
-                           (const __bf16*)w_packed, bias, T, E, groups, out);
+                           (const __bf16*)w_packed, bias, T, E, groups, out, (__bf16*)out_half);
     } else if (dtype == AVEXHIP_F16) {
         static bool set = false;
         if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES)); set = true; }
         hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * groups), dim3(512), SLAB_BYTES, s, (const _Float16*)x_half, x_f32,
-                           (const _Float16*)w_packed, bias, T, E, groups, out);
+                           (const _Float16*)w_packed, bias, T, E, groups, out, (_Float16*)out_half);
     } else {
         avexhip_set_error("posconv: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;

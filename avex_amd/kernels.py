@@ -139,7 +139,8 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
-         resid: Optional[torch.Tensor] = None, alpha: float = 1.0, gelu: bool = False,
+         resid: Optional[torch.Tensor] = None, resid_half: Optional[torch.Tensor] = None, alpha: float = 1.0,
+         gelu: bool = False,
          out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0
          ) -> Dict[str, torch.Tensor]:
     """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm)."""
@@ -158,6 +159,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     if resid is not None:
         resid = resid.contiguous()
         args.resid, args.ldr = _ptr(resid), N
+    elif resid_half is not None:
+        resid_half = resid_half.contiguous()
+        args.resid_half, args.ldrh = _ptr(resid_half), N
     args.alpha, args.gelu, args.variant = alpha, int(gelu), variant
     if out_f32:
         res["f32"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
@@ -174,13 +178,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
 
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, half_dtype="f16"
               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """LayerNorm of an fp32 or half ``[M, C]`` tensor -> (fp32 copy, half copy)."""
     _need_cuda(x, weight, bias)
-    code = dtype_code(half_dtype)
     x = x.contiguous()
     M, Cc = x.shape
-    o32 = torch.empty_like(x)
+    if x.dtype == torch.float32:
+        code = dtype_code(half_dtype)
+        pin, pinh = _ptr(x), None
+    else:
+        code = _capi.F16 if x.dtype == torch.float16 else _capi.BF16
+        pin, pinh = None, _ptr(x)
+    o32 = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
     oh = torch.empty((M, Cc), dtype=half_torch_dtype(code), device=x.device)
-    check(lib().avexhip_layernorm(_ptr(x), Cc, _ptr(weight), _ptr(bias), eps, M, Cc, _ptr(o32), Cc, _ptr(oh), Cc,
+    check(lib().avexhip_layernorm(pin, pinh, Cc, _ptr(weight), _ptr(bias), eps, M, Cc, _ptr(o32), Cc, _ptr(oh), Cc,
                                   code, _stream()), "layernorm")
     return o32, oh
 
@@ -207,14 +217,17 @@ def posconv_pack(g: torch.Tensor, v: torch.Tensor, groups: int, half_dtype="f16"
     return out
 
 
-def posconv(x_half: torch.Tensor, x_f32: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, groups: int,
-            K: int = 128) -> torch.Tensor:
-    _need_cuda(x_half, x_f32, w_packed, bias)
+def posconv(x_half: torch.Tensor, x_f32: Optional[torch.Tensor], w_packed: torch.Tensor, bias: torch.Tensor,
+            groups: int, K: int = 128, half_out: bool = False) -> torch.Tensor:
+    """``x + gelu(conv(x_half) + bias)``; the residual is ``x_f32`` when given, else ``x_half``."""
+    _need_cuda(x_half, w_packed, bias)
     code = _capi.F16 if x_half.dtype == torch.float16 else _capi.BF16
-    B, T, E = x_f32.shape
-    out = torch.empty_like(x_f32)
-    check(lib().avexhip_posconv(_ptr(x_half.contiguous()), _ptr(x_f32.contiguous()), _ptr(w_packed), _ptr(bias), B, T, E,
-                                groups, K, _ptr(out), code, _stream()), "posconv")
+    B, T, E = x_half.shape
+    x_half = x_half.contiguous()
+    out = torch.empty((B, T, E), dtype=x_half.dtype if half_out else torch.float32, device=x_half.device)
+    check(lib().avexhip_posconv(_ptr(x_half), None if x_f32 is None else _ptr(x_f32.contiguous()), _ptr(w_packed),
+                                _ptr(bias), B, T, E, groups, K, None if half_out else _ptr(out),
+                                _ptr(out) if half_out else None, code, _stream()), "posconv")
     return out
 
 
@@ -238,7 +251,11 @@ _CFG_FIELDS = ("input_patch_size", "embed_dim", "encoder_layers", "encoder_embed
                "encoder_attention_heads", "conv_pos", "conv_pos_groups", "num_buckets", "max_distance")
 
 
-def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0) -> BeatsConfig:
+RESIDUAL_CODES = {"f32": 0, "fp32": 0, "float32": 0, "half": 1, "f16": 1, "bf16": 1, "operand": 1}
+
+
+def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0,
+                      residual="f32") -> BeatsConfig:
     if bool(cfg.get("layer_norm_first", False)):
         raise AvexHipError("layer_norm_first=True (pre-LN) BEATs variants are not built; only the post-LN/DeepNorm branch")
     if str(cfg.get("activation_fn", "gelu")) != "gelu":
@@ -260,6 +277,10 @@ def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_
     c.fbank_std = float(cfg.get("fbank_std", 6.55582))
     c.operand_dtype = dtype_code(operand_dtype)
     c.max_chunk_clips = int(max_chunk_clips)
+    try:
+        c.residual_dtype = RESIDUAL_CODES[str(residual).lower()]
+    except KeyError as e:
+        raise ValueError(f"residual must be 'f32' or 'half', got {residual!r}") from e
     return c
 
 
@@ -268,10 +289,10 @@ class BeatsEncoder:
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype="f16",
-                 max_chunk_clips: int = 0) -> None:
+                 max_chunk_clips: int = 0, residual="f32") -> None:
         _capi.require_gpu()
         self.cfg = dict(cfg)
-        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips)
+        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual)
         self.E = int(cfg["encoder_embed_dim"])
         self.L = int(cfg["encoder_layers"])
         keep = []  # keep arrays alive during the call

@@ -55,7 +55,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--dtype", default=os.environ.get("AVEX_AMD_OPERAND", "f16"))
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("AVEX_AMD_CHUNK", "64")))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("AVEX_AMD_CHUNK", "256")))
+    ap.add_argument("--residual", default=os.environ.get("AVEX_AMD_RESIDUAL", "half"), choices=["f32", "half"],
+                    help="inter-kernel residual stream: fp32, or the operand type (default; pooled parity unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -84,7 +86,7 @@ def main():
     build.build(verbose=False)
     cfg = synth.BEATS_BASE_CFG
     sd = synth.beats_state_dict(cfg, seed=0)
-    enc = K.BeatsEncoder(cfg, sd, operand_dtype=args.dtype, max_chunk_clips=args.chunk)
+    enc = K.BeatsEncoder(cfg, sd, operand_dtype=args.dtype, max_chunk_clips=args.chunk, residual=args.residual)
 
     B = args.batch
     # synthetic clips keyed by global clip index (rank r owns clips [r*B, (r+1)*B))
@@ -148,7 +150,7 @@ def main():
             "config": {"workload": f"BEATs-base (12L/768/3072/12H, 90.7 M params, synthetic weights), batch {B} x 10 s @ 16 kHz per GPU, "
                                    f"wav resident in HBM -> mean-pooled 768-d embedding" + (", RCCL all-gather of pooled embeddings" if world > 1 else ""),
                        "global_batch": world * B, "samples_per_clip": SAMPLES, "tokens_per_clip": 496,
-                       "parallelism": f"dp{world}", "chunk_clips": args.chunk,
+                       "parallelism": f"dp{world}", "chunk_clips": args.chunk, "residual_stream": args.residual,
                        "model_tflops_per_s": round(value * FLOP_PER_CLIP / 1e12, 1),
                        "model_frac_of_mfma_peak": round(value * FLOP_PER_CLIP / 1e12 / (PEAK_TFLOPS * world), 4)},
             "roofline": roof, "stages_ms": stages,

@@ -82,7 +82,7 @@ int avexhip_cast_half_to_f32(const void* in_dev, float* out_dev, int64_t n, int 
 /* out[m, n] = epilogue( sum_k A[m,k] * W[n,k] )      (torch.nn.Linear layout: W is [N, K])
  *   acc' = acc + bias[n]                               (bias may be NULL)
  *   if out_raw:  out_raw[m,n] = acc'                   (fp32 "hook tap", e.g. fc2 raw output)
- *   if resid:    acc' = resid[m,n] * alpha + acc'      (DeepNorm residual, backbone.py:360,372)
+ *   if resid / resid_half:  acc' = resid[m,n] * alpha + acc'   (DeepNorm residual, backbone.py:360,372)
  *   if gelu:     acc' = gelu_erf(acc')                 (backbone.py:368)
  *   out_f32 / out_half (either may be NULL) receive acc'.
  * Requirements: N % 128 == 0, K % 64 == 0, all leading dims in elements, 16-byte aligned rows. */
@@ -91,20 +91,23 @@ typedef struct {
     const void*  W;  int64_t ldw;      /* [N, K] half */
     int32_t M, N, K;
     const float* bias;
-    const float* resid; int64_t ldr; float alpha;
+    const float* resid; int64_t ldr; float alpha;   /* fp32 residual, or ... */
+    const void*  resid_half; int64_t ldrh;          /* ... residual in the operand type (resid == NULL) */
     int32_t gelu;
     float* out_f32;  int64_t ldo;
     void*  out_half; int64_t ldh;
     float* out_raw;  int64_t ldraw;
-    int32_t variant;                   /* 0 = default (LDS-DMA staging), 1 = register staging */
+    int32_t variant;                   /* 0 = auto; 1 = 128-tile, register staging; 2 = 256-tile half-tile
+                                          LDS-DMA pipeline (needs N % 256 == 0); 3 = 128-tile LDS-DMA */
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
 
 /* torch.nn.LayerNorm over the last dim C (C % 4 == 0, C <= 1024), eps inside sqrt; writes fp32
- * and/or half copies.  Replaces beats.py:353, backbone.py:176-177,362,373. */
-int avexhip_layernorm(const float* in_dev, int64_t ld_in, const float* weight, const float* bias,
-                      float eps, int M, int C, float* out_f32, int64_t ldo, void* out_half,
-                      int64_t ldh, int dtype, void* stream);
+ * and/or half copies; the input is fp32 (in_dev) or the operand type (in_half_dev), exactly one
+ * non-NULL.  Replaces beats.py:353, backbone.py:176-177,362,373. */
+int avexhip_layernorm(const float* in_dev, const void* in_half_dev, int64_t ld_in, const float* weight,
+                      const float* bias, float eps, int M, int C, float* out_f32, int64_t ldo,
+                      void* out_half, int64_t ldh, int dtype, void* stream);
 
 /* Gated relative-position-bias attention (backbone.py:494-574) for head_dim 64, T <= 512.
  *   qkv: [B*T, 3*E] half rows (q | k | v, head h at columns h*64..h*64+63 of each third)
@@ -118,14 +121,15 @@ int avexhip_attention(const void* qkv_dev, int B, int T, int H, const float* bia
 
 /* Convolutional positional embedding (backbone.py:52-68,172-174): grouped Conv1d(E,E,k=128,
  * pad=64,groups=16) + drop-last + GELU, fused with the residual add:
- *   out[b,t,:] = x_f32[b,t,:] + gelu(conv(x_half)[b,t,:] + bias)
+ *   out[b,t,:] = x[b,t,:] + gelu(conv(x_half)[b,t,:] + bias)     (x = x_f32 if given, else x_half;
+ *   out_f32 and/or out_half receive the result)
  * w_packed: [G][E/G out][128 taps][E/G in] half, weight-norm already folded (see
  * avexhip_posconv_pack).  Only E/G == 48, K == 128 is built. */
 int avexhip_posconv_pack(const float* g_dev, const float* v_dev, int E, int groups, int K,
                          void* w_packed_dev, int dtype, void* stream);
 int avexhip_posconv(const void* x_half_dev, const float* x_f32_dev, const void* w_packed_dev,
                     const float* bias_dev, int B, int T, int E, int groups, int K,
-                    float* out_dev, int dtype, void* stream);
+                    float* out_f32_dev, void* out_half_dev, int dtype, void* stream);
 
 /* mean over T: in [B, T, C] fp32 -> out [B, C] fp32 (features.mean(dim=1), README:80). */
 int avexhip_mean_pool(const float* in_dev, int B, int T, int C, float* out_dev, void* stream);
@@ -160,7 +164,11 @@ typedef struct {
     float   fbank_mean;              /* 15.41663 */
     float   fbank_std;               /* 6.55582 */
     int32_t operand_dtype;           /* AVEXHIP_F16 (default; parity 3e-4) or AVEXHIP_BF16 (2e-3) */
-    int32_t max_chunk_clips;         /* clips processed per internal pass (0 = default 64) */
+    int32_t max_chunk_clips;         /* clips processed per internal pass (0 = default 256) */
+    int32_t residual_dtype;          /* 0: residual stream + pre-LN sums kept fp32 between kernels (frame-level
+                                        error 4e-4); 1: kept in the operand type (1.5e-3 frame level, pooled
+                                        unchanged at 2.8e-4, ~25 % less HBM traffic).  Hook taps and the
+                                        features output are fp32 either way. */
 } avexhip_beats_config;
 
 /* Weight table entry: reference state-dict key ("backbone." prefix optional), fp32 data

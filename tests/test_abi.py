@@ -31,13 +31,31 @@ def test_host_only_entry_points(built_lib):
     assert isinstance(_capi.last_error(), str)
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof/offsetof of every ABI struct as gcc sees include/avexhip.h == the ctypes mirror."""
     import ctypes as C
-    assert C.sizeof(_capi.FbankConfig) == 9 * 4
-    assert C.sizeof(_capi.BeatsConfig) == 20 * 4
-    assert C.sizeof(_capi.Tensor) == 24
-    # avexhip_gemm_args: pointers/int64 8-byte aligned
-    assert C.sizeof(_capi.GemmArgs) == 136
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    structs = {"avexhip_fbank_config": _capi.FbankConfig, "avexhip_gemm_args": _capi.GemmArgs,
+               "avexhip_beats_config": _capi.BeatsConfig, "avexhip_tensor": _capi.Tensor}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/avexhip.h"', "int main(void){"]
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 def test_no_cpu_fallback_without_gpu(built_lib):

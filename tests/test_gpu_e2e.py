@@ -22,11 +22,13 @@ def base_sd():
     return synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0)
 
 
-@pytest.fixture(scope="module", params=["f16", "bf16"])
+@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres"])
 def encoder(request, built_lib, base_sd):
     from avex_amd import kernels as K
-    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype=request.param, max_chunk_clips=3)
-    enc.dtype_name = request.param
+    dt = request.param.split("-")[0]
+    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype=dt, max_chunk_clips=3,
+                         residual="half" if request.param.endswith("halfres") else "f32")
+    enc.dtype_name = dt
     yield enc
     enc.close()
 

@@ -40,8 +40,8 @@ def test_cast_roundtrip(built_lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("shape", [(300, 256, 192), (1984, 768, 768), (128, 128, 64), (77, 3072, 768)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(300, 256, 192), (1984, 768, 768), (128, 128, 64), (77, 3072, 768), (2500, 512, 256), (1024, 768, 3072)])
 def test_gemm_epilogues(built_lib, dtype, variant, shape):
     from avex_amd import kernels as K
     M, N, Kd = shape
@@ -60,9 +60,12 @@ def test_gemm_epilogues(built_lib, dtype, variant, shape):
     assert rel_l2(r["raw"].cpu().numpy(), ref) < 2e-6
     assert rel_l2(r["f32"].cpu().numpy(), resid * alpha + ref) < 2e-6
     assert np.array_equal(r["half"].float().cpu().numpy(), round_half(r["f32"].cpu().numpy(), dtype))
+    rh = round_half(resid, dtype)
+    r = K.gemm(ad, wd, bias=_dev(bias), resid_half=_dev(rh, _tdt(dtype)), alpha=alpha, variant=variant)
+    assert rel_l2(r["f32"].cpu().numpy(), rh * alpha + ref) < 2e-6
     # exact-erf GELU
     r = K.gemm(ad, wd, bias=_dev(bias), gelu=True, variant=variant)
-    assert rel_l2(r["f32"].cpu().numpy(), O.gelu_erf(ref.astype(np.float32))) < 5e-6
+    assert rel_l2(r["f32"].cpu().numpy(), O.gelu_erf(ref.astype(np.float32))) < 5e-6   # A&S 7.1.26 erf: |err| < 6e-7
 
 
 def test_gemm_rejects_bad_shapes(built_lib):
@@ -86,6 +89,10 @@ def test_layernorm(built_lib, C):
     ref = O.layer_norm(x, w.astype(np.float32), b.astype(np.float32))
     assert max_abs(o32.cpu().numpy(), ref) < 5e-6
     assert np.array_equal(oh.float().cpu().numpy(), round_half(o32.cpu().numpy(), "f16"))
+    # half input (residual stream kept in the operand type)
+    xh = round_half(x, "f16")
+    o32h, _ = K.layernorm(_dev(xh, torch.float16), _dev(w), _dev(b))
+    assert max_abs(o32h.cpu().numpy(), O.layer_norm(xh, w.astype(np.float32), b.astype(np.float32))) < 5e-6
 
 
 def test_mean_pool(built_lib):
@@ -175,9 +182,14 @@ def test_posconv(built_lib, dtype, T):
     xh = round_half(x, dtype)
     out = K.posconv(_dev(xh, _tdt(dtype)), _dev(x), wp, _dev(bias), G, Kt).cpu().numpy()
     wq = wp.float().cpu().numpy().reshape(G, E // G, Kt, E // G).transpose(0, 1, 3, 2).reshape(E, E // G, Kt)
-    ref = x + O.pos_conv(xh, wq, bias.astype(np.float32), G)
-    assert rel_l2(out - x, ref - x) < 2e-5       # same rounded operands: fp32 accumulation order only
+    conv = O.pos_conv(xh, wq, bias.astype(np.float32), G)
+    assert rel_l2(out - x, conv) < 2e-5       # same rounded operands: fp32 accumulation order only
     assert out.shape == (B, T, E)
+    # operand-type residual and output (the "half" residual stream mode)
+    outh = K.posconv(_dev(xh, _tdt(dtype)), None, wp, _dev(bias), G, Kt, half_out=True)
+    assert outh.dtype == _tdt(dtype)
+    assert np.array_equal(outh.float().cpu().numpy(), round_half((xh + conv).astype(np.float32), dtype)) or \
+        rel_l2(outh.float().cpu().numpy(), xh + conv) < (6e-4 if dtype == "f16" else 4e-3)
 
 
 def _fbank_close(a, b, what):
