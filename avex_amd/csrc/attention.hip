@@ -6,7 +6,7 @@
 // (backbone.py:543-551).  The reference materialises a [B,H,T,T] fp32 mask (3 GB at B=256); here the
 // bias is a per-head Toeplitz row of 2T-1 floats in LDS and nothing of size T^2 ever exists.
 //
-// One 512-thread workgroup per (clip, head).  The head's whole K (T x 64, row-major, XOR-swizzled
+// One 1024-thread workgroup (16 waves, one 32-query tile each at T = 496) per (clip, head).  The head's whole K (T x 64, row-major, XOR-swizzled
 // 16-byte chunks) and V^T (64 x T, rows padded to 1032 B) live in LDS (129 KiB of the CU's 160), so
 // K/V are read from HBM exactly once.  Each wave owns 32 queries at a time and keeps the QUERY on the
 // MFMA lane for both products (v_mfma_f32_32x32x16):
@@ -25,13 +25,14 @@ constexpr int TMAX = 512;
 constexpr int VT_LD = 516;                       // halves per V^T row (1032 B: conflict-free b64 reads)
 constexpr int KS_BYTES = TMAX * 128;             // 65536
 constexpr int VT_BYTES = 64 * VT_LD * 2;         // 66048
-constexpr int TAB_BYTES = 1024 * 4;              // 4096
+constexpr int TAB_LD = 1040;                     // floats per shifted copy of the bias row
+constexpr int TAB_BYTES = 4 * TAB_LD * 4;        // 4 copies, copy s holds tab[k + s]: every lane reads 16-byte aligned
 constexpr int KADD_BYTES = TMAX * 4;             // 2048
 constexpr int GW_BYTES = 136 * 4;                // wa[64] wb[64] ba bb (+pad)
 constexpr int ATT_LDS = KS_BYTES + VT_BYTES + TAB_BYTES + KADD_BYTES + GW_BYTES;
 
 template <typename T>
-__global__ __launch_bounds__(512) void attention_kernel(const T* __restrict__ qkv, int Tn, int H,
+__global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ qkv, int Tn, int H,
                                                         const float* __restrict__ bias_tab,
                                                         const float* __restrict__ grep_w,
                                                         const float* __restrict__ grep_b,
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const T* __restrict__ qk
 
     // ---- stage K (swizzled rows), V^T, bias row, key mask, gate weights -----------------------
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int idx = tid + 512 * it;
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 1024 * it;
         const int row = idx >> 3, c = idx & 7;
         uint4 kv = make_uint4(0, 0, 0, 0);
         v8 vv;
@@ -71,12 +72,16 @@ __global__ __launch_bounds__(512) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
         for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VT_LD + row] = vv[e];
     }
-    for (int r = tid; r < 1024; r += 512) {
+    for (int r = tid; r < TAB_LD; r += 1024) {
+        // bias row pre-multiplied by log2(e): the softmax runs in base 2 (v_exp_f32 is 2^x).
+        // copy s stores tab[k + s] at k, so a lane whose first index is tb reads copy (tb & 3) at tb - (tb & 3).
         float v = 0.f;
-        if (bias_tab && r < 2 * Tn - 1) v = bias_tab[(int64_t)h * (2 * Tn - 1) + r];
-        tab[r] = v;
+        if (bias_tab && r < 2 * Tn - 1) v = bias_tab[(int64_t)h * (2 * Tn - 1) + r] * 1.4426950408889634f;
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft)
+            if (r - sft >= 0) tab[sft * TAB_LD + (r - sft)] = v;
     }
-    {
+    if (tid < TMAX) {
         const int j = tid;
         bool ok = j < Tn;
         if (ok && key_pad) ok = key_pad[(int64_t)b * Tn + j] == 0;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const T* __restrict__ qk
     const int hh = lane >> 5, r32 = lane & 31;
     const float head_a = grep_w ? grep_a[h] : 0.f;
 
-    for (int qt = wave; qt < nqt; qt += 8) {
+    for (int qt = wave; qt < nqt; qt += 16) {
         const int i = qt * 32 + r32;
         const int iq = i < Tn ? i : Tn - 1;
         v8 qf[4];
@@ -133,37 +138,60 @@ __global__ __launch_bounds__(512) void attention_kernel(const T* __restrict__ qk
 
         for (int kt = 0; kt < nqt; ++kt) {
             f32x16 S;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) S[r] = 0.f;
             const int krow = kt * 32 + r32;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int chunk = hh + 2 * s;
                 const v8 kf = *(const v8*)(Ks + krow * 128 + ((chunk ^ ((krow >> 1) & 7)) << 4));
-                S = mfma32(kf, qf[s], S);
+                if (s == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    S = mfma32(kf, qf[0], z);
+                } else {
+                    S = mfma32(kf, qf[s], S);
+                }
             }
             const int jb = kt * 32 + 4 * hh;
             const int tb = jb - iq + (Tn - 1);
+            const float* tp = tab + (tb & 3) * TAB_LD + (tb & ~3);
+            float tv[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 t4 = *(const f32x4*)(tp + 8 * g4);
+                tv[4 * g4 + 0] = t4[0]; tv[4 * g4 + 1] = t4[1]; tv[4 * g4 + 2] = t4[2]; tv[4 * g4 + 3] = t4[3];
+            }
             float sc[16];
             float mx = NEG_INF;
+            // scores in log2 units: s * (log2e / 8) + gate * (bias * log2e)
+            const bool masked_tile = key_pad != nullptr || (kt * 32 + 32 > Tn);   // wave-uniform
+            if (masked_tile) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jo = (r & 3) + 8 * (r >> 2);
-                sc[r] = S[r] * 0.125f + gate * tab[tb + jo] + kadd[jb + jo];
-                mx = fmaxf(mx, sc[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int jo = (r & 3) + 8 * (r >> 2);
+                    sc[r] = __builtin_fmaf(S[r], 0.125f * 1.4426950408889634f, gate * tv[r]) + kadd[jb + jo];
+                    mx = fmaxf(mx, sc[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jo = (r & 3) + 8 * (r >> 2);
+                    sc[r] = __builtin_fmaf(S[r], 0.125f * 1.4426950408889634f, gate * tv[r]);
+                    mx = fmaxf(mx, sc[r]);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float m_use = m_new == NEG_INF ? 0.f : m_new;
-            const float alpha = __expf(m_run - m_use);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
             float ls = 0.f;
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = __expf(sc[r] - m_use);
+                p[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
                 ls += p[r];
             }
-            l_run = l_run * alpha + ls;
+            l_run = __builtin_fmaf(l_run, alpha, ls);
             m_run = m_new;
             if (__any(alpha != 1.f)) {
 #pragma unroll
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[s2][j] = Half<T>::from(p[8 * s2 + j]);
+                for (int j = 0; j < 8; ++j) pf[s2][j] = (T)p[8 * s2 + j];   // p in [0, 1]: no saturation needed
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int key0 = kt * 32 + 16 * s2 + 4 * hh;
@@ -222,7 +250,7 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(512), ATT_LDS, s, (const T*)qkv, Tn, H, bias_tab, grep_w,
+    hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(1024), ATT_LDS, s, (const T*)qkv, Tn, H, bias_tab, grep_w,
                        grep_b, grep_a, key_pad, (T*)out);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
