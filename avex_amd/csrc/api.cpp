@@ -3,6 +3,7 @@
 // stream.  Compiled with hipcc (host code only in this file).
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -158,6 +159,9 @@ struct avexhip_beats {
     int dtype = AVEXHIP_F16;
     int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 256;
     bool fast = false;   // residual stream / pre-LN sums in the operand type
+    int nstreams = 1;    // chunks of one forward run concurrently on this many streams (caller's + side streams)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float alpha = 1.f;
     avexhip_fbank_plan* fb = nullptr;
     void* w_patch = nullptr;
@@ -181,6 +185,8 @@ struct avexhip_beats {
         for (auto& kv : bias_tabs) (void)hipFree(kv.second);
         if (fb) avexhip_fbank_plan_destroy(fb);
         for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        for (int i = 0; i < 3; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
     }
 };
 
@@ -412,6 +418,19 @@ Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
     return w;
 }
 
+// how a batch is split: chunk size and number of concurrent lanes (streams)
+void plan_chunks(const avexhip_beats* h, int B, int* chunk, int* lanes) {
+    int c = B < h->chunk ? B : h->chunk;
+    int l = 1;
+    if (h->nstreams > 1 && B > 1) {
+        const int per = (B + h->nstreams - 1) / h->nstreams;
+        if (per < c) c = per;
+        l = (B + c - 1) / c;
+        if (l > h->nstreams) l = h->nstreams;
+    }
+    *chunk = c; *lanes = l;
+}
+
 struct Prof {
     avexhip_beats* h;
     hipStream_t s;
@@ -447,12 +466,14 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     AVX_REQUIRE((hook_mask >> (L + 1)) == 0, "beats_forward: hook_mask has bits beyond layer %d", L);
     for (int i = 0; i <= L; ++i)
         AVX_REQUIRE(!((hook_mask >> i) & 1u) || hook_out[i], "beats_forward: hook %d selected but hook_out[%d] is NULL", i, i);
-    const int chunk = B < h->chunk ? B : h->chunk;
+    int chunk = 1, lanes = 1;
+    plan_chunks(h, B, &chunk, &lanes);
     const Ws need = carve(h, nullptr, chunk, Tt);
-    if (!workspace || ws_bytes < need.total) {
-        avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total);
+    if (!workspace || ws_bytes < need.total * (size_t)lanes) {
+        avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total * (size_t)lanes);
         return AVEXHIP_ERR_WORKSPACE;
     }
+    if (h->profiling) lanes = 1;   // per-kernel event timing needs the kernels alone on the device
     float* bias_tab = nullptr;
     int rc = bias_tab_for(h, Tt, &bias_tab);
     if (rc != AVEXHIP_OK) return rc;
@@ -460,13 +481,17 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     Prof prof{h, s};
 #define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
 
-    for (int c0 = 0; c0 < B; c0 += chunk) {
+    // Chunks are processed in rounds of `lanes`.  The frontend of every chunk of a round runs on the
+    // caller's stream BEFORE the fork: the FFT kernel must not share the device with the MFMA kernels of
+    // another lane (observed on MI355X/ROCm 7.2: sporadic wrong FFT values when it does; the other kernels
+    // are unaffected), and it is < 2 % of a step anyway.
+    for (int r0 = 0; r0 < B; r0 += chunk * lanes) {
+    for (int li = 0; li < lanes; ++li) {
+        const int c0 = r0 + li * chunk;
+        if (c0 >= B) break;
         const int Bc = (B - c0) < chunk ? (B - c0) : chunk;
-        const int M = Bc * Tt;
-        const Ws w = carve(h, (char*)workspace, chunk, Tt);
-        const uint8_t* pad = frame_pad ? frame_pad + (size_t)c0 * Tt : nullptr;
-        const double Md = (double)M;
-
+        const Ws w = carve(h, (char*)workspace + (size_t)li * need.total, chunk, Tt);
+        const double Md = (double)Bc * Tt;
         // 1. frontend -> patch-major half tokens [M, P*P]
         if (wav) {
             prof.begin("fbank", Md / Tt * frames * (5.0 * 512 * 9 + 2.0 * 504));
@@ -477,6 +502,25 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             RC(avx::patchify(fbank_in + (size_t)c0 * frames * NM, Bc, frames, NM, P, w.patches, dt, s));
             prof.end();
         }
+    }
+    if (lanes > 1) {
+        // fresh events every round: a re-recorded event must never be observed by a wait enqueued earlier
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        AVX_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        AVX_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+        for (int i = 0; i + 1 < lanes; ++i) AVX_HIP_CHECK(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
+    }
+    for (int li = 0; li < lanes; ++li) {
+        const int c0 = r0 + li * chunk;
+        if (c0 >= B) break;
+        const int Bc = (B - c0) < chunk ? (B - c0) : chunk;
+        const int M = Bc * Tt;
+        const int lane_id = li;
+        hipStream_t cs = lane_id == 0 ? s : h->side[lane_id - 1];
+        const Ws w = carve(h, (char*)workspace + (size_t)lane_id * need.total, chunk, Tt);
+        const uint8_t* pad = frame_pad ? frame_pad + (size_t)c0 * Tt : nullptr;
+        const double Md = (double)M;
+
         // 2. patch embedding (Conv2d as GEMM) -> LayerNorm(D) -> post_extract_proj
         // "fast" keeps the residual stream (post-LN x) and the pre-LN sums in the operand type between
         // kernels; otherwise they are fp32.  x32 / pre32 / preh below are NULL when unused.
@@ -490,13 +534,13 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         g.A = w.patches; g.lda = P * P; g.W = h->w_patch; g.ldw = P * P; g.M = M; g.N = D; g.K = P * P;
         if (fast) { g.out_half = w.h0; g.ldh = D; } else { g.out_f32 = w.f0; g.ldo = D; }
         prof.begin("gemm.patch_embed", 2.0 * Md * D * P * P);
-        RC(avx::gemm(g, dt, s));
+        RC(avx::gemm(g, dt, cs));
         prof.end();
         prof.begin("layernorm", 0.0);
         if (h->w_post) {
-            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, nullptr, D, w.h0, D, dt, s));
+            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, nullptr, D, w.h0, D, dt, cs));
         } else {   // embed_dim == encoder_embed_dim: the LayerNorm output is x itself
-            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, fast ? nullptr : x32, E, w.xh, E, dt, s));
+            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, fast ? nullptr : x32, E, w.xh, E, dt, cs));
         }
         prof.end();
         if (h->w_post) {
@@ -505,21 +549,21 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             g.out_half = w.xh; g.ldh = E; g.row_zero = pad;
             if (!fast || hook0) { g.out_f32 = x32; g.ldo = E; }
             prof.begin("gemm.post_extract_proj", 2.0 * Md * E * D);
-            RC(avx::gemm(g, dt, s));
+            RC(avx::gemm(g, dt, cs));
             prof.end();
         }
         if (hook0 && h->w_post) {
             // the reference's hook holds the tensor that the encoder then zeroes in place at padded tokens
             // (beats.py:359-361 + backbone.py:169-170), so the tap equals x after masking
-            if (hook_pooled) RC(avx::mean_pool(x32, Bc, Tt, E, nullptr, hook_out[0] + (size_t)c0 * E, s));
-            else AVX_HIP_CHECK(hipMemcpyAsync(hook_out[0] + (size_t)c0 * Tt * E, x32, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, s));
+            if (hook_pooled) RC(avx::mean_pool(x32, Bc, Tt, E, nullptr, hook_out[0] + (size_t)c0 * E, cs));
+            else AVX_HIP_CHECK(hipMemcpyAsync(hook_out[0] + (size_t)c0 * Tt * E, x32, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, cs));
         }
         // 3. convolutional positional embedding + residual, encoder LayerNorm
         prof.begin("posconv", 2.0 * Md * E * (E / h->cfg.conv_pos_groups) * h->cfg.conv_pos);
-        RC(avx::posconv(w.xh, fast ? nullptr : x32, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, pre32, preh, dt, s));
+        RC(avx::posconv(w.xh, fast ? nullptr : x32, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, pre32, preh, dt, cs));
         prof.end();
         prof.begin("layernorm", 0.0);
-        RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, s));
+        RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
         prof.end();
 
         // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375)
@@ -529,26 +573,26 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
             g.out_half = w.qkv; g.ldh = 3 * E;
             prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
-            RC(avx::gemm(g, dt, s));
+            RC(avx::gemm(g, dt, cs));
             prof.end();
             prof.begin("attention", 4.0 * Md * Tt * E + 2.0 * Md * 8 * (E / H) * H);
-            RC(avx::attention(w.qkv, Bc, Tt, H, bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, pad, w.ah, dt, s));
+            RC(avx::attention(w.qkv, Bc, Tt, H, bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, pad, w.ah, dt, cs));
             prof.end();
             memset(&g, 0, sizeof(g));
             g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = h->alpha;
             if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
             else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
             prof.begin("gemm.out_proj", 2.0 * Md * E * E);
-            RC(avx::gemm(g, dt, s));
+            RC(avx::gemm(g, dt, cs));
             prof.end();
             prof.begin("layernorm", 0.0);
-            RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, s));
+            RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
             prof.end();
             memset(&g, 0, sizeof(g));
             g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
             g.out_half = w.hh; g.ldh = F;
             prof.begin("gemm.fc1", 2.0 * Md * F * E);
-            RC(avx::gemm(g, dt, s));
+            RC(avx::gemm(g, dt, cs));
             prof.end();
             const bool hooked = (hook_mask >> (i + 1)) & 1u;
             memset(&g, 0, sizeof(g));
@@ -560,20 +604,20 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
                 g.ldraw = E;
             }
             prof.begin("gemm.fc2", 2.0 * Md * E * F);
-            RC(avx::gemm(g, dt, s));
+            RC(avx::gemm(g, dt, cs));
             prof.end();
-            if (hooked && hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, hook_out[i + 1] + (size_t)c0 * E, s));
+            if (hooked && hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, hook_out[i + 1] + (size_t)c0 * E, cs));
             const bool last = i == L - 1;
             // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
             float* xo = nullptr;
             if (last) xo = features_out ? features_out + (size_t)c0 * Tt * E : ((pooled_out || !fast) ? x32 : nullptr);
             else if (!fast) xo = x32;
             prof.begin("layernorm", 0.0);
-            if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, s));
+            if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
             prof.end();
             if (last && pooled_out) {
                 prof.begin("mean_pool", 0.0);
-                RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, s));
+                RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, cs));
                 prof.end();
             }
         }
@@ -581,11 +625,20 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             // no layers: features = encoder LayerNorm output; recompute it in fp32 for the outputs
             if (features_out || pooled_out) {
                 float* xo = features_out ? features_out + (size_t)c0 * Tt * E : x32;
-                RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, xo, E, nullptr, E, dt, s));
-                if (pooled_out) RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, s));
+                RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, xo, E, nullptr, E, dt, cs));
+                if (pooled_out) RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, cs));
             }
         }
     }
+    if (lanes > 1) {
+        for (int i = 0; i + 1 < lanes; ++i) {
+            if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+            AVX_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+            AVX_HIP_CHECK(hipEventRecord(h->ev_join[i], h->side[i]));
+            AVX_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        }
+    }
+    }   // rounds
 #undef RC
     if (h->profiling) {
         AVX_HIP_CHECK(hipStreamSynchronize(s));
@@ -650,6 +703,26 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->L = c.encoder_layers; h->D = c.embed_dim; h->P = c.input_patch_size; h->NM = c.num_mel_bins;
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     h->fast = c.residual_dtype != 0;
+    {
+        // Independent chunks of a batch can overlap on several HIP streams: one chunk's HBM-bound kernels
+        // (LayerNorm, epilogue tails, attention staging) fill the gaps of another chunk's MFMA kernels.
+        const char* e = getenv("AVEX_AMD_STREAMS");
+        int ns = e ? atoi(e) : 1;
+        h->nstreams = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
+        for (int i = 0; i + 1 < h->nstreams; ++i) {
+            if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+                avexhip_set_error("beats_create: cannot create side streams");
+                delete h;
+                return nullptr;
+            }
+        }
+        if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) {
+            avexhip_set_error("beats_create: cannot create events");
+            delete h;
+            return nullptr;
+        }
+    }
     h->alpha = c.deep_norm ? powf(2.0f * (float)c.encoder_layers, 0.25f) : 1.0f;
     if (build(h, tensors, n_tensors) != AVEXHIP_OK) {
         delete h;
@@ -670,8 +743,9 @@ extern "C" size_t avexhip_beats_workspace_bytes(const avexhip_beats* h, int B, i
     if (!h || B <= 0) return 0;
     const int Tt = avexhip_beats_num_tokens(h, T);
     if (Tt <= 0) return 0;
-    const int chunk = B < h->chunk ? B : h->chunk;
-    return carve(h, nullptr, chunk, Tt).total;
+    int chunk = 1, lanes = 1;
+    plan_chunks(h, B, &chunk, &lanes);
+    return carve(h, nullptr, chunk, Tt).total * (size_t)lanes;
 }
 
 extern "C" int avexhip_beats_forward(avexhip_beats* h, const float* wav, int B, int64_t T, int64_t wav_stride,

@@ -210,6 +210,41 @@ __global__ void patchify_kernel(const float* __restrict__ fb, int frames, int n_
     out[i] = Half<T>::from(fb[(b * frames + fr) * n_mels + mel]);
 }
 
+// Debug aid: fills a static LDS array with a pattern and re-checks it for a while; any foreign write
+// into this workgroup's LDS shows up in report[] = {mismatch count, first bad word index, value seen, block}.
+__global__ __launch_bounds__(256) void lds_canary_kernel(int iters, unsigned* __restrict__ report) {
+    __shared__ __attribute__((aligned(16))) unsigned words[6720];   // 26880 B, the fbank kernel's footprint
+    uint4* w4 = (uint4*)words;
+    uint2* w2 = (uint2*)words;
+    auto want = [&](int i) { return 0xC0DE0000u ^ (unsigned)i ^ (blockIdx.x << 16); };
+    for (int i = threadIdx.x; i < 1680; i += 256) w4[i] = make_uint4(want(4 * i), want(4 * i + 1), want(4 * i + 2), want(4 * i + 3));
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        // 128-bit reads + rewrites
+        for (int i = threadIdx.x; i < 1680; i += 256) {
+            const uint4 v = w4[i];
+            if (v.x != want(4 * i) || v.y != want(4 * i + 1) || v.z != want(4 * i + 2) || v.w != want(4 * i + 3)) {
+                if (atomicAdd(&report[0], 1u) == 0) { report[1] = (unsigned)(4 * i); report[2] = v.x; report[3] = blockIdx.x; }
+            }
+            w4[i] = make_uint4(want(4 * i), want(4 * i + 1), want(4 * i + 2), want(4 * i + 3));
+        }
+        __syncthreads();
+        // paired 64-bit reads at a 64-element stride (ds_read2st64_b64-style) + rewrites
+        for (int i = threadIdx.x; i < 1600; i += 256) {
+            const uint2 a = w2[i], b = w2[i + 64];
+            if (a.x != want(2 * i) || a.y != want(2 * i + 1) || b.x != want(2 * i + 128) || b.y != want(2 * i + 129)) {
+                if (atomicAdd(&report[0], 1u) == 0) { report[1] = (unsigned)(2 * i); report[2] = a.x; report[3] = blockIdx.x | 0x80000000u; }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1600; i += 256) {
+            w2[i] = make_uint2(want(2 * i), want(2 * i + 1));
+            w2[i + 64] = make_uint2(want(2 * i + 128), want(2 * i + 129));
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 namespace avx {
@@ -310,3 +345,8 @@ int patchify(const float* fbank, int B, int frames, int n_mels, int patch, void*
 }
 
 }  // namespace avx
+
+extern "C" int avexhip_debug_lds_canary(int blocks, int iters, unsigned* report_dev, void* stream) {
+    hipLaunchKernelGGL(lds_canary_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, report_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

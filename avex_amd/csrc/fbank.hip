@@ -54,11 +54,15 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
                                                     int P) {
     __shared__ float2 zbuf[4][8 * ZROW];
     __shared__ float pw[4][2][264];
+    __shared__ float2 tw[512];   // twiddle table staged once per block (pass 1 and 2 gather from it)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int f0 = (blockIdx.x * 4 + wave) * 2;
     const bool valid[2] = {f0 < frames, f0 + 1 < frames};
     float2* z = zbuf[wave];
+    tw[threadIdx.x] = fb.twiddle[threadIdx.x];
+    tw[threadIdx.x + 256] = fb.twiddle[threadIdx.x + 256];
+    __syncthreads();
 
     // ---- load, DC removal, pre-emphasis, window (beats.py:136-151) ----------------------------
     float2 x[8];
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     // ---- 512-point complex FFT: three radix-8 passes ------------------------------------------
     dft8(x);
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) x[k1] = cmul(x[k1], fb.twiddle[lane * k1]);
+    for (int k1 = 1; k1 < 8; ++k1) x[k1] = cmul(x[k1], tw[lane * k1]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) z[k1 * ZROW + lane] = x[k1];
     __syncthreads();
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
         for (int m1 = 0; m1 < 8; ++m1) x[m1] = z[k1 * ZROW + 8 * m1 + m2];
         dft8(x);
 #pragma unroll
-        for (int j1 = 1; j1 < 8; ++j1) x[j1] = cmul(x[j1], fb.twiddle[8 * m2 * j1]);
+        for (int j1 = 1; j1 < 8; ++j1) x[j1] = cmul(x[j1], tw[8 * m2 * j1]);
         __syncthreads();
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) z[k1 * ZROW + j1 * 8 + m2] = x[j1];

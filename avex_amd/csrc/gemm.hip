@@ -15,6 +15,8 @@
 // the 16-byte chunk c of row r lives in slot c ^ ((r>>1)&7) (applied on the DMA *source* address and
 // on the ds_read_b128 address, never on the DMA destination) which makes every fragment read
 // bank-conflict free for the 16x16x32 lane groups.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -400,6 +402,7 @@ template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
     // variant: 0 = auto, 1 = 128-tile register staging, 2 = 256-tile half-tile pipeline, 3 = 128-tile LDS-DMA
     int variant = a.variant;
+    if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
     if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 2 : 3;
     if (variant == 2 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
     if (variant == 2) {
@@ -414,7 +417,16 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         return AVEXHIP_OK;
     }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    const size_t lds = 2 * 2 * TILE_BYTES;
+    static const char* pad_env = getenv("AVEX_AMD_DEBUG_LDS_PAD");
+    const size_t lds = 2 * 2 * TILE_BYTES + (pad_env ? atoi(pad_env) : 0);
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set = true;
+        }
+    }
     if (variant == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(tiles), dim3(256), lds, s, a);
     } else {

@@ -134,6 +134,10 @@ int avexhip_posconv(const void* x_half_dev, const float* x_f32_dev, const void* 
 /* mean over T: in [B, T, C] fp32 -> out [B, C] fp32 (features.mean(dim=1), README:80). */
 int avexhip_mean_pool(const float* in_dev, int B, int T, int C, float* out_dev, void* stream);
 
+/* Debug aid: `blocks` workgroups hold a 26 880-byte LDS pattern for `iters` re-check rounds;
+ * report_dev[4] (zeroed by the caller) = {mismatches, first bad word, value seen, block}. */
+int avexhip_debug_lds_canary(int blocks, int iters, unsigned* report_dev, void* stream);
+
 /* T5 bidirectional bucket of a relative position (backbone.py:438-473).  Pure host function. */
 int avexhip_rel_bucket(int rel, int num_buckets, int max_distance);
 
