@@ -32,20 +32,29 @@ def cpu_baseline(sd, cfg, seconds_budget=20.0):
     import numpy as np
     from avex_amd import synth
     from oracle import beats_oracle as O
-    n = 2
+    threads = min(os.cpu_count() or 1, 32)     # OpenBLAS scales poorly past ~32 threads on these GEMM sizes
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=threads)
+    except Exception:  # noqa: BLE001
+        import contextlib
+        ctx = contextlib.nullcontext()
+        threads = os.cpu_count() or 1
+    n = 4
     x = synth.noise_clips(n, SAMPLES, seed=0)
-    O.beats_forward(x[:1], sd, cfg)                      # warm-up (BLAS threads, page-in)
-    t0 = time.time()
-    done = 0
-    while True:
-        f, _ = O.beats_forward(x, sd, cfg)
-        O.pooled(f)
-        done += n
-        el = time.time() - t0
-        if el > seconds_budget or done >= 64:
-            break
-    return {"value": round(done / el, 3), "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{done} clips x 10 s through oracle/beats_oracle.py (NumPy fp32, OpenBLAS threads={os.cpu_count()}), {el:.1f} s"}
+    with ctx:
+        O.beats_forward(x[:1], sd, cfg)                      # warm-up (BLAS threads, page-in)
+        t0 = time.time()
+        done = 0
+        while True:
+            f, _ = O.beats_forward(x, sd, cfg)
+            O.pooled(f)
+            done += n
+            el = time.time() - t0
+            if el > seconds_budget or done >= 64:
+                break
+    return {"value": round(done / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{done} clips x 10 s through oracle/beats_oracle.py (NumPy fp32, OpenBLAS limited to {threads} threads), {el:.1f} s"}
 
 
 def main():
@@ -134,8 +143,16 @@ def main():
         total_ms = sum(ms for _, ms, _ in prof)
         stages = {n: {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 and fl > 0 else None} for n, ms, fl in prof}
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+        traffic = None     # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and B == 256 and args.dtype == "f16":
+            try:
+                traffic = round(json.load(open(tpath))["gemm256_kernel"]["hbm_bytes_per_launch"])
+            except Exception:  # noqa: BLE001
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "gemm256_kernel", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_tflop_per_launch": round(gemm_fl / n_gemm_launch / 1e12, 4),
                 "launches_per_step": n_gemm_launch, "avg_launch_ms": round(gemm_ms / n_gemm_launch, 4),
                 "gemm_share_of_step": round(gemm_ms / total_ms, 3)}
 
