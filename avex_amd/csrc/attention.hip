@@ -17,6 +17,8 @@
 // reductions are 15 in-register ops + one cross-half shuffle, and P never touches LDS.  The k-order
 // inside a PV k-step is the accumulator's register order: element j of lane-half h is key
 // 16 s + 8 (j>>2) + 4 h + (j&3); the V^T fragment is gathered with exactly that map (two 8-byte reads).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
                                                         const float* __restrict__ grep_b,
                                                         const float* __restrict__ grep_a,
                                                         const uint8_t* __restrict__ key_pad,
-                                                        T* __restrict__ out) {
+                                                        T* __restrict__ out, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
 
-        for (int kt = 0; kt < nqt; ++kt) {
+        const int nkt_run = dbg == 1 ? 0 : (dbg == 2 ? 1 : nqt);
+        for (int kt = 0; kt < nkt_run; ++kt) {
             f32x16 S;
             const int krow = kt * 32 + r32;
 #pragma unroll
@@ -250,8 +253,9 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
         attr_set = true;
     }
+    static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
     hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(1024), ATT_LDS, s, (const T*)qkv, Tn, H, bias_tab, grep_w,
-                       grep_b, grep_a, key_pad, (T*)out);
+                       grep_b, grep_a, key_pad, (T*)out, dbg);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }

@@ -255,7 +255,7 @@ RESIDUAL_CODES = {"f32": 0, "fp32": 0, "float32": 0, "half": 1, "f16": 1, "bf16"
 
 
 def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0,
-                      residual="f32") -> BeatsConfig:
+                      residual="half") -> BeatsConfig:
     if bool(cfg.get("layer_norm_first", False)):
         raise AvexHipError("layer_norm_first=True (pre-LN) BEATs variants are not built; only the post-LN/DeepNorm branch")
     if str(cfg.get("activation_fn", "gelu")) != "gelu":
@@ -289,7 +289,7 @@ class BeatsEncoder:
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype="f16",
-                 max_chunk_clips: int = 0, residual="f32") -> None:
+                 max_chunk_clips: int = 0, residual="half") -> None:
         _capi.require_gpu()
         self.cfg = dict(cfg)
         self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual)
