@@ -78,6 +78,31 @@ static __device__ __forceinline__ float gelu_erf(float x) {
     return __builtin_fmaf(ax, u, 0.5f * x);
 }
 
+// Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two fp32 lanes per VALU slot):
+// 8 instruction slots per element instead of 14; used by the GEMM / pos-conv epilogues (no MFMA runs beside them).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 den = __builtin_elementwise_fma(ax, (f32x2)(0.3275911f * 0.70710678118654752440f), (f32x2)(1.0f));
+    f32x2 t;
+    t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+    f32x2 p = (f32x2)(0.5f * 1.061405429f);
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * -1.453152027f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * 1.421413741f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * -0.284496736f));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * 0.254829592f));
+    p = p * t;
+    const f32x2 xx = x * x * (f32x2)(-0.5f * 1.4426950408889634f);
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(xx[0]); e[1] = __builtin_amdgcn_exp2f(xx[1]);
+    const f32x2 u = __builtin_elementwise_fma(-p, e, (f32x2)(0.5f));
+    return __builtin_elementwise_fma(ax, u, x * (f32x2)(0.5f));
+}
+static __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+    const f32x2 a = gelu_erf2((f32x2){v[0], v[1]}), b = gelu_erf2((f32x2){v[2], v[3]});
+    return (f32x4){a[0], a[1], b[0], b[1]};
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -159,10 +159,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
                 const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v = r * alpha + v;
             }
-            if (p.gelu) {
-                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]);
-                v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-            }
+            if (p.gelu) v = gelu_erf4(v);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
                 v4 h;
@@ -195,11 +192,56 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 // half-tiles issued in B(t) = 6 DMA instructions are younger, hence vmcnt(6) in B(t), before the
 // barrier that every wave must pass before any wave reads tile t+1 (RAW).
 // ---------------------------------------------------------------------------------------------
+__device__ unsigned long long g_gemm_stamps[4 * 8192];
+__device__ int g_gemm_stamps_on = 0;
+
 constexpr int T2 = 256;
 constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32 KiB)
 
 #define AVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define AVX_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// Branch-free epilogue for half-only outputs (bias, optional GELU): bias / GELU are applied in the accumulator
+// layout, the wave's private slab holds the converted f16 values (half the LDS traffic of the fp32 transpose:
+// ds_write_b64 of 4 halves, ds_read_b128 of 8 halves per lane), and the loops carry no uniform branches so the
+// scheduler interleaves the 16 independent GELU chains of a 64-column slice (latency, not issue, bound otherwise).
+template <typename T, bool GELU>
+static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid, int wm,
+                                                     int wn, int lane, int m0, int n0) {
+    typedef typename Half<T>::v8 v8;
+    typedef typename Half<T>::v4 v4;
+    constexpr int HP_LD = 72;   // halves per slab row (64 n + 8 pad = 144 B)
+    T* slab = (T*)(smem + wid * (64 * HP_LD * 2));
+    const int er = lane >> 3, ec = lane & 7;
+    const int lc = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+        f32x4 bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4*)(p.bias + n0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[4 * ih + i][j] + bv[i];
+                if (GELU) v = gelu_erf4(v);
+                v4 h;
+                h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+                *(v4*)(slab + (16 * j + lc) * HP_LD + 16 * i + 4 * lg) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int ml = 8 * ps + er;
+            const int m = m0 + wn * 64 + ml;
+            const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
+            if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
@@ -217,6 +259,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
     const int nk = p.K / BK;
+    const bool stamp = g_gemm_stamps_on != 0 && tid == 0 && blockIdx.x < 8192;
+    if (stamp) g_gemm_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- per-lane DMA source pointers: [half][q] for W and X ------------------------------------
     // W half h = rows 128q + 64h + 8*wid + (lane>>3); X half h = rows 128q + 64*(wid>>2) + 32h + 8*(wid&3) + (lane>>3)
@@ -296,6 +340,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         AVX_VMCNT(0);
     }
     AVX_BAR();
+    if (stamp) g_gemm_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if (wm == 1) { AVX_BAR(); }   // stagger: waves 4-7 run one barrier behind
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -322,6 +367,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         AVX_BAR();
     }
     if (wm == 0) { AVX_BAR(); }   // re-align the two groups
+    if (stamp) g_gemm_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- epilogue -------------------------------------------------------------------------------
     // Each wave transposes its 128(n) x 64(m) accumulators through a private LDS slab (the stage
@@ -330,7 +376,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     // fp32 vectors), 8 lanes cover a 128-byte line, a wave instruction writes 8 full lines.  The
     // direct-from-accumulator form (8-byte stores, 32 B per row per instruction) ran the store path at
     // ~2 TB/s and cost 16 us per tile; bias / residual / GELU / masking happen after the transpose.
-    {
+    if (p.out_half && p.bias && !p.out_f32 && !p.out_raw && !p.resid && !p.resid_half && !p.row_zero) {
+        // Half-only outputs with bias and no residual (QKV, fc1 = 3/4 of the K = 768 work).
+        if (p.gelu) epilogue_half<T, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+        else epilogue_half<T, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+    } else {
         constexpr int EP_LD = 68;   // floats per slab row (64 n + 4 pad: conflict-free 16-byte writes)
         float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
         const int er = lane >> 3, ec = lane & 7;
@@ -373,10 +423,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rh[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rh[4 + e], alpha, v1[e]); }
                     }
-                    if (p.gelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = gelu_erf(v0[e]); v1[e] = gelu_erf(v1[e]); }
-                    }
+                    if (p.gelu) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }
                     if (p.out_f32) {
                         *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb) = v0;
                         *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4) = v1;
@@ -392,11 +439,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
             }
         }
     }
+    if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_gemm_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); }
 #undef AVX_READ_W
 #undef AVX_READ_X
 #undef AVX_HALF
 #undef AVX_BAR
 }
+
 
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
@@ -458,3 +507,14 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
 }
 
 }  // namespace avx
+
+// debug: enable/read the per-block stamps of gemm256_kernel (start, prologue done, loop done, epilogue stores retired)
+extern "C" int avexhip_debug_gemm_stamps(int enable, unsigned long long* host_out, int n_blocks) {
+    int on = enable;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps_on), &on, sizeof(int)) != hipSuccess) return -2;
+    if (host_out && n_blocks > 0) {
+        if (n_blocks > 8192) n_blocks = 8192;
+        if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 4 * n_blocks) != hipSuccess) return -2;
+    }
+    return 0;
+}

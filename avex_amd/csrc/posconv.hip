@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, 
         for (int ot = 0; ot < 3; ++ot) {
             const int n = ot * 16 + 4 * g4;
             f32x4 v = acc[ot][tt] + *(const f32x4*)(bias + g * CG + n);
-            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+            v = gelu_erf4(v);
             f32x4 r;
             if (xf) {
                 r = *(const f32x4*)(xf + rowoff + n);

@@ -137,6 +137,9 @@ int avexhip_mean_pool(const float* in_dev, int B, int T, int C, float* out_dev, 
 /* Debug aid: `blocks` workgroups hold a 26 880-byte LDS pattern for `iters` re-check rounds;
  * report_dev[4] (zeroed by the caller) = {mismatches, first bad word, value seen, block}. */
 int avexhip_debug_lds_canary(int blocks, int iters, unsigned* report_dev, void* stream);
+/* Debug aid: switch on per-workgroup wall-clock stamps (100 MHz) in the 256-tile GEMM and/or copy them out:
+ * host_out[4*b + {0,1,2,3}] = start, prologue complete, K loop complete, epilogue stores retired. */
+int avexhip_debug_gemm_stamps(int enable, unsigned long long* host_out, int n_blocks);
 
 /* T5 bidirectional bucket of a relative position (backbone.py:438-473).  Pure host function. */
 int avexhip_rel_bucket(int rel, int num_buckets, int max_distance);
