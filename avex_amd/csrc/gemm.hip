@@ -243,6 +243,57 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
     }
 }
 
+// Branch-free epilogue for the residual GEMMs in operand-type residual mode (out_proj, fc2 without a hook tap):
+// out = half( resid_half * alpha + acc + bias ).  The sum is formed in fp32 AFTER the transpose (fp32 slab), so the
+// residual is read and the result written as row-contiguous 16-byte vectors and nothing is rounded twice.
+template <typename T>
+static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid,
+                                                           int wm, int wn, int lane, int m0, int n0) {
+    typedef typename Half<T>::v8 v8;
+    constexpr int EP_LD = 68;
+    float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
+    const int er = lane >> 3, ec = lane & 7;
+    const float alpha = p.alpha;
+    const T* __restrict__ resid = (const T*)p.resid_half;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+        const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;
+        const f32x4 b0 = *(const f32x4*)(p.bias + nb), b1 = *(const f32x4*)(p.bias + nb + 4);
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            // residual rows of this chunk: issued first so their latency hides under the slab round trip
+            v8 rh[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                int m = m0 + wn * 64 + 32 * jh + 8 * ps + er;
+                m = m < p.M ? m : p.M - 1;
+                rh[ps] = *(const v8*)(resid + (int64_t)m * p.ldrh + nb);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *(f32x4*)(slab + (16 * j + (lane & 15)) * EP_LD + 16 * i + 4 * (lane >> 4)) = acc[4 * ih + i][2 * jh + j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int ml = 8 * ps + er;
+                const int m = m0 + wn * 64 + 32 * jh + ml;
+                const f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec) + b0;
+                const f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4) + b1;
+                v8 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = Half<T>::from(__builtin_fmaf((float)rh[ps][e], alpha, v0[e]));
+                    h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ps][4 + e], alpha, v1[e]));
+                }
+                if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -380,6 +431,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         // Half-only outputs with bias and no residual (QKV, fc1 = 3/4 of the K = 768 work).
         if (p.gelu) epilogue_half<T, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
         else epilogue_half<T, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+    } else if (p.out_half && p.bias && p.resid_half && !p.gelu && !p.out_f32 && !p.out_raw && !p.resid && !p.row_zero) {
+        epilogue_resid_half<T>(p, acc, smem, wid, wm, wn, lane, m0, n0);
     } else {
         constexpr int EP_LD = 68;   // floats per slab row (64 n + 4 pad: conflict-free 16-byte writes)
         float* slab = (float*)(smem + wid * (32 * EP_LD * 4));

@@ -63,6 +63,15 @@ def test_gemm_epilogues(built_lib, dtype, variant, shape):
     rh = round_half(resid, dtype)
     r = K.gemm(ad, wd, bias=_dev(bias), resid_half=_dev(rh, _tdt(dtype)), alpha=alpha, variant=variant)
     assert rel_l2(r["f32"].cpu().numpy(), rh * alpha + ref) < 2e-6
+    # half-only outputs take the branch-free epilogues of the 256-tile kernel: bias(+GELU) and bias+residual
+    tolh = 6e-4 if dtype == "f16" else 5e-3      # one rounding to the operand type
+    r = K.gemm(ad, wd, bias=_dev(bias), out_f32=False, out_half=True, variant=variant)
+    assert rel_l2(r["half"].float().cpu().numpy(), ref) < tolh
+    r = K.gemm(ad, wd, bias=_dev(bias), gelu=True, out_f32=False, out_half=True, variant=variant)
+    assert rel_l2(r["half"].float().cpu().numpy(), O.gelu_erf(ref.astype(np.float32))) < tolh
+    r = K.gemm(ad, wd, bias=_dev(bias), resid_half=_dev(rh, _tdt(dtype)), alpha=alpha, out_f32=False, out_half=True, variant=variant)
+    assert np.array_equal(r["half"].float().cpu().numpy(), round_half((rh * alpha + ref).astype(np.float32), dtype)) or \
+        rel_l2(r["half"].float().cpu().numpy(), rh * alpha + ref) < tolh
     # exact-erf GELU
     r = K.gemm(ad, wd, bias=_dev(bias), gelu=True, variant=variant)
     assert rel_l2(r["f32"].cpu().numpy(), O.gelu_erf(ref.astype(np.float32))) < 5e-6   # A&S 7.1.26 erf: |err| < 6e-7
