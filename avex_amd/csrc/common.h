@@ -172,6 +172,8 @@ struct GemmArgs {
     float* out_raw; int64_t ldraw;
     const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to every output
     int variant;
+    int stagger_ticks;        // variant 5: workgroups of odd slot start this many 10-ns ticks late (desynchronised epilogues)
+    int stagger_groups;       // variant 5: number of start phases (>= 1)
 };
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // exactly one of in / in_half is non-null

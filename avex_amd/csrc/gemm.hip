@@ -194,12 +194,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 // ---------------------------------------------------------------------------------------------
 __device__ unsigned long long g_gemm_stamps[4 * 8192];
 __device__ int g_gemm_stamps_on = 0;
+__device__ unsigned long long g_gemm_clk[2 * 8192];   // s_memtime (shader clock) at loop start / end, variant 5
 
 constexpr int T2 = 256;
 constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32 KiB)
 
 #define AVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define AVX_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+#define AVX_READ_W(h, st)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+        const char* r = smem + (st) * STAGE2 + wfrag + (64 * (h) + 16 * i) * 128;              \
+        wf[i][0] = *(const v8*)(r + foff0);                                                    \
+        wf[i][1] = *(const v8*)(r + foff1);                                                    \
+    }
+#define AVX_READ_X(st)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+        const char* r = smem + (st) * STAGE2 + xfrag + (16 * j) * 128;                         \
+        xf[j][0] = *(const v8*)(r + foff0);                                                    \
+        xf[j][1] = *(const v8*)(r + foff1);                                                    \
+    }
+#define AVX_HALF(hw)                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+        acc[4 * (hw) + i][j] = mfma16(wf[i][ks], xf[j][ks], acc[4 * (hw) + i][j]);             \
+    __builtin_amdgcn_s_setprio(0);
+#define AVX_BAR()                                   \
+    __builtin_amdgcn_sched_barrier(0);              \
+    __builtin_amdgcn_s_barrier();                   \
+    __builtin_amdgcn_sched_barrier(0);
+
 
 // Branch-free epilogue for half-only outputs (bias, optional GELU): bias / GELU are applied in the accumulator
 // layout, the wave's private slab holds the converted f16 values (half the LDS traffic of the fp32 transpose:
@@ -358,30 +384,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     v8 wf[4][2], xf[4][2];
 
-#define AVX_READ_W(h, st)                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-        const char* r = smem + (st) * STAGE2 + wfrag + (64 * (h) + 16 * i) * 128;              \
-        wf[i][0] = *(const v8*)(r + foff0);                                                    \
-        wf[i][1] = *(const v8*)(r + foff1);                                                    \
-    }
-#define AVX_READ_X(st)                                                                         \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
-        const char* r = smem + (st) * STAGE2 + xfrag + (16 * j) * 128;                         \
-        xf[j][0] = *(const v8*)(r + foff0);                                                    \
-        xf[j][1] = *(const v8*)(r + foff1);                                                    \
-    }
-#define AVX_HALF(hw)                                                                           \
-    __builtin_amdgcn_s_setprio(1);                                                             \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-        acc[4 * (hw) + i][j] = mfma16(wf[i][ks], xf[j][ks], acc[4 * (hw) + i][j]);             \
-    __builtin_amdgcn_s_setprio(0);
-#define AVX_BAR()                                   \
-    __builtin_amdgcn_sched_barrier(0);              \
-    __builtin_amdgcn_s_barrier();                   \
-    __builtin_amdgcn_sched_barrier(0);
-
     // ---- prologue: tile 0 complete, W0/X0/X1 of tile 1 in flight --------------------------------
     dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
     if (nk > 1) {
@@ -493,20 +495,347 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         }
     }
     if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_gemm_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); }
-#undef AVX_READ_W
-#undef AVX_READ_X
-#undef AVX_HALF
-#undef AVX_BAR
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// Variant 5: the variant-2 pipeline made PERSISTENT (one workgroup per CU walks its tiles).  The in-kernel
+// stamps of variant 2 at K = 768 read: DMA prologue 3.0 us + K loop 17.8 us + epilogue 4.4 us + 1.9 us
+// until the next workgroup starts.  Here the next tile's first 14 DMA instructions (K-tile 0 into stage 0,
+// three half-tiles of K-tile 1 into stage 1) are issued right after the K loop, BEFORE the epilogue, whose
+// transpose slabs live in the 32 KiB of LDS above the two stages (16-row chunks) -- so the prologue latency
+// and the workgroup turnaround disappear behind the epilogue.  vmcnt counts stores too, in order: the
+// epilogue's 16 stores per lane are YOUNGER than those DMAs, so the wait at the top of the next tile is
+// vmcnt(6 + 16) and does not drain them; the residual rows are loaded BEFORE the DMAs (into the fragment
+// registers, dead by then) for the same reason.  Epilogues other than the two branch-free ones fall back to
+// epilogue-then-DMA.
+// ---------------------------------------------------------------------------------------------
+constexpr int LDS5 = 2 * STAGE2 + 32768;
+
+template <typename T, int EPI>   // EPI: 0 generic epilogue, 1 half + bias (+GELU), 2 half + bias + half residual
+__global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half<T>::v8 v8;
+    typedef typename Half<T>::v4 v4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tiles_n = p.N / T2;
+    const int tiles_m = (p.M + T2 - 1) / T2;
+    const int ntiles = tiles_m * tiles_n;
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+    const int nk = p.K / BK;   // >= 2 (launcher)
+    // blocks sharing blockIdx % 8 share an XCD: in round `it` they take 32 consecutive tiles (n fastest)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7) >> 3;
+    int m0 = 0, n0 = 0;
+
+    const T* wsrc[2][2];
+    const T* xsrc[2][2];
+    int wdst[2][2], xdst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wdst[h][q] = (128 * q + 64 * h + 8 * wid) * 128;
+            xdst[h][q] = T2 * BK * 2 + (128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3)) * 128;
+        }
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        m0 = tm * T2; n0 = tn * T2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int wr = 128 * q + 64 * h + 8 * wid + (lane >> 3);
+                wsrc[h][q] = W + (int64_t)(n0 + wr) * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3);
+                const int xr = 128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3) + (lane >> 3);
+                int arow = m0 + xr;
+                arow = arow < p.M ? arow : p.M - 1;
+                xsrc[h][q] = A + (int64_t)arow * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3);
+            }
+    };
+    auto dma_w = [&](int h, int kt) __attribute__((always_inline)) {
+        char* base = smem + (kt & 1) * STAGE2;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, 0);
+    };
+    auto dma_x = [&](int h, int kt) __attribute__((always_inline)) {
+        char* base = smem + (kt & 1) * STAGE2;
+        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, 0);
+    };
+    auto tile_prologue = [&]() __attribute__((always_inline)) {   // 14 DMA instructions
+        dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
+        dma_w(0, 1); dma_x(0, 1); dma_x(1, 1);
+    };
+    const int sw = (lane >> 1) & 7;
+    const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);
+    const int foff1 = foff0 ^ 64;
+    const int wfrag = (wm * 128) * 128;
+    const int xfrag = T2 * BK * 2 + (wn * 64) * 128;
+    constexpr bool fast_half = EPI == 1, fast_resid = EPI == 2, overlapped = EPI != 0;
+
+    f32x4 acc[8][4];
+    v8 wf[4][2], xf[4][2];
+
+    int tile = (0 * 8 + xcd) * per_xcd + slot;
+    if (tile >= ntiles) return;
+    set_tile(tile);
+    tile_prologue();
+    if (p.stagger_ticks > 0 && p.stagger_groups > 1) {
+        // Start phases: every workgroup runs the same schedule, so without this all 256 CUs reach their epilogues together
+        // and the chip alternates between an HBM-idle K loop and an HBM-bound store burst.  Phase g starts g * ticks late.
+        const int g = slot % p.stagger_groups;
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(g * p.stagger_ticks);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
+    const bool stamp_on = g_gemm_stamps_on != 0 && tid == 0;
+    bool stores_behind = false;   // the previous epilogue's 16 stores are younger than this tile's prologue DMAs
+
+    for (int it = 0;; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool stamp = stamp_on && tile < 8192;
+        if (stamp) g_gemm_stamps[4 * tile + 0] = __builtin_amdgcn_s_memrealtime();
+        if (stores_behind) { AVX_VMCNT(22); } else { AVX_VMCNT(6); }
+        AVX_BAR();
+        if (stamp) { g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); }
+        if (wm == 1) { AVX_BAR(); }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int st = kt & 1;
+            AVX_READ_X(st);
+            AVX_READ_W(0, st);
+            if (kt + 1 < nk) dma_w(1, kt + 1);
+            AVX_LGKM0();
+            AVX_BAR();
+            AVX_HALF(0);
+            AVX_BAR();
+            AVX_READ_W(1, st);
+            if (kt + 2 < nk) {
+                dma_w(0, kt + 2); dma_x(0, kt + 2); dma_x(1, kt + 2);
+                AVX_VMCNT(6);
+            } else {
+                AVX_VMCNT(0);
+            }
+            AVX_LGKM0();
+            AVX_BAR();
+            AVX_HALF(1);
+            AVX_BAR();
+        }
+        if (wm == 0) { AVX_BAR(); }
+        if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); }
+
+        const int em0 = m0, en0 = n0;
+        const int next_tile = ((it + 1) * 8 + xcd) * per_xcd + slot;
+        const bool has_next = next_tile < ntiles;
+        const int er = lane >> 3, ec = lane & 7, lc = lane & 15, lg = lane >> 4;
+
+        if constexpr (fast_half) {
+            // bias first: a vector load issued after the DMAs could only be waited for together with them
+            f32x4 bvv[2][4];
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bvv[ih][i] = *(const f32x4*)(p.bias + en0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has_next) { set_tile(next_tile); tile_prologue(); }
+            constexpr int HP_LD = 72;
+            T* slab = (T*)(smem + 2 * STAGE2 + wid * (16 * HP_LD * 2));
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                f32x4 bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = bvv[ih][i];
+                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 v = acc[4 * ih + i][j] + bv[i];
+                        if (p.gelu) v = gelu_erf4(v);
+                        v4 h;
+                        h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+                        *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int ml = 8 * ps + er;
+                        const int m = em0 + wn * 64 + 16 * j + ml;
+                        const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
+                        if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next chunk overwrites it
+                }
+            }
+        } else if constexpr (fast_resid) {
+            // the first half's residual vectors are loaded before the DMAs (so waiting for them does not wait for the
+            // DMAs); the second half's are issued two chunks later, when the DMAs have long landed
+            const T* __restrict__ resid = (const T*)p.resid_half;
+            v8 rh[2][4][2];
+            auto load_resid = [&](int ih) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        int m = em0 + wn * 64 + 16 * j + 8 * ps + er;
+                        m = m < p.M ? m : p.M - 1;
+                        rh[ih][j][ps] = *(const v8*)(resid + (int64_t)m * p.ldrh + en0 + wm * 128 + 64 * ih + 8 * ec);
+                    }
+            };
+            f32x4 bb[2][2];
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                bb[ih][0] = *(const f32x4*)(p.bias + en0 + wm * 128 + 64 * ih + 8 * ec);
+                bb[ih][1] = *(const f32x4*)(p.bias + en0 + wm * 128 + 64 * ih + 8 * ec + 4);
+            }
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // bias landed (older than the 8 residual loads)
+            load_resid(0);
+            asm volatile("" ::: "memory");
+            if (has_next) { set_tile(next_tile); tile_prologue(); }
+            float* slab = (float*)(smem + 2 * STAGE2 + wid * 4096);   // 16 rows x 64 floats, 16-byte chunk c of row r at slot c ^ r
+            const float alpha = p.alpha;
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
+                const f32x4 b0 = bb[ih][0], b1 = bb[ih][1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ih == 0 && j == 2) load_resid(1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *(f32x4*)((char*)slab + lc * 256 + (((4 * i + lg) ^ lc) << 4)) = acc[4 * ih + i][j];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int ml = 8 * ps + er;
+                        const int m = em0 + wn * 64 + 16 * j + ml;
+                        const f32x4 v0 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec) ^ ml) << 4)) + b0;
+                        const f32x4 v1 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec + 1) ^ ml) << 4)) + b1;
+                        v8 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h[e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][e], alpha, v0[e]));
+                            h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][4 + e], alpha, v1[e]));
+                        }
+                        if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        } else {
+            // generic epilogue (fp32 outputs, hook taps, masks): slabs in the stage memory, then the next prologue
+            constexpr int EP_LD = 68;
+            float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
+            const float alpha = p.alpha;
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            *(f32x4*)(slab + (16 * j + lc) * EP_LD + 16 * i + 4 * lg) = acc[4 * ih + i][2 * jh + j];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int ml = 8 * ps + er;
+                        const int m = em0 + wn * 64 + 32 * jh + ml;
+                        f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
+                        f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
+                        if (m >= p.M) continue;
+                        v0 += b0; v1 += b1;
+                        if (p.row_zero != nullptr && p.row_zero[m] != 0) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+                        if (p.out_raw) {
+                            *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb) = v0;
+                            *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4) = v1;
+                        }
+                        if (p.resid) {
+                            const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
+                            const f32x4 r1 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf(r0[e], alpha, v0[e]); v1[e] = __builtin_fmaf(r1[e], alpha, v1[e]); }
+                        } else if (p.resid_half) {
+                            const v8 rr = *(const v8*)((const T*)p.resid_half + (int64_t)m * p.ldrh + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rr[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rr[4 + e], alpha, v1[e]); }
+                        }
+                        if (p.gelu) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }
+                        if (p.out_f32) {
+                            *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb) = v0;
+                            *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4) = v1;
+                        }
+                        if (p.out_half) {
+                            v8 h;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
+                            *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+            if (has_next) {
+                AVX_BAR();   // every wave is done with its slab before the stages are refilled
+                set_tile(next_tile);
+                tile_prologue();
+            }
+        }
+        if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime();
+        if (!has_next) break;
+        tile = next_tile;
+        stores_behind = overlapped;
+    }
+}
+
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
-    // variant: 0 = auto, 1 = 128-tile register staging, 2 = 256-tile half-tile pipeline, 3 = 128-tile LDS-DMA
+    // variant: 0 = auto, 1 = 128-tile register staging, 2 = 256-tile half-tile pipeline, 3 = 128-tile LDS-DMA,
+    // 5 = variant 2 persistent (next tile's DMA prologue issued before the epilogue)
     int variant = a.variant;
     if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
     if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 2 : 3;
     if (variant == 2 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
+    if (variant == 5 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8) || a.K < 2 * BK)) variant = 3;
+    if (variant == 5) {
+        static bool attr_set5 = false;
+        static int n_cu = 0;
+        if (!attr_set5) {
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
+            int dev = 0;
+            hipDeviceProp_t prop;
+            AVX_HIP_CHECK(hipGetDevice(&dev));
+            AVX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            attr_set5 = true;
+        }
+        const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
+        static const int stag_us10 = getenv("AVEX_AMD_GEMM_STAGGER") ? atoi(getenv("AVEX_AMD_GEMM_STAGGER")) : 0;    // 0.1-us units
+        static const int stag_groups = getenv("AVEX_AMD_GEMM_STAGGER_GROUPS") ? atoi(getenv("AVEX_AMD_GEMM_STAGGER_GROUPS")) : 2;
+        avx::GemmArgs a5 = a;
+        a5.stagger_ticks = stag_us10 * 10;
+        a5.stagger_groups = stag_groups;
+        int grid = tiles < n_cu ? ((tiles + 7) / 8) * 8 : (n_cu / 8) * 8;
+        if (grid < 8) grid = 8;
+        if (const char* fg = getenv("AVEX_AMD_GEMM_GRID")) { const int g = atoi(fg); if (g >= 8) grid = (g / 8) * 8; }   // tests: force many tiles per workgroup
+        const bool fast_half = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.resid_half && !a.row_zero;
+        const bool fast_resid = a.out_half && a.bias && a.resid_half && !a.gelu && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero;
+        if (fast_half) hipLaunchKernelGGL((gemm256p_kernel<T, 1>), dim3(grid), dim3(512), LDS5, s, a5);
+        else if (fast_resid) hipLaunchKernelGGL((gemm256p_kernel<T, 2>), dim3(grid), dim3(512), LDS5, s, a5);
+        else hipLaunchKernelGGL((gemm256p_kernel<T, 0>), dim3(grid), dim3(512), LDS5, s, a5);
+        AVX_LAUNCH_CHECK();
+        return AVEXHIP_OK;
+    }
     if (variant == 2) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -569,5 +898,13 @@ extern "C" int avexhip_debug_gemm_stamps(int enable, unsigned long long* host_ou
         if (n_blocks > 8192) n_blocks = 8192;
         if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 4 * n_blocks) != hipSuccess) return -2;
     }
+    return 0;
+}
+
+// debug: shader-clock readings (s_memtime) at the K loop's start and end, per tile, of the persistent 256-tile GEMM
+extern "C" int avexhip_debug_gemm_clocks(unsigned long long* host_out, int n_tiles) {
+    if (!host_out || n_tiles <= 0) return -1;
+    if (n_tiles > 8192) n_tiles = 8192;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_clk), sizeof(unsigned long long) * 2 * n_tiles) != hipSuccess) return -2;
     return 0;
 }

@@ -140,6 +140,9 @@ int avexhip_debug_lds_canary(int blocks, int iters, unsigned* report_dev, void* 
 /* Debug aid: switch on per-workgroup wall-clock stamps (100 MHz) in the 256-tile GEMM and/or copy them out:
  * host_out[4*b + {0,1,2,3}] = start, prologue complete, K loop complete, epilogue stores retired. */
 int avexhip_debug_gemm_stamps(int enable, unsigned long long* host_out, int n_blocks);
+/* Debug aid: shader-clock counter (s_memtime) at the start and end of each tile's K loop in the persistent GEMM
+ * (variant 5), host_out[2*tile + {0,1}]; with the stamps above this gives the clock the chip held in the loop. */
+int avexhip_debug_gemm_clocks(unsigned long long* host_out, int n_tiles);
 
 /* T5 bidirectional bucket of a relative position (backbone.py:438-473).  Pure host function. */
 int avexhip_rel_bucket(int rel, int num_buckets, int max_distance);

@@ -40,7 +40,7 @@ def test_cast_roundtrip(built_lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
 @pytest.mark.parametrize("shape", [(300, 256, 192), (1984, 768, 768), (128, 128, 64), (77, 3072, 768), (2500, 512, 256), (1024, 768, 3072)])
 def test_gemm_epilogues(built_lib, dtype, variant, shape):
     from avex_amd import kernels as K
@@ -75,6 +75,32 @@ def test_gemm_epilogues(built_lib, dtype, variant, shape):
     # exact-erf GELU
     r = K.gemm(ad, wd, bias=_dev(bias), gelu=True, variant=variant)
     assert rel_l2(r["f32"].cpu().numpy(), O.gelu_erf(ref.astype(np.float32))) < 5e-6   # A&S 7.1.26 erf: |err| < 6e-7
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2500, 768, 256), (3000, 512, 128), (1100, 3072, 192)])
+def test_gemm_persistent_matches_tiled(built_lib, dtype, shape, monkeypatch):
+    """Variant 5 (persistent workgroups) walks several tiles per workgroup when the grid is forced to 8:
+    every epilogue must reproduce variant 2 bit for bit (same K order, same epilogue arithmetic)."""
+    from avex_amd import kernels as K
+    monkeypatch.setenv("AVEX_AMD_GEMM_GRID", "8")
+    M, N, Kd = shape
+    a = _dev(round_half(synth.normal(f"pA{shape}", (M, Kd), 1.0), dtype), _tdt(dtype))
+    w = _dev(round_half(synth.normal(f"pW{shape}", (N, Kd), 0.05), dtype), _tdt(dtype))
+    bias = _dev(synth.normal("pbias", (N,), 0.1))
+    rh = _dev(round_half(synth.normal("presid", (M, N), 1.0), dtype), _tdt(dtype))
+    resid = _dev(synth.normal("presid32", (M, N), 1.0))
+    cases = [dict(out_f32=False, out_half=True), dict(out_f32=False, out_half=True, gelu=True),
+             dict(out_f32=False, out_half=True, resid_half=rh, alpha=2.2133638),
+             dict(out_f32=True, out_half=True, out_raw=True, resid=resid, alpha=2.2133638),
+             dict(out_f32=True, resid_half=rh, alpha=0.5, gelu=True)]
+    for kw in cases:
+        for _ in range(2):          # twice: a stale prologue from the previous launch must not matter
+            r5 = K.gemm(a, w, bias=bias, variant=5, **kw)
+            r2 = K.gemm(a, w, bias=bias, variant=2, **kw)
+            for key in r2:
+                if r2[key] is not None:
+                    assert torch.equal(r5[key], r2[key]), (kw.keys(), key)
 
 
 def test_gemm_rejects_bad_shapes(built_lib):
