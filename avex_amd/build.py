@@ -45,6 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdr = _deps_mtime()
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-Wno-unused-result",
              "-fno-gpu-rdc", "-ffp-contract=off"]
+    flags += os.environ.get("AVEX_AMD_EXTRA_CFLAGS", "").split()      # diagnostic builds, e.g. -DATT_STAMPS=1
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

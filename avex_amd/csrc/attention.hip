@@ -245,6 +245,404 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Variant 2: persistent, K/V streamed by LDS-DMA under the compute.
+//
+// Variant 1 above stages a whole head (K, V^T, bias row) and only then computes: at B = 256 its staging is
+// HBM-bound (15 of 42 us per workgroup) and nothing overlaps it.  Here one workgroup per CU walks a contiguous
+// range of (head, clip) items; the keys of an item are split in two halves of 256 and the two 64 KiB LDS
+// buffers are filled by LDS-DMA one phase ahead (item i half 1 while half 0 is computed, item i+1 half 0 while
+// half 1 is computed), so the HBM stream runs continuously beside the MFMA/softmax work.  V stays row-major
+// in 8-key x 32-column subtiles and is consumed with ds_read_b64_tr_b16 (the hardware transpose read), which
+// removes the scalar transposing stores of variant 1.  The next item's Q fragment is prefetched into registers
+// during the last phase of the current one, and an item's output is stored after the next phase's DMA has been
+// issued.  The softmax uses a deferred running maximum (rescale only when a row's maximum grows by more than 2^8):
+// the reference value is subtracted inside the score FMA, so a score costs two packed FMAs, one v_exp_f32, one
+// add and half a convert.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void a_gptr_t;
+typedef __attribute__((address_space(3))) void a_lptr_t;
+typedef short a_s4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef int a_i32x2 __attribute__((ext_vector_type(2)));
+template <int N> struct a_ic { static constexpr int value = N; };
+
+constexpr int A2_KBUF = 32768;                            // 256 keys x 128 B, 16-byte chunks XOR-swizzled
+constexpr int A2_HALF = 65536;                            // + 256 keys of V as 32 subtile rows of 1 KiB
+constexpr int A2_TAB_OFF = 2 * A2_HALF;
+constexpr int A2_KADD_OFF = A2_TAB_OFF + TAB_BYTES;
+constexpr int A2_GW_OFF = A2_KADD_OFF + 2 * KADD_BYTES;
+constexpr int ATT2_LDS = A2_GW_OFF + GW_BYTES;
+constexpr float A2_THR = 8.f;
+#ifndef ATT_STAMPS
+#define ATT_STAMPS 0     // diagnostic build: -DATT_STAMPS=1 prints one tile's cycle stamps (AVEX_AMD_ATT_DEBUG=4)
+#endif                             // deferred-max threshold, log2 units (p <= 256)
+
+template <typename T>
+__global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block,
+                                                        const float* __restrict__ bias_tab,
+                                                        const float* __restrict__ grep_w,
+                                                        const float* __restrict__ grep_b,
+                                                        const float* __restrict__ grep_a,
+                                                        const uint8_t* __restrict__ key_pad,
+                                                        T* __restrict__ out, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half<T>::v8 v8;
+    typedef typename Half<T>::v4 v4;
+    constexpr int NQ = 2, NW = 8, NT = 512;              // 8 waves, two 32-query tiles each (tile wave + 8 u)
+    float* tab = (float*)(smem + A2_TAB_OFF);
+    float* kadd = (float*)(smem + A2_KADD_OFF);
+    float* gw = (float*)(smem + A2_GW_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_items = Bc * H;
+    const int it0 = blockIdx.x * per_block;
+    const int it1 = it0 + per_block < n_items ? it0 + per_block : n_items;
+    if (it0 >= it1) return;
+    const int E = H * 64;
+    const int64_t ld = 3 * (int64_t)E;
+    const float NEG_INF = -__builtin_inff();
+    const int nh = Tn > 256 ? 2 : 1;
+    const int np = (it1 - it0) * nh;
+    const int nkt = (Tn + 31) >> 5;
+    const int hh = lane >> 5, r32 = lane & 31;
+    int qi[NQ], iq[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        qi[u] = (wave + NW * u) * 32 + r32;
+        iq[u] = qi[u] < Tn ? qi[u] : Tn - 1;             // clamped for loads; stores are masked
+    }
+    const bool has_q = wave * 32 < Tn;                   // wave-uniform: tile u = 0 exists
+
+    // Items are h * Bc + b, walked in order: (h, b) of the item being computed and of the one being loaded are kept
+    // incrementally (no division in the loop).  A workgroup's range stays on one head, or two at a seam.
+    int h_cur = it0 / Bc, b_cur = it0 - h_cur * Bc;      // item of the phase being computed
+    int h_ld = h_cur, b_ld = b_cur, half_ld = 0;         // (item, half) the next DMA fetches
+    int item_par = 0;                                    // parity of the item being computed: its kadd slot
+
+    auto issue_next = [&](int ph) __attribute__((always_inline)) {      // DMA for phase ph = (h_ld, b_ld, half_ld), then advance
+        const T* base = qkv + (int64_t)b_ld * Tn * ld + h_ld * 64;
+        char* buf = smem + (ph & 1) * A2_HALF;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ri = 4 * wave + u;                                   // 8-key group inside the half
+            const int kl = 8 * ri + (lane >> 3);
+            int key = half_ld * 256 + kl;
+            key = key < Tn ? key : Tn - 1;                                 // clamped rows are masked by kadd
+            const int chunk = (lane & 7) ^ ((kl >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((a_gptr_t*)(base + (int64_t)key * ld + E + chunk * 8), (a_lptr_t*)(buf + ri * 1024), 16, 0, 0);
+            int vkey = half_ld * 256 + 8 * ri + ((lane >> 2) & 7);
+            vkey = vkey < Tn ? vkey : Tn - 1;
+            const int ch = 4 * (lane >> 5) + (lane & 3);
+            __builtin_amdgcn_global_load_lds((a_gptr_t*)(base + (int64_t)vkey * ld + 2 * E + ch * 8), (a_lptr_t*)(buf + A2_KBUF + ri * 1024), 16, 0, 0);
+        }
+        if (++half_ld == nh) { half_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } }
+    };
+    auto write_kadd = [&](int slot, int b) __attribute__((always_inline)) {
+        for (int j = tid; j < TMAX; j += NT) {
+            bool ok = j < Tn;
+            if (ok && key_pad) ok = key_pad[(int64_t)b * Tn + j] == 0;
+            kadd[slot * TMAX + j] = ok ? 0.f : NEG_INF;
+        }
+    };
+
+    v8 qf[NQ][4];
+    auto load_q = [&](int h, int b) __attribute__((always_inline)) {
+        const T* base = qkv + (int64_t)b * Tn * ld + h * 64;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[u][s] = *(const v8*)(base + (int64_t)iq[u] * ld + 16 * s + 8 * hh);
+    };
+    load_q(h_cur, b_cur);                                // older than the DMA below: waiting for it never waits for the DMA
+    issue_next(0);
+    write_kadd(0, b_cur);
+    if (tid < 64) {
+        float a = 0.f, bb = 0.f;
+        if (grep_w) {
+            a = (grep_w[0 * 64 + tid] + grep_w[1 * 64 + tid]) + (grep_w[2 * 64 + tid] + grep_w[3 * 64 + tid]);
+            bb = (grep_w[4 * 64 + tid] + grep_w[5 * 64 + tid]) + (grep_w[6 * 64 + tid] + grep_w[7 * 64 + tid]);
+        }
+        gw[tid] = a;
+        gw[64 + tid] = bb;
+        if (tid == 0) {
+            gw[128] = grep_w ? (grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]) : 0.f;
+            gw[129] = grep_w ? (grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]) : 0.f;
+        }
+    }
+
+    int h_tab = -1;
+    float gate[NQ], m_run[NQ], l_run[NQ];
+    bool ref_set[NQ];
+    f32x16 o0[NQ], o1[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        gate[u] = 1.f; m_run[u] = 0.f; l_run[u] = 0.f; ref_set[u] = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
+    }
+    const int li = lane & 15;
+    const int v_lane = 64 * (4 * hh + (li >> 2)) + 32 * ((lane >> 4) & 1) + 8 * (li & 3);   // transposed-read address, per lane
+    const float cs = 0.125f * 1.4426950408889634f;
+
+    // Output of item (h, b): the lane pair (l, l + 32) holds a query row's d = 8g + 4hh + 0..3; two v_permlane32_swap per
+    // pair of g give each lane 8 consecutive d, so a row is written in 16-byte pieces (four stores per 32-query tile).
+    auto store_item = [&](int h, int b) __attribute__((always_inline)) {
+        if (!has_q) return;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+            const float inv = 1.f / l_tot;
+            T* orow = out + ((int64_t)b * Tn + qi[u]) * E + h * 64 + 8 * hh;
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    v4 x, y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = Half<T>::from((oh ? o1[u] : o0[u])[8 * gp + e] * inv);
+                        y[e] = Half<T>::from((oh ? o1[u] : o0[u])[8 * gp + 4 + e] * inv);
+                    }
+                    a_i32x2 xi = __builtin_bit_cast(a_i32x2, x), yi = __builtin_bit_cast(a_i32x2, y);
+                    int x0 = xi[0], x1 = xi[1], y0 = yi[0], y1 = yi[1];
+                    // swap x's upper-half lanes with y's lower-half lanes: low lanes end with d 16gp + 0..7, high lanes with 8..15
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+                    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+                    const i32x4_t w = {x0, x1, y0, y1};
+                    if (qi[u] < Tn) *(i32x4_t*)(orow + 32 * oh + 16 * gp) = w;
+                }
+            }
+        }
+    };
+
+    for (int ph = 0; ph < np; ++ph) {
+        const int half = nh == 2 ? (ph & 1) : 0;
+        const bool last_half = half == nh - 1;
+        const bool more_items = ph + (nh - half) < np;   // another item follows the one being computed
+        // phase boundary: this wave's DMA for phase ph (issued one phase ago) has landed and every wave has finished
+        // reading the other buffer.  When the previous phase ended an item, the 8 loads of the next item's Q are younger
+        // than that DMA and stay in flight.
+#define AVX_PT(i) if (ATT_STAMPS) { __builtin_amdgcn_sched_barrier(0); pt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        unsigned long long pt[8];
+        AVX_PT(0)
+        if (half == 0 && ph > 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        AVX_PT(1)
+        __builtin_amdgcn_s_barrier();
+        AVX_PT(2)
+        if (ph + 1 < np && dbg != 3) issue_next(ph + 1);
+        AVX_PT(3)
+        if (half == 0) {
+            if (h_cur != h_tab) {                        // workgroup-uniform
+                for (int r = tid; r < TAB_LD; r += NT) {
+                    float v = 0.f;
+                    if (bias_tab && r < 2 * Tn - 1) v = bias_tab[(int64_t)h_cur * (2 * Tn - 1) + r] * 1.4426950408889634f;
+#pragma unroll
+                    for (int sft = 0; sft < 4; ++sft)
+                        if (r - sft >= 0) tab[sft * TAB_LD + (r - sft)] = v;
+                }
+                h_tab = h_cur;
+                __syncthreads();
+            }
+            if (more_items) {                            // the next item's key mask, read two barriers from now
+                int bn = b_cur + 1;
+                bn = bn == Bc ? 0 : bn;
+                write_kadd(item_par ^ 1, bn);
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                gate[u] = 1.f;
+                if (grep_w) {
+                    f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                        for (int j4 = 0; j4 < 2; ++j4) {
+                            const f32x4 wa = *(const f32x4*)(gw + 16 * s + 8 * hh + 4 * j4);
+                            const f32x4 wb = *(const f32x4*)(gw + 64 + 16 * s + 8 * hh + 4 * j4);
+                            const f32x2 q01 = {(float)qf[u][s][4 * j4], (float)qf[u][s][4 * j4 + 1]};
+                            const f32x2 q23 = {(float)qf[u][s][4 * j4 + 2], (float)qf[u][s][4 * j4 + 3]};
+                            pa = __builtin_elementwise_fma((f32x2){wa[0], wa[1]}, q01, pa);
+                            pa = __builtin_elementwise_fma((f32x2){wa[2], wa[3]}, q23, pa);
+                            pb = __builtin_elementwise_fma((f32x2){wb[0], wb[1]}, q01, pb);
+                            pb = __builtin_elementwise_fma((f32x2){wb[2], wb[3]}, q23, pb);
+                        }
+                    }
+                    float sa = pa[0] + pa[1], sb = pb[0] + pb[1];
+                    sa += __shfl_xor(sa, 32, 64);
+                    sb += __shfl_xor(sb, 32, 64);
+                    const float ga = 1.f / (1.f + __expf(-(sa + gw[128])));
+                    const float gb = 1.f / (1.f + __expf(-(sb + gw[129])));
+                    gate[u] = ga * (gb * grep_a[h_cur] - 1.f) + 2.f;
+                }
+            }
+        }
+        AVX_PT(4)
+        if (has_q) {
+            const char* Kb = smem + (ph & 1) * A2_HALF;
+            const float* kad = kadd + item_par * TMAX;
+            int kt_end = nkt - half * 8 < 8 ? nkt - half * 8 : 8;
+            if (dbg == 1) kt_end = 0;
+            if (dbg == 2) kt_end = 1;
+            // per-phase address registers; everything inside the 8 unrolled key tiles is base + immediate
+            const int swz = (r32 >> 1) & 7;
+            const char* kp[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kp[s] = Kb + r32 * 128 + (((hh + 2 * s) ^ swz) << 4);
+            const float* tp[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int tb = half * 256 + 4 * hh - iq[u] + (Tn - 1);
+                tp[u] = tab + (tb & 3) * TAB_LD + (tb & ~3);
+            }
+            const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + A2_KBUF + v_lane);
+
+            v8 kf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s]);
+            auto tile = [&](auto KT) __attribute__((always_inline)) {
+                constexpr int ktl = decltype(KT)::value;
+                const int kt = half * 8 + ktl;
+                const int jb = kt * 32 + 4 * hh;
+                const bool masked_tile = key_pad != nullptr || kt * 32 + 32 > Tn;   // wave-uniform
+                // V fragments of this key tile, transposed by the LDS: issued now, waited for after the softmax
+                a_i32x2 vt[2][2][2];
+#define AVX_TR(dst, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF))
+                AVX_TR(vt[0][0][0], 1024 * (ktl * 4 + 0) + 0);   AVX_TR(vt[0][0][1], 1024 * (ktl * 4 + 1) + 0);
+                AVX_TR(vt[0][1][0], 1024 * (ktl * 4 + 0) + 512); AVX_TR(vt[0][1][1], 1024 * (ktl * 4 + 1) + 512);
+                AVX_TR(vt[1][0][0], 1024 * (ktl * 4 + 2) + 0);   AVX_TR(vt[1][0][1], 1024 * (ktl * 4 + 3) + 0);
+                AVX_TR(vt[1][1][0], 1024 * (ktl * 4 + 2) + 512); AVX_TR(vt[1][1][1], 1024 * (ktl * 4 + 3) + 512);
+#undef AVX_TR
+                // both query tiles in one straight-line block: S chains, scores, exponentials.  The running reference is
+                // checked AFTER the exponentials, on the half-row sums that are needed anyway: a sum below 2^12 proves every p of
+                // this lane is below 2^12 (f16-safe), so the common path has no maximum at all.
+                float e[NQ][16];
+                v8 pf[NQ][2];
+                f32x2 ls[NQ];
+                bool moves = false;
+                f32x16 Sq[NQ];
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Sq[u][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Sq[u] = mfma32(kf[s], qf[u][s], Sq[u]);
+                }
+                // the K fragment is dead once both chains are issued: the next tile's goes into the same registers now
+                if (ktl + 1 < 8) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
+                }
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const f32x16 S = Sq[u];
+                    // e = score - m_run in log2 units: S * (log2e / 8) + (gate * (bias * log2e) - m_run)
+                    const f32x2 g2 = {gate[u], gate[u]}, c2 = {cs, cs}, nm2 = {-m_run[u], -m_run[u]};
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 t4 = *(const f32x4*)(tp[u] + ktl * 32 + 8 * g4);
+                        const f32x2 ea = __builtin_elementwise_fma((f32x2){S[4 * g4], S[4 * g4 + 1]}, c2, __builtin_elementwise_fma(g2, (f32x2){t4[0], t4[1]}, nm2));
+                        const f32x2 eb = __builtin_elementwise_fma((f32x2){S[4 * g4 + 2], S[4 * g4 + 3]}, c2, __builtin_elementwise_fma(g2, (f32x2){t4[2], t4[3]}, nm2));
+                        e[u][4 * g4] = ea[0]; e[u][4 * g4 + 1] = ea[1]; e[u][4 * g4 + 2] = eb[0]; e[u][4 * g4 + 3] = eb[1];
+                    }
+                    if (masked_tile) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) e[u][r] += kad[jb + (r & 3) + 8 * (r >> 2)];
+                    }
+                    ls[u] = (f32x2){0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 pp = {__builtin_amdgcn_exp2f(e[u][r]), __builtin_amdgcn_exp2f(e[u][r + 1])};
+                        ls[u] += pp;
+                        pf[u][r >> 3][r & 7] = (T)pp[0];
+                        pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
+                    }
+                    // !(sum < 2^12) also catches the overflowed (inf) and the invalid (NaN) sum
+                    moves = moves || !ref_set[u] || !(ls[u][0] + ls[u][1] < 4096.f);
+                }
+                if (__any(moves)) {
+                    // a row's first unmasked tile sets its reference to the row maximum; later it moves when a tile has grown past it.
+                    // The exponentials of this tile are redone against the new reference.
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        float mx = e[u][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, e[u][r]);
+                        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                        const bool need = ref_set[u] ? mx > A2_THR : mx != NEG_INF;
+                        const float d = need ? mx : 0.f;
+                        const float alpha = (need && ref_set[u]) ? __builtin_amdgcn_exp2f(-d) : 1.f;
+                        ref_set[u] = ref_set[u] || need;
+                        m_run[u] += d;
+                        l_run[u] *= alpha;
+                        ls[u] = (f32x2){0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2 pp = {__builtin_amdgcn_exp2f(e[u][r] - d), __builtin_amdgcn_exp2f(e[u][r + 1] - d)};
+                            ls[u] += pp;
+                            pf[u][r >> 3][r & 7] = (T)pp[0];
+                            pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) l_run[u] += ls[u][0] + ls[u][1];
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                               "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]));
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int dh = 0; dh < 2; ++dh) {
+                        const v4 lo = __builtin_bit_cast(v4, vt[s2][dh][0]), hi = __builtin_bit_cast(v4, vt[s2][dh][1]);
+                        const v8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int u = 0; u < NQ; ++u) {
+                            if (dh == 0) o0[u] = mfma32(vf, pf[u][s2], o0[u]);
+                            else o1[u] = mfma32(vf, pf[u][s2], o1[u]);
+                        }
+                    }
+                }
+            };
+            if (0 < kt_end) tile(a_ic<0>{});
+            if (1 < kt_end) tile(a_ic<1>{});
+            if (2 < kt_end) tile(a_ic<2>{});
+            if (3 < kt_end) tile(a_ic<3>{});
+            if (4 < kt_end) tile(a_ic<4>{});
+            if (5 < kt_end) tile(a_ic<5>{});
+            if (6 < kt_end) tile(a_ic<6>{});
+            if (7 < kt_end) tile(a_ic<7>{});
+        }
+        AVX_PT(5)
+        if (last_half) {
+            // the item is complete: its Q fragment is dead, so the next item's goes straight into the same registers (these 8
+            // loads are what the vmcnt(8) at the next boundary leaves in flight); then normalise and store
+            int hn = h_cur, bn = b_cur + 1;
+            if (bn == Bc) { bn = 0; ++hn; }
+            if (more_items) load_q(hn, bn);
+            store_item(h_cur, b_cur);
+            h_cur = hn; b_cur = bn; item_par ^= 1;
+            // (stores are younger than the Q loads: the boundary's vmcnt(8) would have to be vmcnt(16) to skip them; it waits
+            // for them instead, which also keeps the count independent of has_q)
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                m_run[u] = 0.f; l_run[u] = 0.f; ref_set[u] = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
+            }
+        }
+        AVX_PT(6)
+#undef AVX_PT
+        if (ATT_STAMPS && dbg == 4 && blockIdx.x == 3 && tid == 0 && ph >= 2 && ph < 8)
+            printf("phase %d half %d: vmwait %llu barrier %llu dma-issue %llu setup %llu tiles %llu finish %llu\n", ph, half, pt[1] - pt[0], pt[2] - pt[1],
+                   pt[3] - pt[2], pt[4] - pt[3], pt[5] - pt[4], pt[6] - pt[5]);
+    }
+}
+
 template <typename T>
 int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const float* grep_w, const float* grep_b,
            const float* grep_a, const uint8_t* key_pad, void* out, hipStream_t s) {
@@ -254,6 +652,29 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         attr_set = true;
     }
     static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
+    const int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
+    if (variant == 2) {
+        static bool attr2_set = false;
+        static int n_cu = 0;
+        if (!attr2_set) {
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+            int dev = 0;
+            hipDeviceProp_t prop;
+            AVX_HIP_CHECK(hipGetDevice(&dev));
+            AVX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            attr2_set = true;
+        }
+        const int n_items = B * H;
+        int n_wg = n_cu;
+        if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several items per workgroup
+        const int per_block = (n_items + n_wg - 1) / n_wg;
+        const int grid = (n_items + per_block - 1) / per_block;
+        hipLaunchKernelGGL(attention2_kernel<T>, dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab,
+                           grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+        AVX_LAUNCH_CHECK();
+        return AVEXHIP_OK;
+    }
     hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(1024), ATT_LDS, s, (const T*)qkv, Tn, H, bias_tab, grep_w,
                        grep_b, grep_a, key_pad, (T*)out, dbg);
     AVX_LAUNCH_CHECK();

@@ -168,10 +168,12 @@ def _toeplitz(table, T, nb, md):
     return tab
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("T", [496, 48, 384, 33, 512])
-def test_attention(built_lib, dtype, T):
+def test_attention(built_lib, dtype, T, variant, monkeypatch):
     from avex_amd import kernels as K
+    monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", variant)
     B, H = 2, 12
     E = H * 64
     qkv = round_half(synth.normal(f"qkv{T}", (B * T, 3 * E), 1.0), dtype)
@@ -197,6 +199,53 @@ def test_attention_key_padding_and_plain_bias(built_lib):
     out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), None, None, None,
                       key_pad=_dev(pad.astype(np.uint8), torch.uint8))
     ref = _attention_ref(qkv, B, T, H, table, None, None, None, key_pad=pad)
+    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("T,grid", [(496, 7), (200, 5), (300, 60), (512, 1)])
+def test_attention_persistent_items(built_lib, T, grid, variant, monkeypatch):
+    """The persistent attention (variant 2) walks several (head, clip) items per workgroup: ranges that cross a head
+    seam, a ragged last workgroup, per-clip key padding, one- and two-half key ranges.  Variant 1 runs the same cases."""
+    from avex_amd import kernels as K
+    monkeypatch.setenv("AVEX_AMD_ATT_GRID", str(grid))
+    monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", variant)
+    B, H = 5, 12
+    E = H * 64
+    qkv = round_half(synth.normal(f"qkvp{T}", (B * T, 3 * E), 1.0), "f16")
+    table = synth.normal("rel", (320, H), 0.5)
+    gw = synth.normal("gw", (8, 64), 0.1); gb = synth.normal("gb", (8,), 0.1); ga = 1.0 + synth.normal("ga", (H,), 0.2)
+    tab = _toeplitz(table, T, 320, 800)
+    pad = np.zeros((B, T), bool); pad[1, T // 3:] = True; pad[3, T - 5:] = True; pad[4, :40] = True   # incl. a masked FIRST key tile
+    out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), _dev(gw), _dev(gb), _dev(ga),
+                      key_pad=_dev(pad.astype(np.uint8), torch.uint8))
+    ref = _attention_ref(qkv, B, T, H, table, gw, gb, ga, key_pad=pad)
+    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+    out2 = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), _dev(gw), _dev(gb), _dev(ga))
+    ref2 = _attention_ref(qkv, B, T, H, table, gw, gb, ga)
+    assert rel_l2(out2.float().cpu().numpy(), ref2) < 1.5e-3
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_attention_large_logits(built_lib, variant, monkeypatch):
+    """Row maxima that keep growing along the keys exercise the deferred-maximum rescale of variant 2 (the branch is
+    data dependent and rare on gaussian scores): q.k grows with the key index, so every tile moves the reference."""
+    from avex_amd import kernels as K
+    monkeypatch.setenv("AVEX_AMD_ATT_GRID", "3")
+    monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", variant)
+    B, H, T = 2, 12, 496
+    E = H * 64
+    rng = np.random.default_rng(5)
+    qkv = synth.normal("qkvbig", (B * T, 3 * E), 1.0).reshape(B, T, 3, H, 64)
+    ramp = (np.arange(T, dtype=np.float32) / T)[None, :, None, None]
+    qkv[:, :, 0] = 3.0 + 0.3 * qkv[:, :, 0]                       # q ~ 3
+    qkv[:, :, 1] = 3.0 * ramp * (1.0 + 0.1 * qkv[:, :, 1])        # k grows along the sequence: logits up to ~ 70 (log2 ~ 100)
+    qkv = round_half(qkv.reshape(B * T, 3 * E), "f16")
+    table = synth.normal("rel", (320, H), 0.5)
+    tab = _toeplitz(table, T, 320, 800)
+    out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), None, None, None)
+    ref = _attention_ref(qkv, B, T, H, table, None, None, None)
+    assert np.isfinite(out.float().cpu().numpy()).all()
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
 
 
