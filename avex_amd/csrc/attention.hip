@@ -278,6 +278,15 @@ constexpr float A2_THR = 8.f;
 #define ATT_STAMPS 0     // diagnostic build: -DATT_STAMPS=1 prints one tile's cycle stamps (AVEX_AMD_ATT_DEBUG=4)
 #endif                             // deferred-max threshold, log2 units (p <= 256)
 
+// One LDS-DMA wave instruction (64 lanes x 16 B -> 1 KiB of LDS at a wave-uniform base), written as inline assembly on
+// purpose: behind a __builtin_amdgcn_global_load_lds the compiler puts an s_waitcnt vmcnt(0) in front of every later LDS
+// read it cannot prove disjoint (here: all of them), which stalls the first key tile of each phase until the whole next
+// buffer has landed and undoes the overlap.  The kernel orders DMA and reads itself (explicit vmcnt + barrier per phase).
+static __device__ __forceinline__ void a2_dma16(const void* src, const char* lds_dst) {
+    const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block,
                                                         const float* __restrict__ bias_tab,
@@ -331,11 +340,11 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             int key = half_ld * 256 + kl;
             key = key < Tn ? key : Tn - 1;                                 // clamped rows are masked by kadd
             const int chunk = (lane & 7) ^ ((kl >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((a_gptr_t*)(base + (int64_t)key * ld + E + chunk * 8), (a_lptr_t*)(buf + ri * 1024), 16, 0, 0);
+            a2_dma16(base + (int64_t)key * ld + E + chunk * 8, buf + ri * 1024);
             int vkey = half_ld * 256 + 8 * ri + ((lane >> 2) & 7);
             vkey = vkey < Tn ? vkey : Tn - 1;
             const int ch = 4 * (lane >> 5) + (lane & 3);
-            __builtin_amdgcn_global_load_lds((a_gptr_t*)(base + (int64_t)vkey * ld + 2 * E + ch * 8), (a_lptr_t*)(buf + A2_KBUF + ri * 1024), 16, 0, 0);
+            a2_dma16(base + (int64_t)vkey * ld + 2 * E + ch * 8, buf + A2_KBUF + ri * 1024);
         }
         if (++half_ld == nh) { half_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } }
     };
@@ -432,7 +441,6 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         AVX_PT(1)
         __builtin_amdgcn_s_barrier();
         AVX_PT(2)
-        if (ph + 1 < np && dbg != 3) issue_next(ph + 1);
         AVX_PT(3)
         if (half == 0) {
             if (h_cur != h_tab) {                        // workgroup-uniform
@@ -479,6 +487,13 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 }
             }
         }
+        // Every global load of the setup above (bias row, key mask) and the item's Q fragment (8 loads issued at the end of the
+        // previous item) complete HERE, before the DMA goes out: after it a compiler-placed vmcnt wait would wait for the DMA
+        // as well.  Passing qf through the statement makes this the definition the tiles see, in every phase, so no wait
+        // for those loads is placed inside the tiles.  From here to the next boundary a phase touches only LDS and registers.
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]));
+        if (ph + 1 < np && dbg != 3) issue_next(ph + 1);
         AVX_PT(4)
         if (has_q) {
             const char* Kb = smem + (ph & 1) * A2_HALF;
