@@ -8,7 +8,7 @@
 // One 512-thread workgroup per (clip, group): the group's slab (zero-padded, 96-byte rows — the
 // 16x16x32 fragment reads are bank-conflict free at that stride) is staged in LDS once; each wave
 // owns 64 tokens x 48 channels = 12 accumulators.  The MFMA "A" operand is the WEIGHT fragment
-// (rows = output channel, streamed from L2 with a register double buffer), the "B" operand the slab
+// (rows = output channel, read from a two-stage LDS ring that LDS-DMA fills one tap pair ahead), the "B" operand the slab
 // fragment, so each lane ends with 4 consecutive channels of one token and the epilogue
 // (bias, exact GELU, residual add) is float4 traffic.  K is ordered (tap, c) with c fastest: 48 is a
 // multiple of 8, so an 8-element operand fragment never straddles a tap and is one 16-byte LDS read;
@@ -24,17 +24,43 @@ constexpr int TMAX = 512;
 constexpr int SLAB_ROWS = TMAX + KT;              // 640
 constexpr int SLAB_BYTES = SLAB_ROWS * CG * 2;    // 61440
 constexpr int KTOT = KT * CG;                     // 6144
+constexpr int NU = KT / 2;                        // tap pairs: 96 = 3 x 32 k-values each
+constexpr int WST = CG * 96 * 2;                  // 9216 bytes of weights per tap pair and group
+constexpr int PC_LDS = SLAB_BYTES + 2 * WST;      // 79872: two workgroups per CU
 
+// One LDS-DMA wave instruction, as inline assembly (see attention.hip: behind the builtin the compiler would wait for the
+// DMA in front of every later LDS read; this kernel orders them itself with one vmcnt + barrier per tap pair).
+static __device__ __forceinline__ void pc_dma16(const void* src, const char* lds_dst) {
+    const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+}
+
+// Weights arrive packed [g][u][v][g4][o][8] (u = tap pair, v = 32-wide chunk of its 96 k-values, g4 = 8-element piece,
+// o = output channel): the 9216 bytes of (g, u) are contiguous, nine LDS-DMA instructions copy them into a two-stage ring
+// one tap pair ahead of the MFMAs, and the A fragment of lane (o & 15, g4) is one conflict-free 16-byte LDS read.  The
+// first version of this kernel had every wave pull the group's whole 590 KB of weights from L2 into registers (8 x per
+// workgroup, 19 GB per 256-clip step); now a workgroup reads them once, two workgroups share a CU and hide each other's
+// barriers.
 template <typename T>
-__global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf,
-                                                      const T* __restrict__ wp, const float* __restrict__ bias,
-                                                      int Tn, int E, int G, float* __restrict__ out,
-                                                      T* __restrict__ out_h) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, const T* __restrict__ wp,
+                    const float* __restrict__ bias, int Tn, int E, int G, float* __restrict__ out, T* __restrict__ out_h) {
     extern __shared__ __attribute__((aligned(16))) char slab[];
     typedef typename Half<T>::v8 v8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* wring = slab + SLAB_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x % G, b = blockIdx.x / G;
     const T* xg = xh + (int64_t)b * Tn * E + g * CG;
+    const char* wg = (const char*)(wp + (int64_t)g * CG * KTOT);      // this group's 64 x 9216 bytes
+
+    auto issue_w = [&](int u) __attribute__((always_inline)) {         // nine 1 KiB pieces: one per wave, the ninth rotates
+        const char* src = wg + (int64_t)u * WST;
+        char* dst = wring + (u & 1) * WST;
+        pc_dma16(src + wave * 1024 + lane * 16, dst + wave * 1024);
+        if (wave == (u & 7)) pc_dma16(src + 8 * 1024 + lane * 16, dst + 8 * 1024);
+    };
+    issue_w(0);
 
     // ---- stage the zero-padded slab: slab row r <-> token r - 64 -------------------------------
     for (int idx = tid; idx < SLAB_ROWS * 6; idx += 512) {
@@ -44,11 +70,12 @@ __global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, 
         if (t >= 0 && t < Tn) v = *(const uint4*)(xg + (int64_t)t * E + c * 8);
         *(uint4*)(slab + r * (CG * 2) + c * 16) = v;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int t16 = lane & 15, g4 = lane >> 4;
     const int tw0 = wave * 64;
-    if (tw0 >= Tn) return;  // whole wave beyond the sequence (no further barriers below)
+    const bool has_work = tw0 < Tn;     // wave-uniform; idle waves still copy weights and join the barriers
 
     // per-lane constants for the three chunks of a tap pair
     int xoff[3];
@@ -58,8 +85,7 @@ __global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, 
         xoff[v] = (off / CG) * (CG * 2) + (off % CG) * 2;
     }
     const char* xbase = slab + (tw0 + t16) * (CG * 2);
-    // weight rows: group g, out channel ot*16 + t16(lane&15 = row of A operand)
-    const T* wbase = wp + ((int64_t)g * CG + t16) * KTOT + 8 * g4;
+    const int woff = (g4 * CG + t16) * 16;                              // + (v * 4 * CG + ot * 16) * 16
 
     f32x4 acc[3][4];
 #pragma unroll
@@ -67,36 +93,28 @@ __global__ __launch_bounds__(512) void posconv_kernel(const T* __restrict__ xh, 
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[ot][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    v8 wcur[3][3], wnext[3][3];
+    for (int u = 0; u < NU; ++u) {
+        if (u + 1 < NU) issue_w(u + 1);          // the other stage: every wave left it before the last barrier
+        if (has_work) {
+            const char* xu = xbase + u * (2 * CG * 2);
+            const char* ws = wring + (u & 1) * WST + woff;
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
+            for (int v = 0; v < 3; ++v) {
+                v8 xfr[4], wf[3];
 #pragma unroll
-        for (int ot = 0; ot < 3; ++ot) wcur[v][ot] = *(const v8*)(wbase + (int64_t)ot * 16 * KTOT + 32 * v);
-
-    for (int u = 0; u < KT / 2; ++u) {
-        if (u + 1 < KT / 2) {
+                for (int ot = 0; ot < 3; ++ot) wf[ot] = *(const v8*)(ws + (v * 4 * CG + ot * 16) * 16);
 #pragma unroll
-            for (int v = 0; v < 3; ++v)
+                for (int tt = 0; tt < 4; ++tt) xfr[tt] = *(const v8*)(xu + tt * 16 * (CG * 2) + xoff[v]);
 #pragma unroll
                 for (int ot = 0; ot < 3; ++ot)
-                    wnext[v][ot] = *(const v8*)(wbase + (int64_t)ot * 16 * KTOT + 96 * (u + 1) + 32 * v);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[ot][tt] = mfma16(wf[ot], xfr[tt], acc[ot][tt]);
+            }
         }
-        const char* xu = xbase + u * (2 * CG * 2);
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            v8 xfr[4];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) xfr[tt] = *(const v8*)(xu + tt * 16 * (CG * 2) + xoff[v]);
-#pragma unroll
-            for (int ot = 0; ot < 3; ++ot)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[ot][tt] = mfma16(wcur[v][ot], xfr[tt], acc[ot][tt]);
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-#pragma unroll
-            for (int ot = 0; ot < 3; ++ot) wcur[v][ot] = wnext[v][ot];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // tap pair u + 1 has landed; reads of u are done
+        __builtin_amdgcn_s_barrier();
     }
+    if (!has_work) return;
 
     // ---- epilogue: + bias, exact GELU, + residual (backbone.py:68,174) --------------------------
 #pragma unroll
@@ -144,7 +162,8 @@ __global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restri
     if (threadIdx.x == 0) norm[k] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
 }
 
-// out[g][o][tap][c] = half( v[g*cg+o][c][tap] * (gk[tap] / norm[tap]) )
+// out[g][u][v][g4][o][e] = half( v[g*cg+o][c][tap] * (gk[tap] / norm[tap]) ) with tap*cg + c = 96 u + 32 v + 8 g4 + e
+// (the order posconv_kernel's LDS-DMA ring and A-fragment reads want; cg = 48)
 template <typename T>
 __global__ void posconv_pack_kernel(const float* __restrict__ v, const float* __restrict__ gk,
                                     const float* __restrict__ norm, int E, int cg, int K, T* __restrict__ out) {
@@ -155,7 +174,10 @@ __global__ void posconv_pack_kernel(const float* __restrict__ v, const float* __
     const int tap = (int)((i / cg) % K);
     const int64_t o = i / ((int64_t)cg * K);  // global out channel = g*cg + o_local
     const float w = v[(o * cg + c) * K + tap] * (gk[tap] / norm[tap]);
-    out[i] = Half<T>::from(w);
+    const int k = tap * cg + c, u = k / 96, rem = k - 96 * u, cv = rem >> 5, g4 = (rem >> 3) & 3, e = rem & 7;
+    const int64_t grp = o / cg, ol = o - grp * cg;
+    const int nu = cg * K / 96;
+    out[(((((grp * nu + u) * 3 + cv) * 4 + g4) * cg + ol) << 3) + e] = Half<T>::from(w);
 }
 
 }  // namespace
@@ -194,13 +216,13 @@ int posconv(const void* x_half, const float* x_f32, const void* w_packed, const 
     AVX_REQUIRE(B > 0 && T > 0 && T <= TMAX, "posconv: T=%d tokens unsupported (1..%d)", T, TMAX);
     if (dtype == AVEXHIP_BF16) {
         static bool set = false;
-        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES)); set = true; }
-        hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * groups), dim3(512), SLAB_BYTES, s, (const __bf16*)x_half, x_f32,
+        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS)); set = true; }
+        hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * groups), dim3(512), PC_LDS, s, (const __bf16*)x_half, x_f32,
                            (const __bf16*)w_packed, bias, T, E, groups, out, (__bf16*)out_half);
     } else if (dtype == AVEXHIP_F16) {
         static bool set = false;
-        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES)); set = true; }
-        hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * groups), dim3(512), SLAB_BYTES, s, (const _Float16*)x_half, x_f32,
+        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS)); set = true; }
+        hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * groups), dim3(512), PC_LDS, s, (const _Float16*)x_half, x_f32,
                            (const _Float16*)w_packed, bias, T, E, groups, out, (_Float16*)out_half);
     } else {
         avexhip_set_error("posconv: unknown dtype %d", dtype);

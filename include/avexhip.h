@@ -123,8 +123,9 @@ int avexhip_attention(const void* qkv_dev, int B, int T, int H, const float* bia
  * pad=64,groups=16) + drop-last + GELU, fused with the residual add:
  *   out[b,t,:] = x[b,t,:] + gelu(conv(x_half)[b,t,:] + bias)     (x = x_f32 if given, else x_half;
  *   out_f32 and/or out_half receive the result)
- * w_packed: [G][E/G out][128 taps][E/G in] half, weight-norm already folded (see
- * avexhip_posconv_pack).  Only E/G == 48, K == 128 is built. */
+ * w_packed: E*E/G*K halves, weight-norm already folded, in the kernel's own order [G][64 tap pairs][3][4][48 out][8]
+ * (k = tap*48 + c_in = 96 u + 32 v + 8 g4 + e), produced by avexhip_posconv_pack and opaque to callers.
+ * Only E/G == 48, K == 128 is built. */
 int avexhip_posconv_pack(const float* g_dev, const float* v_dev, int E, int groups, int K,
                          void* w_packed_dev, int dtype, void* stream);
 int avexhip_posconv(const void* x_half_dev, const float* x_f32_dev, const void* w_packed_dev,

@@ -259,13 +259,15 @@ def test_posconv(built_lib, dtype, T):
     g = (np.sqrt((v.astype(np.float64) ** 2).sum((0, 1), keepdims=True)) * (1.0 + synth.normal("pcg", (1, 1, Kt), 0.1))).astype(np.float32)
     bias = synth.normal("pcb", (E,), 0.05)
     wp = K.posconv_pack(_dev(g), _dev(v), G, dtype)
-    # packed layout [g][o][tap][c] and folded weight-norm
+    # packed layout [g][u][v][g4][o][8] (k = tap * 48 + c = 96 u + 32 v + 8 g4 + e) and folded weight-norm
     w = O.pos_conv_weight(g, v)
-    wp_ref = w.reshape(G, E // G, E // G, Kt).transpose(0, 1, 3, 2).reshape(-1)
-    assert rel_l2(wp.float().cpu().numpy(), wp_ref) < (6e-4 if dtype == "f16" else 4e-3)
+    cg = E // G
+    unpack = lambda a: a.reshape(G, Kt * cg // 96, 3, 4, cg, 8).transpose(0, 4, 1, 2, 3, 5).reshape(G, cg, Kt, cg)   # -> [g][o][tap][c]
+    wp_ref = w.reshape(G, cg, cg, Kt).transpose(0, 1, 3, 2)
+    assert rel_l2(unpack(wp.float().cpu().numpy()), wp_ref) < (6e-4 if dtype == "f16" else 4e-3)
     xh = round_half(x, dtype)
     out = K.posconv(_dev(xh, _tdt(dtype)), _dev(x), wp, _dev(bias), G, Kt).cpu().numpy()
-    wq = wp.float().cpu().numpy().reshape(G, E // G, Kt, E // G).transpose(0, 1, 3, 2).reshape(E, E // G, Kt)
+    wq = unpack(wp.float().cpu().numpy()).transpose(0, 1, 3, 2).reshape(E, cg, Kt)
     conv = O.pos_conv(xh, wq, bias.astype(np.float32), G)
     assert rel_l2(out - x, conv) < 2e-5       # same rounded operands: fp32 accumulation order only
     assert out.shape == (B, T, E)
