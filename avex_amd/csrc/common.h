@@ -61,41 +61,51 @@ static __device__ __forceinline__ float fast_erf(float x) {
     const float r = __builtin_fmaf(-p, __expf(-(ax * ax)), 1.0f);
     return __builtin_copysignf(r, x);
 }
-// gelu(x) = x * Phi(x) = 0.5 x + |x| (0.5 - q),  q = 0.5 * poly(t) * exp(-x^2/2),  t = 1/(1 + p |x|/sqrt2)
-// (same A-S 7.1.26 polynomial with the 0.5 and the 1/sqrt2 folded into the constants; explicit FMAs
-// because the library is built with -ffp-contract=off)
+// Exact-erf GELU with ONE transcendental per element:
+//   gelu(x) = x Phi(x) = 0.5 x + |x| (0.5 - q(|x|)),   q(a) = Phi(-a) = 0.5 erfc(a / sqrt2) = 2^P(a)
+// P is a degree-6 polynomial fitted to log2 q on [0, 5.7] with the error weighted by a * q (what reaches the output);
+// beyond 5.7 the argument is clamped (a * q < 4e-8 there).  |gelu - exact| <= 3.5e-7 over [-10, 10] in fp32 (the A-S 7.1.26
+// form this replaces: 2.1e-7, with a v_rcp_f32 and a v_exp_f32 per element; v_exp/v_rcp cost two VALU slots each).
+// Explicit FMAs because the library is built with -ffp-contract=off.
+#define AVX_GELU_A 5.7f
+#define AVX_GELU_C0 -0.999993085861206f
+#define AVX_GELU_C1 -1.1512017250061035f
+#define AVX_GELU_C2 -0.4587709605693817f
+#define AVX_GELU_C3 -0.05341210588812828f
+#define AVX_GELU_C4 0.00808071717619896f
+#define AVX_GELU_C5 -0.0007692198269069195f
+#define AVX_GELU_C6 3.309283420094289e-05f
 static __device__ __forceinline__ float gelu_erf(float x) {
     const float ax = __builtin_fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float p = 0.5f * 1.061405429f;
-    p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
-    p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
-    p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
-    p = p * t;
-    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
-    const float u = __builtin_fmaf(-p, e, 0.5f);
+    const float a = __builtin_fminf(ax, AVX_GELU_A);
+    float p = AVX_GELU_C6;
+    p = __builtin_fmaf(p, a, AVX_GELU_C5);
+    p = __builtin_fmaf(p, a, AVX_GELU_C4);
+    p = __builtin_fmaf(p, a, AVX_GELU_C3);
+    p = __builtin_fmaf(p, a, AVX_GELU_C2);
+    p = __builtin_fmaf(p, a, AVX_GELU_C1);
+    p = __builtin_fmaf(p, a, AVX_GELU_C0);
+    const float u = 0.5f - __builtin_amdgcn_exp2f(p);
     return __builtin_fmaf(ax, u, 0.5f * x);
 }
 
-// Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two fp32 lanes per VALU slot):
-// 8 instruction slots per element instead of 14; used by the GEMM / pos-conv epilogues (no MFMA runs beside them).
+// Two elements at a time on the packed-fp32 pipe (v_pk_fma_f32: two fp32 lanes per VALU slot); used by the GEMM / pos-conv
+// epilogues (no MFMA runs beside them).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-    const f32x2 ax = __builtin_elementwise_abs(x);
-    const f32x2 den = __builtin_elementwise_fma(ax, (f32x2)(0.3275911f * 0.70710678118654752440f), (f32x2)(1.0f));
-    f32x2 t;
-    t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
-    f32x2 p = (f32x2)(0.5f * 1.061405429f);
-    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * -1.453152027f));
-    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * 1.421413741f));
-    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * -0.284496736f));
-    p = __builtin_elementwise_fma(p, t, (f32x2)(0.5f * 0.254829592f));
-    p = p * t;
-    const f32x2 xx = x * x * (f32x2)(-0.5f * 1.4426950408889634f);
-    f32x2 e;
-    e[0] = __builtin_amdgcn_exp2f(xx[0]); e[1] = __builtin_amdgcn_exp2f(xx[1]);
-    const f32x2 u = __builtin_elementwise_fma(-p, e, (f32x2)(0.5f));
+    f32x2 ax, a;
+    ax[0] = __builtin_fabsf(x[0]); ax[1] = __builtin_fabsf(x[1]);
+    a[0] = __builtin_fminf(ax[0], AVX_GELU_A); a[1] = __builtin_fminf(ax[1], AVX_GELU_A);
+    f32x2 p = (f32x2)(AVX_GELU_C6);
+    p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELU_C5));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELU_C4));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELU_C3));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELU_C2));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELU_C1));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELU_C0));
+    f32x2 q;
+    q[0] = __builtin_amdgcn_exp2f(p[0]); q[1] = __builtin_amdgcn_exp2f(p[1]);
+    const f32x2 u = (f32x2)(0.5f) - q;
     return __builtin_elementwise_fma(ax, u, x * (f32x2)(0.5f));
 }
 static __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
