@@ -214,7 +214,8 @@ struct FbankDev {
 };
 // out_f32: [B, frames, n_mels] or NULL; out_patch: half patch-major [B, frames/P, n_mels/P, P*P] or NULL
 int fbank(const FbankDev& fb, const float* wav, int B, int64_t T, int64_t stride, int frames,
-          float* out_f32, void* out_patch, int patch, int dtype, hipStream_t s);
+          float* out_f32, void* out_patch, int patch, int dtype, hipStream_t s, const float* clip_offset = nullptr,
+          int out_frames = 0);
 // fbank [B, frames, n_mels] fp32 -> half patch-major (used by forward_fbank)
 int patchify(const float* fbank, int B, int frames, int n_mels, int patch, void* out_patch, int dtype,
              hipStream_t s);

@@ -51,7 +51,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const float* __restrict__ wav,
                                                     int64_t stride, int frames,
                                                     float* __restrict__ out_f32, T* __restrict__ out_patch,
-                                                    int P) {
+                                                    int P, const float* __restrict__ clip_offset, int out_frames) {
     __shared__ float2 zbuf[4][8 * ZROW];
     __shared__ float pw[4][2][264];
     __shared__ float2 tw[512];   // twiddle table staged once per block (pass 1 and 2 gather from it)
@@ -73,13 +73,14 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
         float cur[8], prev[8];
         float s = 0.f;
         const float* src = wav + (int64_t)b * stride + (int64_t)(f0 + fr) * fb.hop;
+        const float coff = clip_offset ? clip_offset[b] : 0.f;   // EAT: mono - mono.mean() (eat/audio_processor.py:107)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = lane + 64 * q;
             cur[q] = 0.f; prev[q] = 0.f;
             if (valid[fr] && n < fb.win) {
-                cur[q] = src[n] * fb.input_scale;
-                prev[q] = src[n > 0 ? n - 1 : 0] * fb.input_scale;
+                cur[q] = (src[n] - coff) * fb.input_scale;
+                prev[q] = (src[n > 0 ? n - 1 : 0] - coff) * fb.input_scale;
                 s += cur[q];
             }
         }
@@ -143,17 +144,22 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
 
     // ---- mel, log, affine (beats.py:159-163,323) -----------------------------------------------
     const int nm = fb.n_mels;
-    const int nt = frames / P, nf = nm / P;
+    const int nt = out_frames / P, nf = nm / P;
     for (int o = lane; o < 2 * nm; o += 64) {
         const int fr = o >= nm ? 1 : 0;
         const int m = o - fr * nm;
         const int f = f0 + fr;
-        if (f >= frames) continue;
-        const int st = fb.mel_start[m], len = fb.mel_len[m], off = fb.mel_off[m];
-        float e = 0.f;
-        for (int t = 0; t < len; ++t) e += pw[wave][fr][st + t] * fb.mel_w[off + t];
-        const float y = (logf(fmaxf(e, fb.log_floor)) - fb.norm_mean) / fb.norm_div;
-        if (out_f32) out_f32[((int64_t)b * frames + f) * nm + m] = y;
+        if (f >= out_frames) continue;
+        float y;
+        if (f < frames) {
+            const int st = fb.mel_start[m], len = fb.mel_len[m], off = fb.mel_off[m];
+            float e = 0.f;
+            for (int t = 0; t < len; ++t) e += pw[wave][fr][st + t] * fb.mel_w[off + t];
+            y = (logf(fmaxf(e, fb.log_floor)) - fb.norm_mean) / fb.norm_div;
+        } else {
+            y = (0.f - fb.norm_mean) / fb.norm_div;      // zero-padded log-mel rows, normalised like the rest (audio_processor.py:121-135)
+        }
+        if (out_f32) out_f32[((int64_t)b * out_frames + f) * nm + m] = y;
         if (out_patch) {
             const int tp = f / P;
             if (tp < nt && m < nf * P) {
@@ -164,23 +170,41 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     }
 }
 
+// mean[b] = mean(wav[b, :T]) (fp32; block tree sum): the EAT frontend's per-clip DC removal (eat/audio_processor.py:107)
+__global__ __launch_bounds__(1024) void clip_mean_kernel(const float* __restrict__ wav, int64_t T, int64_t stride, float* __restrict__ mean) {
+    __shared__ float red[16];
+    const float* src = wav + (int64_t)blockIdx.x * stride;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < T; i += 1024) s += src[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if (threadIdx.x == 0) mean[blockIdx.x] = v / (float)T;
+    }
+}
+
 }  // namespace
 
 namespace avx {
 
 int fbank(const FbankDev& fb, const float* wav, int B, int64_t T, int64_t stride, int frames,
-          float* out_f32, void* out_patch, int patch, int dtype, hipStream_t s) {
+          float* out_f32, void* out_patch, int patch, int dtype, hipStream_t s, const float* clip_offset, int out_frames) {
     AVX_REQUIRE(wav && B > 0, "fbank: bad arguments");
     AVX_REQUIRE(fb.win > 0 && fb.win <= 512 && fb.hop > 0, "fbank: win_length=%d must be in 1..512", fb.win);
     AVX_REQUIRE(out_f32 || out_patch, "fbank: no output");
     AVX_REQUIRE(stride >= T, "fbank: wav_stride < T");
-    if (frames <= 0) return AVEXHIP_OK;
+    if (out_frames <= 0) out_frames = frames;      // output rows per clip: rows >= frames are padding, rows >= out_frames are cut
+    if (frames > out_frames) frames = out_frames;
+    if (out_frames <= 0) return AVEXHIP_OK;
     if (patch <= 0) patch = 16;
-    const dim3 grid(((frames + 1) / 2 + 3) / 4, B);
+    const dim3 grid(((out_frames + 1) / 2 + 3) / 4, B);
     if (dtype == AVEXHIP_BF16)
-        hipLaunchKernelGGL(fbank_kernel<__bf16>, grid, dim3(256), 0, s, fb, wav, stride, frames, out_f32, (__bf16*)out_patch, patch);
+        hipLaunchKernelGGL(fbank_kernel<__bf16>, grid, dim3(256), 0, s, fb, wav, stride, frames, out_f32, (__bf16*)out_patch, patch, clip_offset, out_frames);
     else
-        hipLaunchKernelGGL(fbank_kernel<_Float16>, grid, dim3(256), 0, s, fb, wav, stride, frames, out_f32, (_Float16*)out_patch, patch);
+        hipLaunchKernelGGL(fbank_kernel<_Float16>, grid, dim3(256), 0, s, fb, wav, stride, frames, out_f32, (_Float16*)out_patch, patch, clip_offset, out_frames);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
@@ -296,3 +320,24 @@ extern "C" int avexhip_fbank_forward(const avexhip_fbank_plan* plan, const float
     return avx::fbank(plan->dev, wav_dev, B, T, wav_stride, frames, out_dev, nullptr, 16, AVEXHIP_F16,
                       (hipStream_t)stream);
 }
+
+extern "C" int avexhip_clip_mean(const float* wav_dev, int B, int64_t T, int64_t wav_stride, float* mean_dev, void* stream) {
+    AVX_REQUIRE(wav_dev && mean_dev, "clip_mean: null argument");
+    AVX_REQUIRE(B > 0 && T > 0, "clip_mean: empty input B=%d T=%lld", B, (long long)T);
+    if (wav_stride <= 0) wav_stride = T;
+    hipLaunchKernelGGL(clip_mean_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, wav_dev, T, wav_stride, mean_dev);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+extern "C" int avexhip_fbank_forward_padded(const avexhip_fbank_plan* plan, const float* wav_dev, int B, int64_t T,
+                                            int64_t wav_stride, const float* clip_offset_dev, int out_frames, float* out_dev,
+                                            void* stream) {
+    AVX_REQUIRE(plan && wav_dev && out_dev, "fbank_forward_padded: null argument");
+    AVX_REQUIRE(B > 0 && T > 0 && out_frames > 0, "fbank_forward_padded: empty input B=%d T=%lld out_frames=%d", B, (long long)T, out_frames);
+    if (wav_stride <= 0) wav_stride = T;
+    const int frames = avexhip_fbank_num_frames(plan, T);
+    return avx::fbank(plan->dev, wav_dev, B, T, wav_stride, frames, out_dev, nullptr, 16, AVEXHIP_F16, (hipStream_t)stream,
+                      clip_offset_dev, out_frames);
+}
+

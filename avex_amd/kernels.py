@@ -108,6 +108,28 @@ class FbankPlan:
         check(lib().avexhip_fbank_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(out), _stream()), "fbank_forward")
         return out
 
+    def padded(self, wav: torch.Tensor, out_frames: int, remove_clip_mean: bool = False) -> torch.Tensor:
+        """``[B, T]`` -> ``[B, out_frames, n_mels]``: rows past the last frame hold the normalised zero padding, frames past
+        ``out_frames`` are cut; ``remove_clip_mean`` subtracts each clip's mean at load (EAT, eat/audio_processor.py:107)."""
+        _need_cuda(wav)
+        if wav.dim() != 2 or wav.dtype != torch.float32:
+            raise ValueError("wav must be a [B, T] float32 tensor")
+        if out_frames <= 0:
+            raise ValueError("out_frames must be positive")
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, T = wav.shape
+        out = torch.empty((B, out_frames, self.n_mels), dtype=torch.float32, device=wav.device)
+        if B == 0:
+            return out
+        off = None
+        if remove_clip_mean:
+            off = torch.empty((B,), dtype=torch.float32, device=wav.device)
+            check(lib().avexhip_clip_mean(_ptr(wav), B, T, wav.stride(0), _ptr(off), _stream()), "clip_mean")
+        check(lib().avexhip_fbank_forward_padded(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(off) if off is not None else None,
+                                                 out_frames, _ptr(out), _stream()), "fbank_forward_padded")
+        return out
+
     def __del__(self) -> None:
         try:
             if getattr(self, "_h", None):

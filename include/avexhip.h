@@ -71,6 +71,14 @@ int avexhip_fbank_num_frames(const avexhip_fbank_plan* plan, int64_t T);
 /* wav_dev: [B, T] fp32 (row stride = wav_stride elements).  out_dev: [B, frames, n_mels] fp32. */
 int avexhip_fbank_forward(const avexhip_fbank_plan* plan, const float* wav_dev, int B, int64_t T,
                           int64_t wav_stride, float* out_dev, void* stream);
+/* EAT frontend (avex/models/eat/audio_processor.py:72-143): the same kernel with the per-clip offset `mono - mono.mean()`
+ * (:107) subtracted at load, and a fixed number of output rows per clip: rows past the last frame are the zero-padded
+ * log-mel rows AFTER normalisation, (0 - norm_mean) / norm_div (:121-135); frames past out_frames are cut.
+ * clip_offset_dev: [B] fp32 or NULL.  out_dev: [B, out_frames, n_mels] fp32. */
+int avexhip_clip_mean(const float* wav_dev, int B, int64_t T, int64_t wav_stride, float* mean_dev, void* stream);
+int avexhip_fbank_forward_padded(const avexhip_fbank_plan* plan, const float* wav_dev, int B, int64_t T,
+                                 int64_t wav_stride, const float* clip_offset_dev, int out_frames,
+                                 float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Building blocks (exported so every kernel can be parity-tested in isolation through the ABI).

@@ -101,6 +101,41 @@ def beats_preprocess(wav: np.ndarray, cfg: Mapping[str, object]) -> np.ndarray:
     return ((fb - mean) / (np.float32(2.0) * std)).astype(np.float32)
 
 
+def eat_preprocess(wav: np.ndarray, *, sample_rate: int = 16000, target_length: int = 1024, n_mels: int = 128,
+                   norm_mean: float = -4.268, norm_std: float = 4.569, frame_shift_ms: int = 10) -> np.ndarray:
+    """``EATAudioProcessor.__call__`` (avex/models/eat/audio_processor.py:72-143): per clip ``mono - mono.mean()`` (:107),
+    kaldi fbank with a Hann window, dither 0, NO 2**15 scale (:110-119; torchaudio.compliance.kaldi.fbank defaults: 25 ms
+    frames, pre-emphasis 0.97, per-frame DC removal, snip_edges, power-of-two FFT, low_freq 20, log of max(., fp32 eps)),
+    zero-pad / truncate to ``target_length`` frames (:121-126), ``(mel - norm_mean) / (2 norm_std)`` (:135), or per-sample
+    statistics when the constants are (0, 1) (:131-134).  Returns ``(B, target_length, n_mels)``.
+
+    PARITY UNPINNED against torchaudio itself: ``torchaudio`` (2.11.0 in the reference's uv.lock) is not installed in the
+    development container, so no golden of this function exists.  It is pinned transitively: ``fbank`` above is the same
+    kaldi algorithm (the reference's own ``_BatchedFbank`` is tested against torchaudio's, tests/unittests/test_batched_fbank.py)
+    and IS pinned by the reference goldens; this function only swaps the window and the scale around it."""
+    wav = np.asarray(wav, np.float32)
+    if wav.ndim == 1:
+        wav = wav[None]
+    hop = int(round(sample_rate * frame_shift_ms / 1000))
+    win = int(sample_rate * 25 / 1000)
+    out = []
+    for mono in wav:
+        mono = mono - mono.mean(dtype=np.float32)                                   # :107
+        mel = fbank(mono[None], n_mels=n_mels, win_length=win, hop_length=hop, window=hann_window(win))[0]
+        t = mel.shape[0]
+        if t < target_length:
+            mel = np.pad(mel, ((0, target_length - t), (0, 0)))                      # :123
+        else:
+            mel = mel[:target_length]                                               # :125
+        if norm_mean == 0.0 and norm_std == 1.0:
+            std = mel.std(ddof=1)
+            mel = (mel - mel.mean()) / ((std if std > 0 else 1.0) * 2)
+        else:
+            mel = (mel - np.float32(norm_mean)) / (np.float32(norm_std) * np.float32(2))   # :135
+        out.append(mel.astype(np.float32))
+    return np.stack(out, 0)
+
+
 # --------------------------------------------------------------------------------------
 # Encoder building blocks
 # --------------------------------------------------------------------------------------

@@ -28,6 +28,27 @@ def _tdt(name):
     return torch.float16 if name == "f16" else torch.bfloat16
 
 
+def test_eat_frontend_matches_oracle(built_lib):
+    """EAT frontend (eat/audio_processor.py:72-143) through the C ABI vs the NumPy restatement: clip-mean removal, Hann
+    window, no 2**15 scale, zero-padded rows after normalisation (5 s clip), truncation to 1024 frames (10.6 s clip)."""
+    from avex_amd.eat_audio_processor import EATAudioProcessor
+    proc = EATAudioProcessor()
+    assert proc.hop_length == 160 and proc.target_length == 1024
+    x = synth.noise_clips(3, 80000, seed=11) + np.float32(0.05)             # DC offset exercises mono - mono.mean()
+    y = proc(torch.from_numpy(x).cuda())
+    assert y.shape == (3, 1024, 128) and y.dtype == torch.float32 and y.is_cuda
+    ref = O.eat_preprocess(x)
+    assert np.abs(y.cpu().numpy() - ref).max() < 2e-4                       # log-mel / 9.1: same tolerance class as the BEATs frontend
+    pad = np.float32((0.0 + 4.268) / (2 * 4.569))
+    assert np.allclose(y[:, 498:].cpu().numpy(), pad, atol=1e-6)
+    long = synth.noise_clips(2, 170000, seed=12)
+    yl = proc(long)                                                         # numpy in -> tensor on the input's (CPU) device, like the reference
+    assert yl.shape == (2, 1024, 128) and not yl.is_cuda
+    assert np.abs(yl.numpy() - O.eat_preprocess(long)).max() < 2e-4
+    ps = EATAudioProcessor(norm_mean=0.0, norm_std=1.0)(torch.from_numpy(x).cuda()).cpu().numpy()   # per-sample statistics branch
+    assert np.abs(ps - O.eat_preprocess(x, norm_mean=0.0, norm_std=1.0)).max() < 2e-4
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_cast_roundtrip(built_lib, dtype):
     from avex_amd import kernels as K

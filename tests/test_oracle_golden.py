@@ -131,3 +131,31 @@ def test_base_aggregations_and_mask(base):
     tap0 = np.where(fpad[..., None], np.float32(0), taps["backbone.post_extract_proj"])
     e = np.concatenate([tap0.mean(1), taps["backbone.encoder.layers.11.fc2"].mean(1)], 1)
     assert rel_l2(e, g["mask.mean"]) < 1e-5
+
+
+def test_eat_frontend_oracle_known_answers():
+    """EAT frontend restatement (eat/audio_processor.py:72-143): shape contract, padded rows, truncation, and the two
+    invariances that follow from the kaldi per-frame DC removal (a clip offset and the clip-mean removal change nothing
+    beyond fp32 rounding).  torchaudio is absent here, so this function has no golden of its own (see its docstring)."""
+    from avex_amd import synth
+    x = synth.noise_clips(2, 80000, seed=3)                       # 5 s: 498 frames -> zero-padded to 1024
+    y = O.eat_preprocess(x)
+    assert y.shape == (2, 1024, 128) and y.dtype == np.float32
+    pad = (0.0 + 4.268) / (2 * 4.569)
+    assert np.allclose(y[:, 498:], pad, atol=1e-6) and not np.allclose(y[:, 497], pad, atol=1e-3)
+    # the valid rows are the pinned fbank with a Hann window, no 2**15 scale
+    ref = (O.fbank(x - x.mean(1, keepdims=True, dtype=np.float32), window=O.hann_window(400)) + 4.268) / (2 * 4.569)
+    assert np.allclose(y[:, :498], ref, atol=1e-5)
+    # the BEATs scale only shifts the log-mel by log((2**15)**2) wherever neither side sits on the fp32-eps floor
+    xc = x - x.mean(1, keepdims=True, dtype=np.float32)
+    plain, scaled = O.fbank(xc, window=O.hann_window(400)), O.fbank(xc * np.float32(2 ** 15), window=O.hann_window(400))
+    above = plain > np.log(O.F32_EPS) + 1.0
+    assert above.mean() > 0.9 and np.abs((scaled - 2 * np.log(2.0 ** 15)) - plain)[above].max() < 2e-3
+    # a DC offset is removed twice over
+    y_dc = O.eat_preprocess(x + np.float32(0.25))
+    assert np.abs(y_dc[:, :498] - y[:, :498]).max() < 5e-3
+    long = synth.noise_clips(1, 170000, seed=4)                   # 1060 frames -> cut to 1024
+    assert O.eat_preprocess(long).shape == (1, 1024, 128)
+    z = O.eat_preprocess(x, norm_mean=0.0, norm_std=1.0)          # per-sample statistics branch
+    assert abs(float(z[0].mean())) < 1e-5 and abs(float(z[0].std(ddof=1)) - 0.5) < 1e-4
+
