@@ -92,7 +92,11 @@ def main():
 
     from avex_amd import build, synth
     from avex_amd import kernels as K
-    build.build(verbose=False)
+    # the library is prebuilt in tree; if it is stale only rank 0 compiles, the others wait for it
+    if rank == 0:
+        build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
     cfg = synth.BEATS_BASE_CFG
     sd = synth.beats_state_dict(cfg, seed=0)
     enc = K.BeatsEncoder(cfg, sd, operand_dtype=args.dtype, max_chunk_clips=args.chunk, residual=args.residual)
