@@ -46,6 +46,9 @@ __device__ __forceinline__ void dft8(float2 (&x)[8]) {
 }
 
 constexpr int ZROW = 72;  // complex elements per LDS row (64 + 8 pad)
+// Every exchange buffer below is private to one wave, and a wave's LDS operations execute in order: the passes need no
+// workgroup barrier, only the compiler kept from moving LDS accesses across the exchange points.
+#define AVX_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <typename T>
 __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const float* __restrict__ wav,
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     for (int k1 = 1; k1 < 8; ++k1) x[k1] = cmul(x[k1], tw[lane * k1]);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) z[k1 * ZROW + lane] = x[k1];
-    __syncthreads();
+    AVX_WAVE_SYNC();
     {
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
@@ -111,21 +114,21 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
         dft8(x);
 #pragma unroll
         for (int j1 = 1; j1 < 8; ++j1) x[j1] = cmul(x[j1], tw[8 * m2 * j1]);
-        __syncthreads();
+        AVX_WAVE_SYNC();
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) z[k1 * ZROW + j1 * 8 + m2] = x[j1];
     }
-    __syncthreads();
+    AVX_WAVE_SYNC();
     {
         const int k1 = lane & 7, j1 = lane >> 3;
 #pragma unroll
         for (int m2 = 0; m2 < 8; ++m2) x[m2] = z[k1 * ZROW + j1 * 8 + m2];
         dft8(x);
-        __syncthreads();
+        AVX_WAVE_SYNC();
 #pragma unroll
         for (int j2 = 0; j2 < 8; ++j2) z[lane + 64 * j2] = x[j2];  // natural order Z[k]
     }
-    __syncthreads();
+    AVX_WAVE_SYNC();
 
     // ---- split the two real spectra, power (beats.py:154-155) ----------------------------------
 #pragma unroll
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
             pw[wave][1][k] = mb * mb;
         }
     }
-    __syncthreads();
+    AVX_WAVE_SYNC();
 
     // ---- mel, log, affine (beats.py:159-163,323) -----------------------------------------------
     const int nm = fb.n_mels;

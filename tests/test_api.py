@@ -188,3 +188,63 @@ def test_unsupported_variants_fail_loudly():
         avex_amd.beats_model.Model(device="cpu", init_config=dict(synth.BEATS_BASE_CFG, layer_norm_first=True, deep_norm=False))
     with pytest.raises(FileNotFoundError):
         avex_amd.beats_model.Model(device="cpu", pretrained=True)
+
+
+def test_extraction_loop_semantics_cpu():
+    """Harness counterpart (reference: evaluation/embedding_utils.py:26-144) with a stand-in model on the CPU: batch schema,
+    single tensor / list / dict returns, stacking order, embedding_dims, ValueError on an empty loader, hooks deregistered and
+    disable_layerdrop restored in `finally` even when a batch raises."""
+    import pytest
+    import torch
+    from avex_amd.extraction import extract_embeddings_in_memory
+
+    class Fake:
+        def __init__(self, mode):
+            self.mode, self.disable_layerdrop, self.registered, self.deregistered, self.calls = mode, False, None, 0, []
+
+        def register_hooks_for_layers(self, layers):
+            self.registered = list(layers)
+            return ["L0", "L1"][: len(layers)]
+
+        def deregister_all_hooks(self):
+            self.deregistered += 1
+
+        def extract_embeddings(self, x, aggregation="none"):
+            masked = isinstance(x, dict)
+            wav = x["raw_wav"] if masked else x
+            self.calls.append((masked, aggregation, self.disable_layerdrop))
+            base = wav.sum(dim=1, keepdim=True)
+            if self.mode == "tensor":
+                return base.repeat(1, 4)
+            if self.mode == "list":
+                return [base.repeat(1, 4), base.repeat(1, 3) * 2]
+            if self.mode == "dict":
+                return {"a": base.repeat(1, 2), "b": base.repeat(1, 5)}
+            raise RuntimeError("boom")
+
+    batches = [{"raw_wav": torch.full((2, 8), float(i + 1)), "padding_mask": torch.zeros(2, 8, dtype=torch.bool) if i % 2 else None,
+                "label": torch.tensor([i, i + 10])} for i in range(3)]
+    for b in batches:
+        if b["padding_mask"] is None:
+            del b["padding_mask"]
+    m = Fake("tensor")
+    emb, labels, dims = extract_embeddings_in_memory(m, batches, [0], "cpu", aggregation="mean", disable_layerdrop=True)
+    assert list(emb) == ["L0"] and emb["L0"].shape == (6, 4) and dims == [(4,)]
+    assert labels.tolist() == [0, 10, 1, 11, 2, 12]
+    assert emb["L0"][:, 0].tolist() == [8.0, 8.0, 16.0, 16.0, 24.0, 24.0]                 # batch order kept
+    assert [c[0] for c in m.calls] == [False, True, False] and all(c[1] == "mean" and c[2] is True for c in m.calls)
+    assert m.deregistered == 1 and m.disable_layerdrop is False and m.registered == [0]
+    m = Fake("list")
+    emb, _, dims = extract_embeddings_in_memory(m, batches, [0, -1], "cpu")
+    assert list(emb) == ["L0", "L1"] and dims == [(4,), (3,)]
+    m = Fake("dict")
+    emb, _, dims = extract_embeddings_in_memory(m, batches, ["all"], "cpu")
+    assert list(emb) == ["a", "b"] and dims == [(2,), (5,)]
+    m = Fake("tensor")
+    with pytest.raises(ValueError):
+        extract_embeddings_in_memory(m, [], [0], "cpu")
+    assert m.deregistered == 1
+    m = Fake("raise")
+    with pytest.raises(RuntimeError):
+        extract_embeddings_in_memory(m, batches, [0], "cpu", disable_layerdrop=True)
+    assert m.deregistered == 1 and m.disable_layerdrop is False

@@ -132,6 +132,31 @@ def test_frontend_namespace(g, golden_dir):
     assert torch.allclose(z, (y - 15.41663) / (2 * 6.55582), atol=2e-5)
 
 
+def test_extraction_loop_on_gpu(model, g):
+    """The harness loop (reference: embedding_utils.py:26-144) over a Collater-style loader with the real model: pinned/async
+    prefetch and the plain synchronous path give the same rows, in loader order, and the golden pooled embedding comes out."""
+    from avex_amd.extraction import extract_embeddings_in_memory
+    x = synth.noise_clips(4, 160000, seed=0)
+    pad = torch.zeros(2, 160000, dtype=torch.bool); pad[1, 80000:] = True
+    loader = [{"raw_wav": torch.from_numpy(x[:1]), "label": torch.tensor([7])},
+              {"raw_wav": torch.from_numpy(x[1:3]), "padding_mask": pad, "label": torch.tensor([1, 2])},
+              {"raw_wav": torch.from_numpy(x[3:4]), "label": torch.tensor([3])}]
+    a, la, dims = extract_embeddings_in_memory(model, loader, [0, -1], "cuda", aggregation="mean", prefetch=True)
+    b, lb, _ = extract_embeddings_in_memory(model, loader, [0, -1], "cuda", aggregation="mean", prefetch=False)
+    assert la.tolist() == lb.tolist() == [7, 1, 2, 3]
+    assert len(a) == 1 and dims == [(1536,)]                    # mean aggregation concatenates the two taps: one entry, like the reference
+    (name, ea), (_, eb) = next(iter(a.items())), next(iter(b.items()))
+    assert name == "backbone.post_extract_proj" and ea.shape == (4, 1536) and not ea.is_cuda
+    assert torch.equal(ea, eb)
+    model.register_hooks_for_layers([0, -1])
+    try:
+        row0 = model.extract_embeddings(torch.from_numpy(x[:1]), aggregation="mean").cpu()
+    finally:
+        model.deregister_all_hooks()
+    assert torch.equal(ea[:1], row0)
+    assert not model._hooks                                     # loop deregistered its hooks
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
