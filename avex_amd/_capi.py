@@ -32,7 +32,10 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int64), ("alpha", C.c_float),
                 ("resid_half", C.c_void_p), ("ldrh", C.c_int64), ("gelu", C.c_int32), ("out_f32", C.c_void_p), ("ldo", C.c_int64),
                 ("out_half", C.c_void_p), ("ldh", C.c_int64), ("out_raw", C.c_void_p), ("ldraw", C.c_int64),
-                ("variant", C.c_int32)]
+                ("variant", C.c_int32),
+                ("ln_stats", C.c_void_p), ("ln_nseg", C.c_int32), ("ln_eps", C.c_float), ("ln_s", C.c_void_p),
+                ("lnr_y", C.c_void_p), ("ldy", C.c_int64), ("lnr_stats", C.c_void_p), ("lnr_nseg", C.c_int32),
+                ("lnr_gamma", C.c_void_p), ("lnr_beta", C.c_void_p), ("stats_out", C.c_void_p)]
 
 
 class BeatsConfig(C.Structure):

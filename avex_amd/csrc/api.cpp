@@ -44,6 +44,10 @@ extern "C" int avexhip_cast_half_to_f32(const void* in, float* out, int64_t n, i
 extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream) {
     AVX_REQUIRE(a, "gemm: null args");
     avx::GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.ln_stats = a->ln_stats; g.ln_nseg = a->ln_nseg; g.ln_eps = a->ln_eps; g.ln_s = a->ln_s;
+    g.lnr_y = a->lnr_y; g.ldy = (int)a->ldy; g.lnr_stats = a->lnr_stats; g.lnr_nseg = a->lnr_nseg;
+    g.lnr_gamma = a->lnr_gamma; g.lnr_beta = a->lnr_beta; g.stats_out = a->stats_out;
     g.A = a->A; g.lda = a->lda; g.W = a->W; g.ldw = a->ldw;
     g.M = a->M; g.N = a->N; g.K = a->K;
     g.bias = a->bias; g.resid = a->resid; g.ldr = a->ldr; g.alpha = a->alpha; g.gelu = a->gelu;

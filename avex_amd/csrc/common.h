@@ -182,6 +182,24 @@ struct GemmArgs {
     float* out_raw; int64_t ldraw;
     const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to every output
     int variant;
+    // ---- LayerNorm folded into the GEMMs around it (256-tile kernel, variant 2 only) ---------------------------------
+    // A tensor y that is only ever consumed through LayerNorm is kept RAW in the operand type together with per-row
+    // partial statistics [M][nseg][2] = (sum, sum of squares) of each 64-column segment (written by the GEMM that produced y).
+    //  * consumer of LN(y) as its A operand:  A = y, W = W * diag(gamma) (folded by the caller), ln_s[n] = sum_k W'[n][k],
+    //    bias = b + W beta;  the epilogue forms  rstd[m] * (acc - mu[m] * ln_s[n]) + bias[n]  before GELU / rounding;
+    //  * consumer of LN(y) as its residual:  out = alpha * ((y - mu) * rstd * gamma + beta) + acc + bias;
+    //  * producer: stats_out receives the partial statistics of the rows it writes (from the ROUNDED outputs).
+    const float* ln_stats;    // consumer-as-A: statistics of the A rows, or NULL
+    int ln_nseg;              // segments per row (row width = 64 * ln_nseg)
+    float ln_eps;
+    const float* ln_s;        // [N]
+    const void* lnr_y;        // consumer-as-residual: raw residual rows (half), or NULL
+    int ldy;
+    const float* lnr_stats;   // [M][lnr_nseg][2]
+    int lnr_nseg;
+    const float* lnr_gamma;   // [N]
+    const float* lnr_beta;    // [N]
+    float* stats_out;         // [M][N/64][2] or NULL
     int stagger_ticks;        // variant 5: workgroups of odd slot start this many 10-ns ticks late (desynchronised epilogues)
     int stagger_groups;       // variant 5: number of start phases (>= 1)
 };

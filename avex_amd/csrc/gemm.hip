@@ -198,6 +198,8 @@ __device__ unsigned long long g_gemm_clk[2 * 8192];   // s_memtime (shader clock
 
 constexpr int T2 = 256;
 constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32 KiB)
+constexpr int LNS_OFF = 2 * STAGE2;        // (mu, rstd) of the tile's 256 rows: A-side statistics, then residual-side (2 x 2 KiB)
+constexpr int LDS2 = 2 * STAGE2 + 4096;
 
 #define AVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define AVX_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -231,7 +233,7 @@ constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32
 // layout, the wave's private slab holds the converted f16 values (half the LDS traffic of the fp32 transpose:
 // ds_write_b64 of 4 halves, ds_read_b128 of 8 halves per lane), and the loops carry no uniform branches so the
 // scheduler interleaves the 16 independent GELU chains of a 64-column slice (latency, not issue, bound otherwise).
-template <typename T, bool GELU>
+template <typename T, bool GELU, bool LNA>
 static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid, int wm,
                                                      int wn, int lane, int m0, int n0) {
     typedef typename Half<T>::v8 v8;
@@ -242,14 +244,28 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
     const int lc = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih) {
-        f32x4 bv[4];
+        f32x4 bv[4], sv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4*)(p.bias + n0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
+        if (LNA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = *(const f32x4*)(p.ln_s + n0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            // LayerNorm of the A rows folded in: rstd * (acc - mu * s[n]) + bias'  (mu, rstd of tile row 64 wn + 16 j + lc)
+            float2 st = make_float2(0.f, 1.f);
+            if (LNA) st = ((const float2*)(smem + LNS_OFF))[wn * 64 + 16 * j + lc];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                f32x4 v = acc[4 * ih + i][j] + bv[i];
+                f32x4 v;
+                if (LNA) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = __builtin_fmaf(st.y, __builtin_fmaf(-st.x, sv[i][e], acc[4 * ih + i][j][e]), bv[i][e]);
+                } else {
+                    v = acc[4 * ih + i][j] + bv[i];
+                }
                 if (GELU) v = gelu_erf4(v);
                 v4 h;
                 h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
@@ -272,7 +288,7 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
 // Branch-free epilogue for the residual GEMMs in operand-type residual mode (out_proj, fc2 without a hook tap):
 // out = half( resid_half * alpha + acc + bias ).  The sum is formed in fp32 AFTER the transpose (fp32 slab), so the
 // residual is read and the result written as row-contiguous 16-byte vectors and nothing is rounded twice.
-template <typename T>
+template <typename T, bool LNR, bool STATS>
 static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid,
                                                            int wm, int wn, int lane, int m0, int n0) {
     typedef typename Half<T>::v8 v8;
@@ -280,11 +296,23 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
     float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
     const int er = lane >> 3, ec = lane & 7;
     const float alpha = p.alpha;
-    const T* __restrict__ resid = (const T*)p.resid_half;
+    // LNR: the residual is LayerNorm(y) of raw rows y, applied on the fly from (mu, rstd) in LDS and gamma / beta
+    const T* __restrict__ resid = (const T*)(LNR ? p.lnr_y : p.resid_half);
+    const int ldres = LNR ? p.ldy : p.ldrh;
+    const float2* lnr = (const float2*)(smem + LNS_OFF + 2048);
+    const int nseg_out = p.N >> 6;
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih) {
         const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;
-        const f32x4 b0 = *(const f32x4*)(p.bias + nb), b1 = *(const f32x4*)(p.bias + nb + 4);
+        f32x4 b0 = *(const f32x4*)(p.bias + nb), b1 = *(const f32x4*)(p.bias + nb + 4);
+        f32x4 ga0, ga1;
+        if (LNR) {
+            // alpha * LN(y) + bias = y * (rstd * alpha gamma) + (alpha beta + bias - mu * rstd * alpha gamma)
+            ga0 = *(const f32x4*)(p.lnr_gamma + nb) * alpha; ga1 = *(const f32x4*)(p.lnr_gamma + nb + 4) * alpha;
+            const f32x4 be0 = *(const f32x4*)(p.lnr_beta + nb), be1 = *(const f32x4*)(p.lnr_beta + nb + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { b0[e] = __builtin_fmaf(alpha, be0[e], b0[e]); b1[e] = __builtin_fmaf(alpha, be1[e], b1[e]); }
+        }
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh) {
             // residual rows of this chunk: issued first so their latency hides under the slab round trip
@@ -293,7 +321,7 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
             for (int ps = 0; ps < 4; ++ps) {
                 int m = m0 + wn * 64 + 32 * jh + 8 * ps + er;
                 m = m < p.M ? m : p.M - 1;
-                rh[ps] = *(const v8*)(resid + (int64_t)m * p.ldrh + nb);
+                rh[ps] = *(const v8*)(resid + (int64_t)m * ldres + nb);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -305,15 +333,37 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
             for (int ps = 0; ps < 4; ++ps) {
                 const int ml = 8 * ps + er;
                 const int m = m0 + wn * 64 + 32 * jh + ml;
-                const f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec) + b0;
-                const f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4) + b1;
+                const f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
+                const f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
                 v8 h;
+                if (LNR) {
+                    const float2 st = lnr[wn * 64 + 32 * jh + ml];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = Half<T>::from(__builtin_fmaf((float)rh[ps][e], alpha, v0[e]));
-                    h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ps][4 + e], alpha, v1[e]));
+                    for (int e = 0; e < 4; ++e) {
+                        const float g0 = st.y * ga0[e], g1 = st.y * ga1[e];
+                        const float c0 = __builtin_fmaf(-st.x, g0, b0[e]), c1 = __builtin_fmaf(-st.x, g1, b1[e]);
+                        h[e] = Half<T>::from(__builtin_fmaf((float)rh[ps][e], g0, c0) + v0[e]);
+                        h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ps][4 + e], g1, c1) + v1[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = Half<T>::from(__builtin_fmaf((float)rh[ps][e], alpha, v0[e] + b0[e]));
+                        h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ps][4 + e], alpha, v1[e] + b1[e]));
+                    }
                 }
                 if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                if (STATS) {
+                    // partial LayerNorm statistics of the ROUNDED row segment (64 columns = the 8 lanes that share er)
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float hv = (float)h[e]; s1 += hv; s2 = __builtin_fmaf(hv, hv, s2); }
+                    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+                    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+                    s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                    if (ec == 0 && m < p.M)
+                        *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((n0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
+                }
             }
             asm volatile("" ::: "memory");
         }
@@ -384,6 +434,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     v8 wf[4][2], xf[4][2];
 
+    // ---- folded LayerNorm: finish the row statistics of this tile's 256 rows (threads 0-255: A side, 256-511: residual side)
+    // from the producer's per-segment partial sums; loaded BEFORE the DMA prologue so that waiting for them does not wait for it
+    if (p.ln_stats != nullptr || p.lnr_stats != nullptr) {
+        const bool second = tid >= 256;
+        const float* stp = second ? p.lnr_stats : p.ln_stats;
+        const int nseg = second ? p.lnr_nseg : p.ln_nseg;
+        if (stp != nullptr) {
+            int row = m0 + (tid & 255);
+            row = row < p.M ? row : p.M - 1;
+            const float2* src = (const float2*)stp + (int64_t)row * nseg;
+            float s1 = 0.f, s2 = 0.f;
+            for (int q = 0; q < nseg; ++q) { const float2 v = src[q]; s1 += v.x; s2 += v.y; }
+            const float inv = 1.0f / (float)(64 * nseg);
+            const float mu = s1 * inv;
+            const float var = fmaxf(__builtin_fmaf(-mu, mu, s2 * inv), 0.f);
+            ((float2*)(smem + LNS_OFF))[tid] = make_float2(mu, __builtin_amdgcn_rsqf(var + p.ln_eps));
+        }
+    }
+
     // ---- prologue: tile 0 complete, W0/X0/X1 of tile 1 in flight --------------------------------
     dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
     if (nk > 1) {
@@ -429,12 +498,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     // fp32 vectors), 8 lanes cover a 128-byte line, a wave instruction writes 8 full lines.  The
     // direct-from-accumulator form (8-byte stores, 32 B per row per instruction) ran the store path at
     // ~2 TB/s and cost 16 us per tile; bias / residual / GELU / masking happen after the transpose.
-    if (p.out_half && p.bias && !p.out_f32 && !p.out_raw && !p.resid && !p.resid_half && !p.row_zero) {
+    if (p.out_half && p.bias && !p.out_f32 && !p.out_raw && !p.resid && !p.resid_half && !p.lnr_y && !p.stats_out && !p.row_zero) {
         // Half-only outputs with bias and no residual (QKV, fc1 = 3/4 of the K = 768 work).
-        if (p.gelu) epilogue_half<T, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-        else epilogue_half<T, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-    } else if (p.out_half && p.bias && p.resid_half && !p.gelu && !p.out_f32 && !p.out_raw && !p.resid && !p.row_zero) {
-        epilogue_resid_half<T>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+        if (p.ln_stats) {
+            if (p.gelu) epilogue_half<T, true, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else epilogue_half<T, false, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+        } else {
+            if (p.gelu) epilogue_half<T, true, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else epilogue_half<T, false, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+        }
+    } else if (p.out_half && p.bias && (p.resid_half || p.lnr_y) && !p.ln_stats && !p.gelu && !p.out_f32 && !p.out_raw && !p.resid && !p.row_zero) {
+        if (p.lnr_y) {
+            if (p.stats_out) epilogue_resid_half<T, true, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else epilogue_resid_half<T, true, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+        } else {
+            if (p.stats_out) epilogue_resid_half<T, false, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else epilogue_resid_half<T, false, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+        }
     } else {
         constexpr int EP_LD = 68;   // floats per slab row (64 n + 4 pad: conflict-free 16-byte writes)
         float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
@@ -445,6 +525,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
             const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;   // this lane's 8 consecutive columns
             f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
+            f32x4 ls0 = b0, ls1 = b0, lg0 = b0, lg1 = b0, lb0 = b0, lb1 = b0;     // folded-LayerNorm column vectors (see GemmArgs)
+            if (p.ln_stats) { ls0 = *(const f32x4*)(p.ln_s + nb); ls1 = *(const f32x4*)(p.ln_s + nb + 4); }
+            if (p.lnr_y) {
+                lg0 = *(const f32x4*)(p.lnr_gamma + nb) * alpha; lg1 = *(const f32x4*)(p.lnr_gamma + nb + 4) * alpha;
+                lb0 = *(const f32x4*)(p.lnr_beta + nb) * alpha; lb1 = *(const f32x4*)(p.lnr_beta + nb + 4) * alpha;
+            }
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
 #pragma unroll
@@ -460,7 +546,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                     f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
                     f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
                     if (m >= p.M) continue;
-                    v0 += b0; v1 += b1;
+                    if (p.ln_stats) {
+                        const float2 st = ((const float2*)(smem + LNS_OFF))[wn * 64 + 32 * jh + ml];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = __builtin_fmaf(st.y, __builtin_fmaf(-st.x, ls0[e], v0[e]), b0[e]);
+                            v1[e] = __builtin_fmaf(st.y, __builtin_fmaf(-st.x, ls1[e], v1[e]), b1[e]);
+                        }
+                    } else {
+                        v0 += b0; v1 += b1;
+                    }
                     if (p.row_zero != nullptr && p.row_zero[m] != 0) {
                         v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
                     }
@@ -477,6 +572,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                         const v8 rh = *(const v8*)((const T*)p.resid_half + (int64_t)m * p.ldrh + nb);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rh[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rh[4 + e], alpha, v1[e]); }
+                    } else if (p.lnr_y) {
+                        const v8 rh = *(const v8*)((const T*)p.lnr_y + (int64_t)m * p.ldy + nb);
+                        const float2 st = ((const float2*)(smem + LNS_OFF + 2048))[wn * 64 + 32 * jh + ml];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g0 = st.y * lg0[e], g1 = st.y * lg1[e];
+                            v0[e] = __builtin_fmaf((float)rh[e], g0, __builtin_fmaf(-st.x, g0, lb0[e])) + v0[e];
+                            v1[e] = __builtin_fmaf((float)rh[4 + e], g1, __builtin_fmaf(-st.x, g1, lb1[e])) + v1[e];
+                        }
                     }
                     if (p.gelu) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }
                     if (p.out_f32) {
@@ -488,6 +592,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
                         *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = (float)h[e]; v1[e] = (float)h[4 + e]; }   // statistics see the rounded row
+                    }
+                    if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1 += v0[e] + v1[e]; s2 = __builtin_fmaf(v0[e], v0[e], __builtin_fmaf(v1[e], v1[e], s2)); }
+                        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+                        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+                        s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                        if (ec == 0)
+                            *(float2*)(p.stats_out + ((int64_t)m * (p.N >> 6) + ((n0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -801,6 +917,16 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     // variant: 0 = auto, 1 = 128-tile register staging, 2 = 256-tile half-tile pipeline, 3 = 128-tile LDS-DMA,
     // 5 = variant 2 persistent (next tile's DMA prologue issued before the epilogue)
     int variant = a.variant;
+    const bool ln_fold = a.ln_stats || a.lnr_y || a.stats_out;
+    if (ln_fold) {
+        // folded LayerNorm exists in the 256-tile kernel only
+        AVX_REQUIRE(a.N % T2 == 0 && (!a.out_half || a.ldh % 8 == 0), "gemm: folded LayerNorm needs N %% 256 == 0 (N=%d)", a.N);
+        AVX_REQUIRE(!a.ln_stats || (a.ln_s && a.bias && a.ln_nseg > 0 && 64 * a.ln_nseg == a.K), "gemm: ln_stats needs ln_s, bias and 64*ln_nseg == K");
+        AVX_REQUIRE(!a.lnr_y || (a.lnr_stats && a.lnr_gamma && a.lnr_beta && a.lnr_nseg > 0 && 64 * a.lnr_nseg == a.N && a.ldy % 8 == 0 && !a.resid && !a.resid_half),
+                    "gemm: lnr_y needs lnr_stats/gamma/beta, 64*lnr_nseg == N and no other residual");
+        AVX_REQUIRE(a.variant == 0 || a.variant == 2, "gemm: folded LayerNorm is built for variant 2 only");
+        variant = 2;
+    }
     if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
     if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 2 : 3;
     if (variant == 2 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
@@ -839,11 +965,11 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     if (variant == 2) {
         static bool attr_set = false;
         if (!attr_set) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2));
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
             attr_set = true;
         }
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
-        hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), 2 * STAGE2, s, a);
+        hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), LDS2, s, a);
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }

@@ -163,9 +163,14 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          resid: Optional[torch.Tensor] = None, resid_half: Optional[torch.Tensor] = None, alpha: float = 1.0,
          gelu: bool = False,
-         out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0
+         out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0,
+         ln_stats: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+         lnr_y: Optional[torch.Tensor] = None, lnr_stats: Optional[torch.Tensor] = None,
+         lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False
          ) -> Dict[str, torch.Tensor]:
-    """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm)."""
+    """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_stats``/``ln_s`` fold a
+    LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual, ``stats_out`` returns the
+    per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"`` (include/avexhip.h)."""
     _need_cuda(a, w)
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise ValueError("a and w must both be float16 or bfloat16")
@@ -194,6 +199,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     if out_raw:
         res["raw"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
         args.out_raw, args.ldraw = _ptr(res["raw"]), N
+    if ln_stats is not None:
+        ln_stats = ln_stats.contiguous()
+        args.ln_stats, args.ln_nseg, args.ln_eps, args.ln_s = _ptr(ln_stats), ln_stats.shape[1], ln_eps, _ptr(ln_s)
+    if lnr_y is not None:
+        lnr_y, lnr_stats = lnr_y.contiguous(), lnr_stats.contiguous()
+        args.lnr_y, args.ldy, args.lnr_stats, args.lnr_nseg = _ptr(lnr_y), N, _ptr(lnr_stats), lnr_stats.shape[1]
+        args.lnr_gamma, args.lnr_beta, args.ln_eps = _ptr(lnr_gamma), _ptr(lnr_beta), ln_eps
+    if stats_out:
+        res["stats"] = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=a.device)
+        args.stats_out = _ptr(res["stats"])
     check(lib().avexhip_gemm(C.byref(args), code, _stream()), "gemm")
     return res
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 1
+#define AVEXHIP_ABI_VERSION 2
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -106,7 +106,20 @@ typedef struct {
     void*  out_half; int64_t ldh;
     float* out_raw;  int64_t ldraw;
     int32_t variant;                   /* 0 = auto; 1 = 128-tile, register staging; 2 = 256-tile half-tile
-                                          LDS-DMA pipeline (needs N % 256 == 0); 3 = 128-tile LDS-DMA */
+                                          LDS-DMA pipeline (needs N % 256 == 0); 3 = 128-tile LDS-DMA;
+                                          5 = variant 2 with persistent workgroups */
+    /* LayerNorm folded into the GEMMs around it (all NULL/0 = off; variant 2 only, N % 256 == 0).
+     * A tensor y that is only consumed through LayerNorm (backbone.py:363,374: x = LN(residual * alpha + sublayer))
+     * stays raw in the operand type with per-row partial statistics [M][width/64][2] = (sum, sum of squares)
+     * of its 64-column segments, written by the GEMM that produced it (stats_out, from the rounded outputs).
+     *  - A operand = LN(y):  pass A = y, W = W * diag(gamma), bias = b + W beta, ln_s[n] = sum_k W'[n][k],
+     *    ln_stats = y's statistics (64 * ln_nseg == K); the epilogue forms rstd * (acc - mu * ln_s) + bias.
+     *  - residual = LN(y):   pass lnr_y = y (ld ldy), its statistics (64 * lnr_nseg == N), gamma, beta:
+     *    out = alpha * ((y - mu) * rstd * gamma + beta) + acc + bias.  */
+    const float* ln_stats; int32_t ln_nseg; float ln_eps; const float* ln_s;
+    const void*  lnr_y; int64_t ldy; const float* lnr_stats; int32_t lnr_nseg;
+    const float* lnr_gamma; const float* lnr_beta;
+    float* stats_out;
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
 

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
 
 
 def test_host_only_entry_points(built_lib):
-    assert built_lib.avexhip_abi_version() == 1
+    assert built_lib.avexhip_abi_version() == 2
     assert built_lib.avexhip_device_count() >= 0
     assert built_lib.avexhip_rel_bucket(0, 320, 800) == 0
     assert built_lib.avexhip_rel_bucket(1, 320, 800) == 161

@@ -124,6 +124,70 @@ def test_gemm_persistent_matches_tiled(built_lib, dtype, shape, monkeypatch):
                     assert torch.equal(r5[key], r2[key]), (kw.keys(), key)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M", [700, 1536])
+def test_gemm_folded_layernorm(built_lib, dtype, M):
+    """LayerNorm folded into the GEMMs around it (include/avexhip.h, avexhip_gemm_args): the producer writes raw rows y and
+    per-segment statistics; a consumer takes LN(y) as its A operand through folded weights (W diag(gamma), bias + W beta,
+    column sums); another takes LN(y) as its residual.  Checked against the explicit two-pass fp32 LayerNorm of the same
+    rounded rows (backbone.py:363,374)."""
+    from avex_amd import kernels as K
+    E, F = 768, 1024
+    td = _tdt(dtype)
+    rnd = lambda a: round_half(a, dtype)
+    a0 = rnd(synth.normal("lnA", (M, 256), 1.0)); w0 = rnd(synth.normal("lnW0", (E, 256), 0.08)); b0 = synth.normal("lnb0", (E,), 0.3)
+    x = rnd(synth.normal("lnx", (M, E), 1.0))
+    gamma = 1.0 + synth.normal("lng", (E,), 0.2); beta = synth.normal("lnbeta", (E,), 0.2)
+    alpha = 2.2133638
+    # producer: y = x * alpha + a0 @ w0.T + b0 (plain half residual), with statistics
+    r = K.gemm(_dev(a0, td), _dev(w0, td), bias=_dev(b0), resid_half=_dev(x, td), alpha=alpha, out_f32=False, out_half=True, stats_out=True)
+    y = r["half"].float().cpu().numpy()
+    y_ref = (x * alpha + a0.astype(np.float64) @ w0.astype(np.float64).T + b0)
+    assert rel_l2(y, y_ref) < (6e-4 if dtype == "f16" else 5e-3)
+    st = r["stats"].cpu().numpy()
+    seg = y.reshape(M, E // 64, 64).astype(np.float64)
+    assert np.allclose(st[..., 0], seg.sum(-1), rtol=1e-5, atol=1e-3) and np.allclose(st[..., 1], (seg ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+    ln = O.layer_norm(y.astype(np.float32), gamma.astype(np.float32), beta.astype(np.float32)).astype(np.float64)   # LN of the ROUNDED rows
+    # consumer A: gelu(LN(y) @ w1.T + b1) through folded weights
+    w1 = synth.normal("lnW1", (F, E), 0.05); b1 = synth.normal("lnb1", (F,), 0.1)
+    w1f = rnd((w1 * gamma[None, :]).astype(np.float32))
+    s1 = w1f.astype(np.float64).sum(1).astype(np.float32)
+    b1f = (b1 + w1.astype(np.float64) @ beta).astype(np.float32)
+    for gelu in (False, True):
+        r1 = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), gelu=gelu, out_f32=False, out_half=True, ln_stats=r["stats"], ln_s=_dev(s1))
+        # exact model of the fold: LN(y) (gamma folded and ROUNDED into w1f) @ ...
+        mu = y.astype(np.float64).mean(1, keepdims=True); rstd = 1.0 / np.sqrt(y.astype(np.float64).var(1, keepdims=True) + 1e-5)
+        ref1 = ((y - mu) * rstd) @ w1f.astype(np.float64).T + b1f
+        if gelu:
+            ref1 = O.gelu_erf(ref1.astype(np.float32))
+        assert rel_l2(r1["half"].float().cpu().numpy(), ref1) < (6e-4 if dtype == "f16" else 5e-3)
+        # and it agrees with the unfused formulation up to the rounding of the folded weights
+        ref_unf = ln @ w1.astype(np.float64).T + b1
+        if gelu:
+            ref_unf = O.gelu_erf(ref_unf.astype(np.float32))
+        assert rel_l2(r1["half"].float().cpu().numpy(), ref_unf) < (1.2e-3 if dtype == "f16" else 8e-3)
+    # generic epilogue with the fold (fp32 output)
+    r1g = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), ln_stats=r["stats"], ln_s=_dev(s1))
+    assert rel_l2(r1g["f32"].cpu().numpy(), ((y - mu) * rstd) @ w1f.astype(np.float64).T + b1f) < 1e-5
+    # consumer R: out = alpha * LN(y) + a2 @ w2.T + b2, fast path (+ statistics), and generic path with a raw tap
+    a2 = rnd(synth.normal("lnA2", (M, 512), 1.0)); w2 = rnd(synth.normal("lnW2", (E, 512), 0.05)); b2 = synth.normal("lnb2", (E,), 0.1)
+    raw_ref = a2.astype(np.float64) @ w2.astype(np.float64).T + b2
+    ref2 = alpha * ln + raw_ref
+    kw = dict(bias=_dev(b2), alpha=alpha, lnr_y=r["half"], lnr_stats=r["stats"], lnr_gamma=_dev(gamma.astype(np.float32)), lnr_beta=_dev(beta.astype(np.float32)))
+    r2 = K.gemm(_dev(a2, td), _dev(w2, td), out_f32=False, out_half=True, stats_out=True, **kw)
+    out2 = r2["half"].float().cpu().numpy()
+    assert rel_l2(out2, ref2) < (6e-4 if dtype == "f16" else 5e-3)
+    seg2 = out2.reshape(M, E // 64, 64).astype(np.float64)
+    assert np.allclose(r2["stats"][..., 0].cpu().numpy(), seg2.sum(-1), rtol=1e-5, atol=1e-3)
+    assert np.allclose(r2["stats"][..., 1].cpu().numpy(), (seg2 ** 2).sum(-1), rtol=1e-5, atol=2e-3)
+    r3 = K.gemm(_dev(a2, td), _dev(w2, td), out_f32=False, out_half=True, out_raw=True, stats_out=True, **kw)
+    assert torch.equal(r3["half"], r2["half"]) or rel_l2(r3["half"].float().cpu().numpy(), out2) < 1e-3
+    assert rel_l2(r3["raw"].cpu().numpy(), raw_ref) < 2e-6
+    assert np.allclose(r3["stats"].cpu().numpy(), r2["stats"].cpu().numpy(), rtol=2e-3, atol=0.1)   # rows may differ by an ulp between the two epilogues
+    r4 = K.gemm(_dev(a2, td), _dev(w2, td), out_f32=True, **kw)
+    assert rel_l2(r4["f32"].cpu().numpy(), ref2) < 2e-5
+
+
 def test_gemm_rejects_bad_shapes(built_lib):
     from avex_amd import kernels as K
     from avex_amd._capi import AvexHipError
