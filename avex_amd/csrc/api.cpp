@@ -115,6 +115,9 @@ struct Layer {
     void* w_fc1 = nullptr; float* b_fc1 = nullptr;
     void* w_fc2 = nullptr; float* b_fc2 = nullptr;
     float* ln2_w = nullptr; float* ln2_b = nullptr;
+    // LayerNorm-folded copies (see GemmArgs): fc1 consumes LN1 of this layer, QKV consumes LN2 of the previous layer
+    void* w_fc1_f = nullptr; float* b_fc1_f = nullptr; float* s_fc1 = nullptr;
+    void* w_qkv_f = nullptr; float* b_qkv_f = nullptr; float* s_qkv = nullptr;
 };
 
 struct StageRec {
@@ -163,6 +166,7 @@ struct avexhip_beats {
     int dtype = AVEXHIP_F16;
     int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 256;
     bool fast = false;   // residual stream / pre-LN sums in the operand type
+    bool ln_fold = false;  // fast mode: LayerNorms between the GEMMs folded into their epilogues
     int nstreams = 1;    // chunks of one forward run concurrently on this many streams (caller's + side streams)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -267,6 +271,58 @@ int dev_half(avexhip_beats* h, const Table& tb, const std::string& name, int64_t
     return dev_half_into(h, tb, name, numel, d);
 }
 
+// W' = half(W * diag(gamma)), b' = b + W beta, s[n] = sum_k float(W'[n][k]) for a consumer of LayerNorm(y; gamma, beta)
+// (W: [N, K] fp32 host rows gathered from the table by the caller)
+int fold_ln(avexhip_beats* h, const std::vector<float>& W, const std::vector<float>& b, int N, int K, const float* gamma_dev,
+            const float* beta_dev, void** w_out, float** b_out, float** s_out) {
+    std::vector<float> gamma(K), beta(K), Wg((size_t)N * K), bf(N);
+    AVX_HIP_CHECK(hipMemcpy(gamma.data(), gamma_dev, sizeof(float) * K, hipMemcpyDefault));
+    AVX_HIP_CHECK(hipMemcpy(beta.data(), beta_dev, sizeof(float) * K, hipMemcpyDefault));
+    for (int n = 0; n < N; ++n) {
+        double acc = b[n];
+        const float* wr = &W[(size_t)n * K];
+        float* wo = &Wg[(size_t)n * K];
+        for (int k = 0; k < K; ++k) { wo[k] = wr[k] * gamma[k]; acc += (double)wr[k] * (double)beta[k]; }
+        bf[n] = (float)acc;
+    }
+    float* tmp = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)N * K));
+    void* wd = nullptr; float* bd = nullptr; float* sd = nullptr;
+    int rc = AVEXHIP_OK;
+    if (hipMalloc(&wd, 2 * (size_t)N * K) != hipSuccess || hipMalloc((void**)&bd, sizeof(float) * N) != hipSuccess ||
+        hipMalloc((void**)&sd, sizeof(float) * N) != hipSuccess) {
+        avexhip_set_error("beats_create: device allocation for folded weights failed");
+        rc = AVEXHIP_ERR_HIP;
+    }
+    if (wd) h->allocs.push_back(wd);
+    if (bd) h->allocs.push_back(bd);
+    if (sd) h->allocs.push_back(sd);
+    if (rc == AVEXHIP_OK && (hipMemcpy(tmp, Wg.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemcpy(bd, bf.data(), sizeof(float) * N, hipMemcpyHostToDevice) != hipSuccess)) {
+        avexhip_set_error("beats_create: upload of folded weights failed");
+        rc = AVEXHIP_ERR_HIP;
+    }
+    if (rc == AVEXHIP_OK) rc = avx::cast_to_half(tmp, wd, (int64_t)N * K, h->dtype, nullptr);
+    if (rc == AVEXHIP_OK) rc = avx::row_sum_half(wd, N, K, sd, h->dtype, nullptr);
+    if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) { avexhip_set_error("beats_create: folding failed"); rc = AVEXHIP_ERR_HIP; }
+    (void)hipFree(tmp);
+    *w_out = wd; *b_out = bd; *s_out = sd;
+    return rc;
+}
+
+// gather an fp32 tensor of the table into a host vector (appending)
+int host_f32(const Table& tb, const std::string& name, int64_t numel, std::vector<float>& out) {
+    const avexhip_tensor* t = tb.find(name);
+    if (!t || t->numel != numel || !t->data) {
+        avexhip_set_error("beats_create: tensor '%s' missing or mis-sized", name.c_str());
+        return AVEXHIP_ERR_MISSING;
+    }
+    const size_t o = out.size();
+    out.resize(o + (size_t)numel);
+    AVX_HIP_CHECK(hipMemcpy(out.data() + o, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
+    return AVEXHIP_OK;
+}
+
 int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
     const avexhip_beats_config& c = h->cfg;
     const Table tb{tensors, n};
@@ -360,6 +416,23 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
         RC(dev_f32(h, tb, p + "fc2.bias", E, &ly.b_fc2));
         RC(dev_f32(h, tb, p + "final_layer_norm.weight", E, &ly.ln2_w));
         RC(dev_f32(h, tb, p + "final_layer_norm.bias", E, &ly.ln2_b));
+        if (h->ln_fold) {
+            std::vector<float> Wh, bh;
+            RC(host_f32(tb, p + "fc1.weight", (int64_t)F * E, Wh));
+            RC(host_f32(tb, p + "fc1.bias", F, bh));
+            RC(fold_ln(h, Wh, bh, F, E, ly.ln1_w, ly.ln1_b, &ly.w_fc1_f, &ly.b_fc1_f, &ly.s_fc1));
+            if (i > 0) {   // QKV of layer i reads LN2 of layer i-1
+                Wh.clear(); bh.clear();
+                RC(host_f32(tb, sa + "q_proj.weight", (int64_t)E * E, Wh));
+                RC(host_f32(tb, sa + "k_proj.weight", (int64_t)E * E, Wh));
+                RC(host_f32(tb, sa + "v_proj.weight", (int64_t)E * E, Wh));
+                RC(host_f32(tb, sa + "q_proj.bias", E, bh));
+                RC(host_f32(tb, sa + "k_proj.bias", E, bh));
+                RC(host_f32(tb, sa + "v_proj.bias", E, bh));
+                const Layer& prev = h->layers[i - 1];
+                RC(fold_ln(h, Wh, bh, 3 * E, E, prev.ln2_w, prev.ln2_b, &ly.w_qkv_f, &ly.b_qkv_f, &ly.s_qkv));
+            }
+        }
     }
     // shared relative-position table (owned by layer 0, backbone.py:100-103)
     if (c.num_buckets > 0) {
@@ -398,6 +471,7 @@ int bias_tab_for(avexhip_beats* h, int T, float** out) {
 
 struct Ws {
     char* patches; float* f0; char* h0; float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
+    float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
     size_t total;
 };
 
@@ -418,6 +492,8 @@ Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
     w.ah = take(M * h->E * 2);
     w.hh = take(M * h->F * 2);
     w.raw = (float*)take(M * h->E * 4);
+    w.st1 = (float*)take(h->ln_fold ? M * (h->E / 64) * 8 : 256);
+    w.st2 = (float*)take(h->ln_fold ? M * (h->E / 64) * 8 : 256);
     w.total = off;
     return w;
 }
@@ -571,11 +647,19 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         prof.end();
 
         // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375)
+        // "fold": the two LayerNorms of a layer never run as kernels.  y1 = x*alpha + attn (preh) and y2 = x1*alpha + ffn (xh) stay raw
+        // in the operand type with per-row partial statistics from the epilogue that wrote them; fc1 / the next QKV read them
+        // through LayerNorm-folded weights, out_proj / fc2 apply LayerNorm to their residual on the fly (GemmArgs, gemm.hip).
+        const bool fold = fast && h->ln_fold;      // any M: the same arithmetic whatever the chunking
+        const int nseg = E / 64;
         for (int i = 0; i < L; ++i) {
             const Layer& ly = h->layers[i];
+            const bool raw_in = fold && i > 0;      // xh holds y2 of layer i-1 (raw) instead of its LayerNorm
+            const Layer* pl = i > 0 ? &h->layers[i - 1] : nullptr;
             memset(&g, 0, sizeof(g));
             g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
             g.out_half = w.qkv; g.ldh = 3 * E;
+            if (raw_in) { g.W = ly.w_qkv_f; g.bias = ly.b_qkv_f; g.ln_stats = w.st2; g.ln_nseg = nseg; g.ln_eps = 1e-5f; g.ln_s = ly.s_qkv; }
             prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
             RC(avx::gemm(g, dt, cs));
             prof.end();
@@ -586,15 +670,25 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = h->alpha;
             if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
             else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
+            if (fold) {
+                g.stats_out = w.st1;
+                if (raw_in) {
+                    g.resid_half = nullptr; g.ldrh = 0;
+                    g.lnr_y = w.xh; g.ldy = E; g.lnr_stats = w.st2; g.lnr_nseg = nseg; g.lnr_gamma = pl->ln2_w; g.lnr_beta = pl->ln2_b; g.ln_eps = 1e-5f;
+                }
+            }
             prof.begin("gemm.out_proj", 2.0 * Md * E * E);
             RC(avx::gemm(g, dt, cs));
             prof.end();
-            prof.begin("layernorm", 0.0);
-            RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
-            prof.end();
+            if (!fold) {
+                prof.begin("layernorm", 0.0);
+                RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
+                prof.end();
+            }
             memset(&g, 0, sizeof(g));
             g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
             g.out_half = w.hh; g.ldh = F;
+            if (fold) { g.A = preh; g.W = ly.w_fc1_f; g.bias = ly.b_fc1_f; g.ln_stats = w.st1; g.ln_nseg = nseg; g.ln_eps = 1e-5f; g.ln_s = ly.s_fc1; }
             prof.begin("gemm.fc1", 2.0 * Md * F * E);
             RC(avx::gemm(g, dt, cs));
             prof.end();
@@ -603,6 +697,11 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = h->alpha;
             if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
             else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
+            if (fold) {   // residual = LN1(y1) on the fly; y2 (raw) goes to xh, which nothing reads any more in this layer
+                g.resid_half = nullptr; g.ldrh = 0;
+                g.lnr_y = preh; g.ldy = E; g.lnr_stats = w.st1; g.lnr_nseg = nseg; g.lnr_gamma = ly.ln1_w; g.lnr_beta = ly.ln1_b; g.ln_eps = 1e-5f;
+                g.out_half = w.xh; g.stats_out = w.st2;
+            }
             if (hooked) {
                 g.out_raw = hook_pooled ? w.raw : hook_out[i + 1] + (size_t)c0 * Tt * E;
                 g.ldraw = E;
@@ -616,9 +715,15 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             float* xo = nullptr;
             if (last) xo = features_out ? features_out + (size_t)c0 * Tt * E : ((pooled_out || !fast) ? x32 : nullptr);
             else if (!fast) xo = x32;
-            prof.begin("layernorm", 0.0);
-            if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
-            prof.end();
+            if (!fold) {
+                prof.begin("layernorm", 0.0);
+                if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
+                prof.end();
+            } else if (last && xo) {   // the only LayerNorm of the layer stack that still runs: fp32 features from the raw y2
+                prof.begin("layernorm", 0.0);
+                RC(avx::layernorm(nullptr, w.xh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, nullptr, E, dt, cs));
+                prof.end();
+            }
             if (last && pooled_out) {
                 prof.begin("mean_pool", 0.0);
                 RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, cs));
@@ -707,6 +812,10 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->L = c.encoder_layers; h->D = c.embed_dim; h->P = c.input_patch_size; h->NM = c.num_mel_bins;
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     h->fast = c.residual_dtype != 0;
+    {
+        const char* e = getenv("AVEX_AMD_LN_FOLD");
+        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && !(e && atoi(e) == 0);
+    }
     {
         // Independent chunks of a batch can overlap on several HIP streams: one chunk's HBM-bound kernels
         // (LayerNorm, epilogue tails, attention staging) fill the gaps of another chunk's MFMA kernels.

@@ -208,6 +208,7 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 int layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int M,
               int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s);
 int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s);
+int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t s);
 int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s);
 int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s);
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,

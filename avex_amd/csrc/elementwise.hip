@@ -245,9 +245,29 @@ __global__ __launch_bounds__(256) void lds_canary_kernel(int iters, unsigned* __
     }
 }
 
+// s[n] = sum_k float(W[n][k]) of a half matrix (fp32 accumulate): the column-sum vector of a LayerNorm-folded weight
+template <typename T>
+__global__ __launch_bounds__(256) void row_sum_half_kernel(const T* __restrict__ w, int N, int K, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += (float)w[(int64_t)row * K + k];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
 }  // namespace
 
 namespace avx {
+
+int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t s) {
+    AVX_REQUIRE(w && out && N > 0 && K > 0, "row_sum_half: bad arguments");
+    if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(row_sum_half_kernel<__bf16>, dim3((N + 3) / 4), dim3(256), 0, s, (const __bf16*)w, N, K, out);
+    else hipLaunchKernelGGL(row_sum_half_kernel<_Float16>, dim3((N + 3) / 4), dim3(256), 0, s, (const _Float16*)w, N, K, out);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
 
 int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s) {
     AVX_REQUIRE(in && out && n >= 0, "cast_to_half: bad arguments");

@@ -233,6 +233,15 @@ constexpr int LDS2 = 2 * STAGE2 + 4096;
 // layout, the wave's private slab holds the converted f16 values (half the LDS traffic of the fp32 transpose:
 // ds_write_b64 of 4 halves, ds_read_b128 of 8 halves per lane), and the loops carry no uniform branches so the
 // scheduler interleaves the 16 independent GELU chains of a 64-column slice (latency, not issue, bound otherwise).
+// Sum over the 8 consecutive lanes that share (lane >> 3), valid in the lane with (lane & 7) == 0: three DPP steps
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shl:4), no LDS traffic (a __shfl_xor becomes a ds_bpermute round trip).
+static __device__ __forceinline__ float seg8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
+    return v;
+}
+
 template <typename T, bool GELU, bool LNA>
 static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid, int wm,
                                                      int wn, int lane, int m0, int n0) {
@@ -254,7 +263,7 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // LayerNorm of the A rows folded in: rstd * (acc - mu * s[n]) + bias'  (mu, rstd of tile row 64 wn + 16 j + lc)
-            float2 st = make_float2(0.f, 1.f);
+            float2 st = make_float2(1.f, 0.f);
             if (LNA) st = ((const float2*)(smem + LNS_OFF))[wn * 64 + 16 * j + lc];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -262,7 +271,7 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
                 if (LNA) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = __builtin_fmaf(st.y, __builtin_fmaf(-st.x, sv[i][e], acc[4 * ih + i][j][e]), bv[i][e]);
+                        v[e] = __builtin_fmaf(st.x, acc[4 * ih + i][j][e], __builtin_fmaf(st.y, sv[i][e], bv[i][e]));
                 } else {
                     v = acc[4 * ih + i][j] + bv[i];
                 }
@@ -336,31 +345,31 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
                 const f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
                 const f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
                 v8 h;
+                f32x4 o0, o1;
                 if (LNR) {
-                    const float2 st = lnr[wn * 64 + 32 * jh + ml];
+                    const float2 st = lnr[wn * 64 + 32 * jh + ml];      // (rstd, -mu * rstd)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float g0 = st.y * ga0[e], g1 = st.y * ga1[e];
-                        const float c0 = __builtin_fmaf(-st.x, g0, b0[e]), c1 = __builtin_fmaf(-st.x, g1, b1[e]);
-                        h[e] = Half<T>::from(__builtin_fmaf((float)rh[ps][e], g0, c0) + v0[e]);
-                        h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ps][4 + e], g1, c1) + v1[e]);
+                        o0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ps][e], st.x, st.y), ga0[e], b0[e]) + v0[e];
+                        o1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ps][4 + e], st.x, st.y), ga1[e], b1[e]) + v1[e];
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        h[e] = Half<T>::from(__builtin_fmaf((float)rh[ps][e], alpha, v0[e] + b0[e]));
-                        h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ps][4 + e], alpha, v1[e] + b1[e]));
+                        o0[e] = __builtin_fmaf((float)rh[ps][e], alpha, v0[e] + b0[e]);
+                        o1[e] = __builtin_fmaf((float)rh[ps][4 + e], alpha, v1[e] + b1[e]);
                     }
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
                 if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
                 if (STATS) {
-                    // partial LayerNorm statistics of the ROUNDED row segment (64 columns = the 8 lanes that share er)
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float hv = (float)h[e]; s1 += hv; s2 = __builtin_fmaf(hv, hv, s2); }
-                    s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-                    s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-                    s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                    // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
+                    // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
+                    const f32x4 q0 = o0 * o0, q1 = o1 * o1;
+                    float s1 = (o0[0] + o0[1]) + (o0[2] + o0[3]) + ((o1[0] + o1[1]) + (o1[2] + o1[3]));
+                    float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+                    s1 = seg8_sum(s1); s2 = seg8_sum(s2);
                     if (ec == 0 && m < p.M)
                         *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((n0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
                 }
@@ -434,32 +443,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     v8 wf[4][2], xf[4][2];
 
-    // ---- folded LayerNorm: finish the row statistics of this tile's 256 rows (threads 0-255: A side, 256-511: residual side)
-    // from the producer's per-segment partial sums; loaded BEFORE the DMA prologue so that waiting for them does not wait for it
-    if (p.ln_stats != nullptr || p.lnr_stats != nullptr) {
-        const bool second = tid >= 256;
-        const float* stp = second ? p.lnr_stats : p.ln_stats;
-        const int nseg = second ? p.lnr_nseg : p.ln_nseg;
-        if (stp != nullptr) {
-            int row = m0 + (tid & 255);
-            row = row < p.M ? row : p.M - 1;
-            const float2* src = (const float2*)stp + (int64_t)row * nseg;
-            float s1 = 0.f, s2 = 0.f;
-            for (int q = 0; q < nseg; ++q) { const float2 v = src[q]; s1 += v.x; s2 += v.y; }
-            const float inv = 1.0f / (float)(64 * nseg);
-            const float mu = s1 * inv;
-            const float var = fmaxf(__builtin_fmaf(-mu, mu, s2 * inv), 0.f);
-            ((float2*)(smem + LNS_OFF))[tid] = make_float2(mu, __builtin_amdgcn_rsqf(var + p.ln_eps));
-        }
-    }
-
     // ---- prologue: tile 0 complete, W0/X0/X1 of tile 1 in flight --------------------------------
     dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
+    // folded LayerNorm: the producer's per-segment partial sums of this tile's 256 rows (threads 0-255: A side, 256-511:
+    // residual side) are loaded BETWEEN the two DMA groups, so the counted wait below covers them and nothing else changes
+    float ls1 = 0.f, ls2 = 0.f;
+    const bool ln_any = p.ln_stats != nullptr || p.lnr_stats != nullptr;
+    const float* lstp = tid >= 256 ? p.lnr_stats : p.ln_stats;
+    const int lnseg = tid >= 256 ? p.lnr_nseg : p.ln_nseg;
+    if (ln_any && lstp != nullptr) {
+        int row = m0 + (tid & 255);
+        row = row < p.M ? row : p.M - 1;
+        const f32x4* src = (const f32x4*)(lstp + (int64_t)row * lnseg * 2);     // 64 * nseg columns: nseg is even (N % 256 == 0 or K % 128 == 0)
+        for (int q = 0; q < (lnseg >> 1); ++q) { const f32x4 v = src[q]; ls1 += v[0] + v[2]; ls2 += v[1] + v[3]; }
+    }
     if (nk > 1) {
         dma_w(0, 1); dma_x(0, 1); dma_x(1, 1);
         AVX_VMCNT(6);
     } else {
         AVX_VMCNT(0);
+    }
+    if (ln_any && lstp != nullptr) {
+        const float inv = 1.0f / (float)(64 * lnseg);
+        const float mu = ls1 * inv;
+        const float var = fmaxf(__builtin_fmaf(-mu, mu, ls2 * inv), 0.f);
+        const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+        ((float2*)(smem + LNS_OFF))[tid] = make_float2(rstd, -mu * rstd);       // LN(y) = y * rstd + (-mu * rstd), times gamma, plus beta
     }
     AVX_BAR();
     if (stamp) g_gemm_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
             if (p.ln_stats) { ls0 = *(const f32x4*)(p.ln_s + nb); ls1 = *(const f32x4*)(p.ln_s + nb + 4); }
             if (p.lnr_y) {
                 lg0 = *(const f32x4*)(p.lnr_gamma + nb) * alpha; lg1 = *(const f32x4*)(p.lnr_gamma + nb + 4) * alpha;
-                lb0 = *(const f32x4*)(p.lnr_beta + nb) * alpha; lb1 = *(const f32x4*)(p.lnr_beta + nb + 4) * alpha;
+                lb0 = *(const f32x4*)(p.lnr_beta + nb); lb1 = *(const f32x4*)(p.lnr_beta + nb + 4);
             }
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
@@ -546,12 +555,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                     f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
                     f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
                     if (m >= p.M) continue;
+                    const f32x4 a0 = v0, a1 = v1;      // accumulators before the bias (the folded-LayerNorm residual adds them last)
                     if (p.ln_stats) {
                         const float2 st = ((const float2*)(smem + LNS_OFF))[wn * 64 + 32 * jh + ml];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v0[e] = __builtin_fmaf(st.y, __builtin_fmaf(-st.x, ls0[e], v0[e]), b0[e]);
-                            v1[e] = __builtin_fmaf(st.y, __builtin_fmaf(-st.x, ls1[e], v1[e]), b1[e]);
+                            v0[e] = __builtin_fmaf(st.x, v0[e], __builtin_fmaf(st.y, ls0[e], b0[e]));
+                            v1[e] = __builtin_fmaf(st.x, v1[e], __builtin_fmaf(st.y, ls1[e], b1[e]));
                         }
                     } else {
                         v0 += b0; v1 += b1;
@@ -577,9 +587,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                         const float2 st = ((const float2*)(smem + LNS_OFF + 2048))[wn * 64 + 32 * jh + ml];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float g0 = st.y * lg0[e], g1 = st.y * lg1[e];
-                            v0[e] = __builtin_fmaf((float)rh[e], g0, __builtin_fmaf(-st.x, g0, lb0[e])) + v0[e];
-                            v1[e] = __builtin_fmaf((float)rh[4 + e], g1, __builtin_fmaf(-st.x, g1, lb1[e])) + v1[e];
+                            // the same operations in the same order as epilogue_resid_half<T, true, *>: bit-identical rows
+                            v0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[e], st.x, st.y), lg0[e], __builtin_fmaf(alpha, lb0[e], b0[e])) + a0[e];
+                            v1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[4 + e], st.x, st.y), lg1[e], __builtin_fmaf(alpha, lb1[e], b1[e])) + a1[e];
                         }
                     }
                     if (p.gelu) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }
@@ -592,16 +602,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
                         *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = (float)h[e]; v1[e] = (float)h[4 + e]; }   // statistics see the rounded row
                     }
                     if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
-                        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1 += v0[e] + v1[e]; s2 = __builtin_fmaf(v0[e], v0[e], __builtin_fmaf(v1[e], v1[e], s2)); }
-                        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-                        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-                        s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                        const f32x4 q0 = v0 * v0, q1 = v1 * v1;     // same order as the branch-free epilogue
+                        float s1 = (v0[0] + v0[1]) + (v0[2] + v0[3]) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                        float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+                        s1 = seg8_sum(s1); s2 = seg8_sum(s2);
                         if (ec == 0)
                             *(float2*)(p.stats_out + ((int64_t)m * (p.N >> 6) + ((n0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
                     }
@@ -921,7 +927,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     if (ln_fold) {
         // folded LayerNorm exists in the 256-tile kernel only
         AVX_REQUIRE(a.N % T2 == 0 && (!a.out_half || a.ldh % 8 == 0), "gemm: folded LayerNorm needs N %% 256 == 0 (N=%d)", a.N);
-        AVX_REQUIRE(!a.ln_stats || (a.ln_s && a.bias && a.ln_nseg > 0 && 64 * a.ln_nseg == a.K), "gemm: ln_stats needs ln_s, bias and 64*ln_nseg == K");
+        AVX_REQUIRE(!a.ln_stats || (a.ln_s && a.bias && a.ln_nseg > 0 && a.ln_nseg % 2 == 0 && 64 * a.ln_nseg == a.K), "gemm: ln_stats needs ln_s, bias and 64*ln_nseg == K (K %% 128 == 0)");
         AVX_REQUIRE(!a.lnr_y || (a.lnr_stats && a.lnr_gamma && a.lnr_beta && a.lnr_nseg > 0 && 64 * a.lnr_nseg == a.N && a.ldy % 8 == 0 && !a.resid && !a.resid_half),
                     "gemm: lnr_y needs lnr_stats/gamma/beta, 64*lnr_nseg == N and no other residual");
         AVX_REQUIRE(a.variant == 0 || a.variant == 2, "gemm: folded LayerNorm is built for variant 2 only");

@@ -146,7 +146,8 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
     assert rel_l2(y, y_ref) < (6e-4 if dtype == "f16" else 5e-3)
     st = r["stats"].cpu().numpy()
     seg = y.reshape(M, E // 64, 64).astype(np.float64)
-    assert np.allclose(st[..., 0], seg.sum(-1), rtol=1e-5, atol=1e-3) and np.allclose(st[..., 1], (seg ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+    # (sums are taken from the fp32 values before the row is rounded to the operand type)
+    assert np.allclose(st[..., 0], seg.sum(-1), rtol=1e-3, atol=0.05 if dtype == "f16" else 0.4) and np.allclose(st[..., 1], (seg ** 2).sum(-1), rtol=2e-3 if dtype == "f16" else 1e-2, atol=0.3)
     ln = O.layer_norm(y.astype(np.float32), gamma.astype(np.float32), beta.astype(np.float32)).astype(np.float64)   # LN of the ROUNDED rows
     # consumer A: gelu(LN(y) @ w1.T + b1) through folded weights
     w1 = synth.normal("lnW1", (F, E), 0.05); b1 = synth.normal("lnb1", (F,), 0.1)
@@ -168,7 +169,8 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
         assert rel_l2(r1["half"].float().cpu().numpy(), ref_unf) < (1.2e-3 if dtype == "f16" else 8e-3)
     # generic epilogue with the fold (fp32 output)
     r1g = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), ln_stats=r["stats"], ln_s=_dev(s1))
-    assert rel_l2(r1g["f32"].cpu().numpy(), ((y - mu) * rstd) @ w1f.astype(np.float64).T + b1f) < 1e-5
+    # (the statistics come from the fp32 rows before rounding: mu differs from the rounded rows' mean by ~1e-5 sigma)
+    assert rel_l2(r1g["f32"].cpu().numpy(), ((y - mu) * rstd) @ w1f.astype(np.float64).T + b1f) < (1e-4 if dtype == "f16" else 1e-3)
     # consumer R: out = alpha * LN(y) + a2 @ w2.T + b2, fast path (+ statistics), and generic path with a raw tap
     a2 = rnd(synth.normal("lnA2", (M, 512), 1.0)); w2 = rnd(synth.normal("lnW2", (E, 512), 0.05)); b2 = synth.normal("lnb2", (E,), 0.1)
     raw_ref = a2.astype(np.float64) @ w2.astype(np.float64).T + b2
@@ -178,14 +180,14 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
     out2 = r2["half"].float().cpu().numpy()
     assert rel_l2(out2, ref2) < (6e-4 if dtype == "f16" else 5e-3)
     seg2 = out2.reshape(M, E // 64, 64).astype(np.float64)
-    assert np.allclose(r2["stats"][..., 0].cpu().numpy(), seg2.sum(-1), rtol=1e-5, atol=1e-3)
-    assert np.allclose(r2["stats"][..., 1].cpu().numpy(), (seg2 ** 2).sum(-1), rtol=1e-5, atol=2e-3)
+    assert np.allclose(r2["stats"][..., 0].cpu().numpy(), seg2.sum(-1), rtol=1e-3, atol=0.05 if dtype == "f16" else 0.4)
+    assert np.allclose(r2["stats"][..., 1].cpu().numpy(), (seg2 ** 2).sum(-1), rtol=2e-3 if dtype == "f16" else 1e-2, atol=0.3)
     r3 = K.gemm(_dev(a2, td), _dev(w2, td), out_f32=False, out_half=True, out_raw=True, stats_out=True, **kw)
-    assert torch.equal(r3["half"], r2["half"]) or rel_l2(r3["half"].float().cpu().numpy(), out2) < 1e-3
+    assert torch.equal(r3["half"], r2["half"])                  # the tap-carrying epilogue repeats the branch-free one operation for operation
     assert rel_l2(r3["raw"].cpu().numpy(), raw_ref) < 2e-6
-    assert np.allclose(r3["stats"].cpu().numpy(), r2["stats"].cpu().numpy(), rtol=2e-3, atol=0.1)   # rows may differ by an ulp between the two epilogues
+    assert torch.equal(r3["stats"], r2["stats"])
     r4 = K.gemm(_dev(a2, td), _dev(w2, td), out_f32=True, **kw)
-    assert rel_l2(r4["f32"].cpu().numpy(), ref2) < 2e-5
+    assert rel_l2(r4["f32"].cpu().numpy(), ref2) < (2e-5 if dtype == "f16" else 5e-4)
 
 
 def test_gemm_rejects_bad_shapes(built_lib):
