@@ -87,6 +87,27 @@ def test_oracle_agrees_on_fresh_input(encoder, base_sd):
     assert rel_l2(r["hooks"][5].cpu().numpy().mean(1), taps["backbone.encoder.layers.4.fc2"].mean(1)) < tol
 
 
+def test_edge_sizes(encoder, base_sd):
+    """Smallest and largest inputs the path takes, and the ones it refuses loudly: 16 frames -> 8 tokens, 1024 frames -> 512
+    tokens (the LDS-resident attention/pos-conv limit), one frame more than that, fewer samples than one analysis window,
+    and an empty batch."""
+    from avex_amd._capi import AvexHipError
+    tol = POOLED_TOL[encoder.dtype_name]
+    for samples, tokens in ((400 + 160 * 15, 8), (400 + 160 * 1023, 512)):
+        x = synth.noise_clips(1, samples, seed=31)
+        f, _ = O.beats_forward(x, base_sd, synth.BEATS_BASE_CFG)
+        assert f.shape[1] == tokens
+        r = encoder.forward(torch.from_numpy(x).cuda(), want_features=True, want_pooled=True)
+        assert r["features"].shape == (1, tokens, 768)
+        assert rel_l2(r["pooled"].cpu().numpy(), O.pooled(f)) < (3 * tol if tokens == 8 else tol)   # 8 tokens: no averaging
+    with pytest.raises(AvexHipError):
+        encoder.forward(torch.zeros(1, 400 + 160 * 1039, device="cuda"), want_pooled=True)          # 520 tokens
+    with pytest.raises(AvexHipError):
+        encoder.forward(torch.zeros(2, 300, device="cuda"), want_pooled=True)                       # shorter than one window
+    with pytest.raises((AvexHipError, ValueError)):
+        encoder.forward(torch.zeros(0, 160000, device="cuda"), want_pooled=True)                    # empty batch
+
+
 def test_full_size_properties(built_lib, base_sd):
     """BASELINE config C2 shape (batch 256 x 10 s) is too big for the CPU oracle; check size-independent
     properties instead: clip independence / permutation equivariance and agreement with small-batch runs."""
