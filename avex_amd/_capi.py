@@ -63,6 +63,8 @@ SYMBOLS = {
     "avexhip_fbank_plan_destroy": (None, [_P]),
     "avexhip_fbank_num_frames": (C.c_int, [_P, C.c_int64]),
     "avexhip_fbank_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
+    "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
+    "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
     "avexhip_fbank_forward_padded": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
     "avexhip_cast_f32_to_half": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),

@@ -142,6 +142,21 @@ class FbankPlan:
 # ---------------------------------------------------------------------------------------
 # Building blocks (used by the parity tests; the encoder handle calls the same launchers in C++)
 # ---------------------------------------------------------------------------------------
+def wavconv0(wav: torch.Tensor, w: torch.Tensor, gn_w: torch.Tensor, gn_b: torch.Tensor, frames_pad: int, slack_rows: int = 8,
+             eps: float = 1e-5, dtype="f16") -> torch.Tensor:
+    """wav2vec2 conv layer 0 (Conv1d(1,512,10,5) + GroupNorm over time + GELU) -> half ``[B * frames_pad + slack_rows, 512]``
+    (``[clip][frame][channel]`` rows; rows past a clip's last frame are zero, the slack rows are uninitialised)."""
+    _need_cuda(wav, w, gn_w, gn_b)
+    code = dtype_code(dtype)
+    wav = wav.contiguous()
+    B, T = wav.shape
+    out = torch.empty((B * frames_pad + slack_rows, 512), dtype=half_torch_dtype(code), device=wav.device)
+    stats = torch.empty((B, 512, 2), dtype=torch.float32, device=wav.device)
+    check(lib().avexhip_wavconv0(_ptr(wav), B, T, wav.stride(0), _ptr(w.contiguous()), _ptr(gn_w), _ptr(gn_b), eps, _ptr(stats),
+                                 _ptr(out), frames_pad, code, _stream()), "wavconv0")
+    return out
+
+
 def to_half(x: torch.Tensor, dtype="f16") -> torch.Tensor:
     _need_cuda(x)
     code = dtype_code(dtype)
@@ -166,7 +181,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
          out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0,
          ln_stats: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
          lnr_y: Optional[torch.Tensor] = None, lnr_stats: Optional[torch.Tensor] = None,
-         lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False
+         lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False,
+         lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0
          ) -> Dict[str, torch.Tensor]:
     """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_stats``/``ln_s`` fold a
     LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual, ``stats_out`` returns the
@@ -176,11 +192,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
         raise ValueError("a and w must both be float16 or bfloat16")
     code = _capi.F16 if a.dtype == torch.float16 else _capi.BF16
     a, w = a.contiguous(), w.contiguous()
-    M, K = a.shape
+    if lda is not None:
+        # strided, possibly overlapping rows of a flat buffer: row m = a.flatten()[m * lda : m * lda + kdim]
+        # (a Conv1d over [frame][channel] activations is this GEMM with lda = stride * C and kdim = kernel * C)
+        M, K = int(rows), int(kdim)
+        if a.numel() < (M - 1) * lda + K:
+            raise ValueError("gemm: buffer too small for the strided view")
+    else:
+        M, K = a.shape
+        lda = K
     N = w.shape[0]
     res: Dict[str, torch.Tensor] = {}
     args = GemmArgs()
-    args.A, args.lda, args.W, args.ldw = _ptr(a), K, _ptr(w), K
+    args.A, args.lda, args.W, args.ldw = _ptr(a), lda, _ptr(w), K
     args.M, args.N, args.K = M, N, K
     args.bias = _ptr(bias)
     if resid is not None:
@@ -194,7 +218,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
         res["f32"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
         args.out_f32, args.ldo = _ptr(res["f32"]), N
     if out_half:
-        res["half"] = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        res["half"] = torch.empty((M + slack_rows, N), dtype=a.dtype, device=a.device)   # slack rows (uninitialised) for strided readers
         args.out_half, args.ldh = _ptr(res["half"]), N
     if out_raw:
         res["raw"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
@@ -213,9 +237,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     return res
 
 
-def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, half_dtype="f16"
-              ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """LayerNorm of an fp32 or half ``[M, C]`` tensor -> (fp32 copy, half copy)."""
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, half_dtype="f16",
+              want_f32: bool = True, want_half: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """LayerNorm of an fp32 or half ``[M, C]`` tensor -> (fp32 copy, half copy); either may be skipped."""
     _need_cuda(x, weight, bias)
     x = x.contiguous()
     M, Cc = x.shape
@@ -225,8 +249,8 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     else:
         code = _capi.F16 if x.dtype == torch.float16 else _capi.BF16
         pin, pinh = None, _ptr(x)
-    o32 = torch.empty((M, Cc), dtype=torch.float32, device=x.device)
-    oh = torch.empty((M, Cc), dtype=half_torch_dtype(code), device=x.device)
+    o32 = torch.empty((M, Cc), dtype=torch.float32, device=x.device) if want_f32 else None
+    oh = torch.empty((M, Cc), dtype=half_torch_dtype(code), device=x.device) if want_half else None
     check(lib().avexhip_layernorm(pin, pinh, Cc, _ptr(weight), _ptr(bias), eps, M, Cc, _ptr(o32), Cc, _ptr(oh), Cc,
                                   code, _stream()), "layernorm")
     return o32, oh

@@ -163,6 +163,59 @@ def beats_state_dict(cfg: Mapping[str, object] = BEATS_BASE_CFG, seed: int = 0,
     return sd
 
 
+AVES_BASE_CFG: Dict[str, object] = dict(        # avex/models/aves_model.py:19-47 (AVESConfig defaults = wav2vec2 base)
+    extractor_conv_layer_config=[[512, 10, 5], [512, 3, 2], [512, 3, 2], [512, 3, 2], [512, 3, 2], [512, 2, 2], [512, 2, 2]],
+    encoder_embed_dim=768, encoder_pos_conv_kernel=128, encoder_pos_conv_groups=16, encoder_num_layers=12,
+    encoder_num_heads=12, encoder_ff_interm_features=3072, encoder_layer_norm_first=False,
+)
+
+
+def aves_state_dict(cfg: Mapping[str, object] = AVES_BASE_CFG, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic AVES / wav2vec2-base state dict (fp32 numpy) with torchaudio's key names under the wrapper's ``model.`` prefix
+    (aves_model.py:86): conv feature extractor (no bias, GroupNorm on layer 0), feature projection, weight-normed positional
+    conv, post-LN transformer.  Scales keep activations O(1) through the stack; LayerNorm / GroupNorm affines and biases are
+    perturbed away from 1 / 0 so every term is exercised."""
+    E = int(cfg["encoder_embed_dim"]); F = int(cfg["encoder_ff_interm_features"]); L = int(cfg["encoder_num_layers"])
+    KP = int(cfg["encoder_pos_conv_kernel"]); G = int(cfg["encoder_pos_conv_groups"])
+    convs = [tuple(int(v) for v in c) for c in cfg["extractor_conv_layer_config"]]
+    sd: Dict[str, np.ndarray] = {}
+    pre = "model."
+
+    def n(name, shape, std):
+        sd[pre + name] = normal("aves." + name, shape, std, seed)
+
+    def aff(name, dim, is_weight):
+        v = normal("aves." + name, (dim,), 0.1 if is_weight else 0.05, seed)
+        sd[pre + name] = (v + 1.0).astype(np.float32) if is_weight else v
+
+    cin = 1
+    for i, (cout, k, _s) in enumerate(convs):
+        n(f"feature_extractor.conv_layers.{i}.conv.weight", (cout, cin, k), math.sqrt(2.0 / (cin * k)))   # kaiming_normal
+        cin = cout
+    aff("feature_extractor.conv_layers.0.layer_norm.weight", convs[0][0], True)
+    aff("feature_extractor.conv_layers.0.layer_norm.bias", convs[0][0], False)
+    C = convs[-1][0]
+    aff("encoder.feature_projection.layer_norm.weight", C, True); aff("encoder.feature_projection.layer_norm.bias", C, False)
+    n("encoder.feature_projection.projection.weight", (E, C), 1.0 / math.sqrt(C)); n("encoder.feature_projection.projection.bias", (E,), 0.02)
+    v = normal("aves.pos_conv.v", (E, E // G, KP), math.sqrt(4.0 / (KP * E)), seed)
+    g = np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
+    g = (g * (1.0 + normal("aves.pos_conv.g", (1, 1, KP), 0.1, seed))).astype(np.float32)
+    sd[pre + "encoder.transformer.pos_conv_embed.conv.parametrizations.weight.original0"] = g
+    sd[pre + "encoder.transformer.pos_conv_embed.conv.parametrizations.weight.original1"] = v
+    n("encoder.transformer.pos_conv_embed.conv.bias", (E,), 0.02)
+    aff("encoder.transformer.layer_norm.weight", E, True); aff("encoder.transformer.layer_norm.bias", E, False)
+    for i in range(L):
+        p = f"encoder.transformer.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            n(p + f"attention.{nm}.weight", (E, E), math.sqrt(1.0 / E) * (1.0 if nm in ("q_proj", "k_proj") else 0.5))
+            n(p + f"attention.{nm}.bias", (E,), 0.02)
+        aff(p + "layer_norm.weight", E, True); aff(p + "layer_norm.bias", E, False)
+        n(p + "feed_forward.intermediate_dense.weight", (F, E), math.sqrt(2.0 / (E + F)) * 0.7); n(p + "feed_forward.intermediate_dense.bias", (F,), 0.02)
+        n(p + "feed_forward.output_dense.weight", (E, F), math.sqrt(2.0 / (E + F)) * 0.7); n(p + "feed_forward.output_dense.bias", (E,), 0.02)
+        aff(p + "final_layer_norm.weight", E, True); aff(p + "final_layer_norm.bias", E, False)
+    return sd
+
+
 # ----------------------------------------------------------------------------------
 # Synthetic clips (BASELINE.md §3 "Inputs")
 # ----------------------------------------------------------------------------------

@@ -80,6 +80,17 @@ int avexhip_fbank_forward_padded(const avexhip_fbank_plan* plan, const float* wa
                                  int64_t wav_stride, const float* clip_offset_dev, int out_frames,
                                  float* out_dev, void* stream);
 
+/* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
+ * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):
+ *   Conv1d(1, 512, k=10, s=5) -> GroupNorm(512, 512, eps) over time per (clip, channel) -> GELU
+ * wav_dev [B, T] fp32; w_dev [512, 10] fp32; gn_w/gn_b [512]; stats_dev [B, 512, 2] fp32 scratch;
+ * out_dev [B, frames_pad, 512] half (rows >= frames are zero).  The other six conv layers are strided-row
+ * avexhip_gemm calls (A row t of clip b = frames s*t .. s*t+k-1 of the previous layer: lda = s * 512, K = k * 512). */
+int avexhip_wavconv0_frames(int64_t T);
+int avexhip_wavconv0(const float* wav_dev, int B, int64_t T, int64_t wav_stride, const float* w_dev,
+                     const float* gn_w_dev, const float* gn_b_dev, float eps, float* stats_dev, void* out_dev,
+                     int frames_pad, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Building blocks (exported so every kernel can be parity-tested in isolation through the ABI).
  * `dtype` selects the half operand type of the half buffers.

@@ -416,3 +416,46 @@ def test_fbank_edge_lengths(built_lib):
         if frames:
             ref = O.fbank(synth.noise_clips(1, T, seed=1) * np.float32(2 ** 15))
             assert max_abs(y.cpu().numpy(), ref) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# AVES / wav2vec2 path: parity unpinned vs torchaudio (absent); checker = oracle/aves_oracle.py
+# ------------------------------------------------------------------------------------------------------------------------
+def test_wavconv0_matches_oracle(built_lib):
+    from avex_amd import kernels as K
+    from oracle import aves_oracle as AO
+    sd = synth.aves_state_dict()
+    x = synth.noise_clips(2, 16000, seed=41) + np.float32(0.02)
+    cfg1 = dict(synth.AVES_BASE_CFG, extractor_conv_layer_config=[[512, 10, 5]])
+    ref = AO.feature_extractor(x, sd, cfg1)                                     # [2, 3199, 512]
+    F = ref.shape[1]
+    out = K.wavconv0(_dev(x), _dev(sd["model.feature_extractor.conv_layers.0.conv.weight"].reshape(512, 10)),
+                     _dev(sd["model.feature_extractor.conv_layers.0.layer_norm.weight"]),
+                     _dev(sd["model.feature_extractor.conv_layers.0.layer_norm.bias"]), frames_pad=F + 9)
+    got = out[:2 * (F + 9)].view(2, F + 9, 512).float().cpu().numpy()
+    assert rel_l2(got[:, :F], ref) < 6e-4                                       # one rounding to f16
+    assert np.all(got[:, F:] == 0)
+
+
+@pytest.mark.parametrize("samples", [16000, 40000])
+def test_aves_encoder_matches_oracle(built_lib, samples):
+    """Conv feature extractor as strided-row GEMMs + the transformer on the shared kernels vs the NumPy restatement
+    (2 transformer layers keep the CPU side short; all widths are the real ones)."""
+    from avex_amd.aves_encoder import AvesEncoder, conv_frame_plan
+    from oracle import aves_oracle as AO
+    cfg = dict(synth.AVES_BASE_CFG, encoder_num_layers=2)
+    sd = synth.aves_state_dict(cfg)
+    enc = AvesEncoder(cfg, sd)
+    x = synth.noise_clips(3, samples, seed=43)
+    F, P = conv_frame_plan(samples, enc.convs)
+    assert F[-1] == (49 if samples == 16000 else 124) and all(p >= f for p, f in zip(P, F))
+    feats = enc.extract_conv_features(_dev(x)).float().cpu().numpy()
+    assert rel_l2(feats, AO.feature_extractor(x, sd, cfg)) < 3e-3               # 7 layers of f16 operands
+    ref, taps = AO.aves_forward(x, sd, cfg)
+    r = enc.forward(_dev(x), hook_layers=[0, 1], want_features=True, want_pooled=True)
+    assert r["features"].shape == ref.shape
+    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean(1)) < 2e-3
+    assert rel_l2(r["features"].cpu().numpy(), ref) < 6e-3
+    for i in (0, 1):
+        name = f"model.encoder.transformer.layers.{i}.feed_forward.output_dense"
+        assert rel_l2(r["hooks"][i].cpu().numpy().mean(1), taps[name].mean(1)) < 3e-3
