@@ -144,6 +144,8 @@ def initialize_registry() -> None:
                        entry.get("class_mapping_path"))
     from .beats_model import Model as BeatsModel
     _MODEL_CLASSES.setdefault("beats", BeatsModel)
+    from .aves_model import Model as AvesModel
+    _MODEL_CLASSES.setdefault("aves", AvesModel)
 
 
 initialize_registry()

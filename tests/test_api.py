@@ -248,3 +248,37 @@ def test_extraction_loop_semantics_cpu():
     with pytest.raises(RuntimeError):
         extract_embeddings_in_memory(m, batches, [0], "cpu", disable_layerdrop=True)
     assert m.deregistered == 1 and m.disable_layerdrop is False
+
+
+def test_aves_class_contract_cpu():
+    """AVES mirror (reference: avex/models/aves_model.py:62-262) without a GPU: torchaudio wav2vec2 key names (210 tensors),
+    hookable layers = the 12 output_dense modules, name/index resolution, prefix-less and old-style weight_norm checkpoints
+    load, forward refuses to run on the CPU."""
+    import numpy as np
+    import pytest
+    import torch
+    import avex_amd
+    from avex_amd import synth
+    from avex_amd._capi import AvexHipError
+    from avex_amd.aves_model import Model
+    assert "aves" in avex_amd.list_model_classes()
+    m = Model(device="cpu")
+    sd = synth.aves_state_dict()
+    assert set(m.state_dict()) == set(sd) and len(sd) == 210
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    bare = {k[len("model."):]: torch.from_numpy(v) for k, v in sd.items()}            # as torchaudio saves it
+    bare["encoder.transformer.pos_conv_embed.conv.weight_g"] = bare.pop("encoder.transformer.pos_conv_embed.conv.parametrizations.weight.original0")
+    bare["encoder.transformer.pos_conv_embed.conv.weight_v"] = bare.pop("encoder.transformer.pos_conv_embed.conv.parametrizations.weight.original1")
+    m.load_state_dict(bare)
+    layers = m.register_hooks_for_layers(["all"])
+    assert layers == [f"model.encoder.transformer.layers.{i}.feed_forward.output_dense" for i in range(12)]
+    assert m.register_hooks_for_layers([-1, 0]) == [layers[-1], layers[0]]
+    with pytest.raises(ValueError):
+        m.register_hooks_for_layers(["model.encoder.nope"])
+    m.deregister_all_hooks()
+    with pytest.raises(ValueError):
+        m.extract_embeddings(torch.zeros(1, 16000))                                    # no hooks registered
+    with pytest.raises((AvexHipError, RuntimeError)):
+        m(torch.zeros(1, 16000))
+    with pytest.raises(FileNotFoundError):
+        Model(device="cpu", pretrained=True)

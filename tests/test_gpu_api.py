@@ -157,6 +157,31 @@ def test_extraction_loop_on_gpu(model, g):
     assert not model._hooks                                     # loop deregistered its hooks
 
 
+def test_aves_model_on_gpu(built_lib):
+    """AVES mirror end to end on the GPU vs the NumPy restatement (2 transformer layers, real widths): features, hook taps
+    through extract_embeddings with every aggregation the reference offers."""
+    from oracle import aves_oracle as AO
+    from avex_amd.aves_model import Model
+    cfg = dict(synth.AVES_BASE_CFG, encoder_num_layers=2)
+    sd = synth.aves_state_dict(cfg)
+    m = Model(device="cuda", init_config={"encoder_num_layers": 2}).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = synth.noise_clips(2, 32000, seed=47)
+    ref, taps = AO.aves_forward(x, sd, cfg)
+    f = m(torch.from_numpy(x))
+    assert f.shape == ref.shape == (2, 99, 768) and f.is_cuda
+    assert rel_l2(f.mean(1).cpu().numpy(), ref.mean(1)) < 2e-3
+    names = m.register_hooks_for_layers(["all"])
+    t0, t1 = taps[names[0]], taps[names[1]]
+    e = m.extract_embeddings({"raw_wav": torch.from_numpy(x)}, aggregation="mean")
+    assert e.shape == (2, 1536) and rel_l2(e.cpu().numpy(), np.concatenate([t0.mean(1), t1.mean(1)], 1)) < 3e-3
+    e = m.extract_embeddings(torch.from_numpy(x), aggregation="max")
+    assert rel_l2(e.cpu().numpy(), np.concatenate([t0.max(1), t1.max(1)], 1)) < 1e-2
+    e = m.extract_embeddings(torch.from_numpy(x), aggregation="none")
+    assert isinstance(e, list) and len(e) == 2 and e[1].shape == (2, 99, 768)
+    m.deregister_all_hooks()
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
