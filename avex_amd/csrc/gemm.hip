@@ -622,16 +622,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// Variant 5: the variant-2 pipeline made PERSISTENT (one workgroup per CU walks its tiles).  The in-kernel
-// stamps of variant 2 at K = 768 read: DMA prologue 3.0 us + K loop 17.8 us + epilogue 4.4 us + 1.9 us
-// until the next workgroup starts.  Here the next tile's first 14 DMA instructions (K-tile 0 into stage 0,
-// three half-tiles of K-tile 1 into stage 1) are issued right after the K loop, BEFORE the epilogue, whose
-// transpose slabs live in the 32 KiB of LDS above the two stages (16-row chunks) -- so the prologue latency
-// and the workgroup turnaround disappear behind the epilogue.  vmcnt counts stores too, in order: the
-// epilogue's 16 stores per lane are YOUNGER than those DMAs, so the wait at the top of the next tile is
-// vmcnt(6 + 16) and does not drain them; the residual rows are loaded BEFORE the DMAs (into the fragment
-// registers, dead by then) for the same reason.  Epilogues other than the two branch-free ones fall back to
-// epilogue-then-DMA.
+// Variant 5: the variant-2 pipeline as ONE CONTINUOUS K STREAM over a persistent workgroup's tiles (one workgroup per CU).
+// The in-kernel stamps of variant 2 at K = 768 read: DMA prologue 3.0 us + K loop 17.8 us + epilogue 4.4 us + 1.9 us
+// until the next workgroup starts.  Here the last iterations of a tile issue the DMA for the next tile's first K-tiles
+// as if they were K-tiles nk, nk + 1 of the same product (pointers switch in the middle of iteration nk - 2), the epilogue's
+// transpose slabs live in the 32 KiB of LDS above the two stages, the bias row arrives by LDS-DMA one tile ahead, and the
+// wave stagger is never re-aligned: no prologue, no turnaround, no barrier between tiles.
+// MEASURED: bit-identical to variant 2, and NOT faster (0 +- 2 % on every shape): prologue and turnaround vanish from the
+// stamps, but the K loop of a K = 768 tile stretches from 17.8 to 22.4 us (1.87 instead of 1.48 us per K-tile).  The
+// per-tile cost is not a pipeline-drain cost; kept as a diagnostic vehicle (scripts/gemm_stamps5.py), variant 2 stays default.
 // ---------------------------------------------------------------------------------------------
 constexpr int LDS5 = 2 * STAGE2 + 32768;
 
@@ -678,26 +677,32 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 xsrc[h][q] = A + (int64_t)arow * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3);
             }
     };
-    auto dma_w = [&](int h, int kt) __attribute__((always_inline)) {
-        char* base = smem + (kt & 1) * STAGE2;
+    auto dma_w = [&](int h, int kt, int stg) __attribute__((always_inline)) {
+        char* base = smem + stg * STAGE2;
         __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, 0);
     };
-    auto dma_x = [&](int h, int kt) __attribute__((always_inline)) {
-        char* base = smem + (kt & 1) * STAGE2;
+    auto dma_x = [&](int h, int kt, int stg) __attribute__((always_inline)) {
+        char* base = smem + stg * STAGE2;
         __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, 0);
     };
+    static_assert(EPI == 1 || EPI == 2, "the streaming kernel has the two branch-free epilogues only");
+    constexpr bool fast_half = EPI == 1, fast_resid = EPI == 2;
+    float* ldsbias = (float*)(smem + 2 * STAGE2 + 8 * 2304);      // EPI 1: [2][256] bias of the current / next tile, filled by LDS-DMA
+    auto dma_bias = [&](int n0b, int par) __attribute__((always_inline)) {   // 256 floats = one LDS-DMA wave instruction (wave 0)
+        if (fast_half && wid == 0)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(p.bias + n0b + lane * 4), (lptr_t*)(ldsbias + par * 256), 16, 0, 0);
+    };
     auto tile_prologue = [&]() __attribute__((always_inline)) {   // 14 DMA instructions
-        dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
-        dma_w(0, 1); dma_x(0, 1); dma_x(1, 1);
+        dma_w(0, 0, 0); dma_x(0, 0, 0); dma_x(1, 0, 0); dma_w(1, 0, 0);
+        dma_w(0, 1, 1); dma_x(0, 1, 1); dma_x(1, 1, 1);
     };
     const int sw = (lane >> 1) & 7;
     const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);
     const int foff1 = foff0 ^ 64;
     const int wfrag = (wm * 128) * 128;
     const int xfrag = T2 * BK * 2 + (wn * 64) * 128;
-    constexpr bool fast_half = EPI == 1, fast_resid = EPI == 2, overlapped = EPI != 0;
 
     f32x4 acc[8][4];
     v8 wf[4][2], xf[4][2];
@@ -705,40 +710,46 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     int tile = (0 * 8 + xcd) * per_xcd + slot;
     if (tile >= ntiles) return;
     set_tile(tile);
+    dma_bias(n0, 0);
     tile_prologue();
-    if (p.stagger_ticks > 0 && p.stagger_groups > 1) {
-        // Start phases: every workgroup runs the same schedule, so without this all 256 CUs reach their epilogues together
-        // and the chip alternates between an HBM-idle K loop and an HBM-bound store burst.  Phase g starts g * ticks late.
-        const int g = slot % p.stagger_groups;
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(g * p.stagger_ticks);
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
     const bool stamp_on = g_gemm_stamps_on != 0 && tid == 0;
-    bool stores_behind = false;   // the previous epilogue's 16 stores are younger than this tile's prologue DMAs
+    AVX_VMCNT(6);
+    AVX_BAR();
+    if (wm == 1) { AVX_BAR(); }      // stagger: waves 4-7 run one barrier behind, for the whole tile walk
+    int g0 = 0;                      // global K-tile index of the tile's first K-tile: its stage parity
 
+    // One continuous K stream over this workgroup's tiles: the DMA for the next tile's first K-tiles is issued by the
+    // LAST iterations of the current tile exactly as if they were K-tiles nk, nk + 1 of the same product (the source
+    // pointers switch to the next tile in the middle of iteration nk - 2, after the last use of the current ones), so the
+    // pipeline never drains: no per-tile prologue, no workgroup turnaround, and the epilogue (private LDS slabs above the
+    // stages, no barrier) runs with two K-tiles of the next tile already in flight.
     for (int it = 0;; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool stamp = stamp_on && tile < 8192;
-        if (stamp) g_gemm_stamps[4 * tile + 0] = __builtin_amdgcn_s_memrealtime();
-        if (stores_behind) { AVX_VMCNT(22); } else { AVX_VMCNT(6); }
-        AVX_BAR();
-        if (stamp) { g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); }
-        if (wm == 1) { AVX_BAR(); }
+        const int em0 = m0, en0 = n0;
+        const int next_tile = ((it + 1) * 8 + xcd) * per_xcd + slot;
+        const bool has_next = next_tile < ntiles;
+        if (stamp) { g_gemm_stamps[4 * tile + 0] = g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); }
         for (int kt = 0; kt < nk; ++kt) {
-            const int st = kt & 1;
+            const int st = (g0 + kt) & 1;
             AVX_READ_X(st);
             AVX_READ_W(0, st);
-            if (kt + 1 < nk) dma_w(1, kt + 1);
+            if (kt + 1 < nk) dma_w(1, kt + 1, st ^ 1);
+            else if (has_next) dma_w(1, 0, st ^ 1);                  // pointers already switched (below, one iteration ago)
+            if (kt == nk - 2 && has_next) { set_tile(next_tile); dma_bias(n0, (it + 1) & 1); }   // last use of this tile's pointers was the line above
             AVX_LGKM0();
             AVX_BAR();
             AVX_HALF(0);
             AVX_BAR();
             AVX_READ_W(1, st);
             if (kt + 2 < nk) {
-                dma_w(0, kt + 2); dma_x(0, kt + 2); dma_x(1, kt + 2);
+                dma_w(0, kt + 2, st); dma_x(0, kt + 2, st); dma_x(1, kt + 2, st);
+                AVX_VMCNT(6);
+            } else if (has_next) {
+                dma_w(0, kt + 2 - nk, st); dma_x(0, kt + 2 - nk, st); dma_x(1, kt + 2 - nk, st);
                 AVX_VMCNT(6);
             } else {
                 AVX_VMCNT(0);
@@ -748,23 +759,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_HALF(1);
             AVX_BAR();
         }
-        if (wm == 0) { AVX_BAR(); }
+        g0 += nk;
         if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); }
 
-        const int em0 = m0, en0 = n0;
-        const int next_tile = ((it + 1) * 8 + xcd) * per_xcd + slot;
-        const bool has_next = next_tile < ntiles;
         const int er = lane >> 3, ec = lane & 7, lc = lane & 15, lg = lane >> 4;
 
         if constexpr (fast_half) {
-            // bias first: a vector load issued after the DMAs could only be waited for together with them
+            // bias from LDS (placed there by LDS-DMA one tile ahead): a global load here could only be waited for together with the
+            // six DMAs of the next tile that are in flight
             f32x4 bvv[2][4];
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bvv[ih][i] = *(const f32x4*)(p.bias + en0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (has_next) { set_tile(next_tile); tile_prologue(); }
+                for (int i = 0; i < 4; ++i) bvv[ih][i] = *(const f32x4*)(ldsbias + (it & 1) * 256 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
             constexpr int HP_LD = 72;
             T* slab = (T*)(smem + 2 * STAGE2 + wid * (16 * HP_LD * 2));
 #pragma unroll
@@ -818,7 +825,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // bias landed (older than the 8 residual loads)
             load_resid(0);
             asm volatile("" ::: "memory");
-            if (has_next) { set_tile(next_tile); tile_prologue(); }
             float* slab = (float*)(smem + 2 * STAGE2 + wid * 4096);   // 16 rows x 64 floats, 16-byte chunk c of row r at slot c ^ r
             const float alpha = p.alpha;
 #pragma unroll
@@ -849,72 +855,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
-        } else {
-            // generic epilogue (fp32 outputs, hook taps, masks): slabs in the stage memory, then the next prologue
-            constexpr int EP_LD = 68;
-            float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
-            const float alpha = p.alpha;
-#pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
-                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
-#pragma unroll
-                for (int jh = 0; jh < 2; ++jh) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            *(f32x4*)(slab + (16 * j + lc) * EP_LD + 16 * i + 4 * lg) = acc[4 * ih + i][2 * jh + j];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const int ml = 8 * ps + er;
-                        const int m = em0 + wn * 64 + 32 * jh + ml;
-                        f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
-                        f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
-                        if (m >= p.M) continue;
-                        v0 += b0; v1 += b1;
-                        if (p.row_zero != nullptr && p.row_zero[m] != 0) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-                        if (p.out_raw) {
-                            *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb) = v0;
-                            *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4) = v1;
-                        }
-                        if (p.resid) {
-                            const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
-                            const f32x4 r1 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf(r0[e], alpha, v0[e]); v1[e] = __builtin_fmaf(r1[e], alpha, v1[e]); }
-                        } else if (p.resid_half) {
-                            const v8 rr = *(const v8*)((const T*)p.resid_half + (int64_t)m * p.ldrh + nb);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rr[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rr[4 + e], alpha, v1[e]); }
-                        }
-                        if (p.gelu) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }
-                        if (p.out_f32) {
-                            *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb) = v0;
-                            *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4) = v1;
-                        }
-                        if (p.out_half) {
-                            v8 h;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
-                            *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-            if (has_next) {
-                AVX_BAR();   // every wave is done with its slab before the stages are refilled
-                set_tile(next_tile);
-                tile_prologue();
-            }
         }
         if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime();
         if (!has_next) break;
         tile = next_tile;
-        stores_behind = overlapped;
     }
 }
 
@@ -938,10 +882,15 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     if (variant == 2 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
     if (variant == 5 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8) || a.K < 2 * BK)) variant = 3;
     if (variant == 5) {
+        // the streaming kernel has the two branch-free epilogues only; everything else runs the tile-per-workgroup kernel
+        const bool fast_half = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.resid_half && !a.row_zero && !ln_fold;
+        const bool fast_resid = a.out_half && a.bias && a.resid_half && !a.gelu && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero && !ln_fold;
+        if (!fast_half && !fast_resid) variant = 2;
+    }
+    if (variant == 5) {
         static bool attr_set5 = false;
         static int n_cu = 0;
         if (!attr_set5) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
             AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
             AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
             int dev = 0;
@@ -952,19 +901,14 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
             attr_set5 = true;
         }
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
-        static const int stag_us10 = getenv("AVEX_AMD_GEMM_STAGGER") ? atoi(getenv("AVEX_AMD_GEMM_STAGGER")) : 0;    // 0.1-us units
-        static const int stag_groups = getenv("AVEX_AMD_GEMM_STAGGER_GROUPS") ? atoi(getenv("AVEX_AMD_GEMM_STAGGER_GROUPS")) : 2;
         avx::GemmArgs a5 = a;
-        a5.stagger_ticks = stag_us10 * 10;
-        a5.stagger_groups = stag_groups;
+        a5.stagger_ticks = 0; a5.stagger_groups = 1;
         int grid = tiles < n_cu ? ((tiles + 7) / 8) * 8 : (n_cu / 8) * 8;
         if (grid < 8) grid = 8;
         if (const char* fg = getenv("AVEX_AMD_GEMM_GRID")) { const int g = atoi(fg); if (g >= 8) grid = (g / 8) * 8; }   // tests: force many tiles per workgroup
-        const bool fast_half = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.resid_half && !a.row_zero;
-        const bool fast_resid = a.out_half && a.bias && a.resid_half && !a.gelu && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero;
+        const bool fast_half = !a.resid_half;
         if (fast_half) hipLaunchKernelGGL((gemm256p_kernel<T, 1>), dim3(grid), dim3(512), LDS5, s, a5);
-        else if (fast_resid) hipLaunchKernelGGL((gemm256p_kernel<T, 2>), dim3(grid), dim3(512), LDS5, s, a5);
-        else hipLaunchKernelGGL((gemm256p_kernel<T, 0>), dim3(grid), dim3(512), LDS5, s, a5);
+        else hipLaunchKernelGGL((gemm256p_kernel<T, 2>), dim3(grid), dim3(512), LDS5, s, a5);
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }
