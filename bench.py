@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--residual", default=os.environ.get("AVEX_AMD_RESIDUAL", "half"), choices=["f32", "half"],
                     help="inter-kernel residual stream: fp32, or the operand type (default; pooled parity unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="tests only: run the launch / barrier / timing / all-gather / JSON control flow on the CPU with gloo and a stub "
+                         "in place of the encoder (no number it prints is a measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,25 +84,40 @@ def main():
         print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
               f"(--nproc-per-node {args.gpus}); see the module docstring", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
+    dry = args.cpu_dry_run
+    if not dry and not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback for the product path)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from avex_amd import build, synth
-    from avex_amd import kernels as K
-    # the library is prebuilt in tree; if it is stale only rank 0 compiles, the others wait for it
-    if rank == 0:
-        build.build(verbose=False)
-    if world > 1:
-        dist.barrier()
     cfg = synth.BEATS_BASE_CFG
-    sd = synth.beats_state_dict(cfg, seed=0)
-    enc = K.BeatsEncoder(cfg, sd, operand_dtype=args.dtype, max_chunk_clips=args.chunk, residual=args.residual)
+    if dry:
+        class _Stub:      # stands in for the encoder in the CPU dry run: per-clip function of the input, [B, 768]
+            def forward(self, wav, want_features=False, want_pooled=True):
+                return {"pooled": wav[:, :768].contiguous() * 2.0}
+        enc, sd = _Stub(), None
+    else:
+        from avex_amd import kernels as K
+        # the library is prebuilt in tree; if it is stale only rank 0 compiles, the others wait for it
+        if rank == 0:
+            build.build(verbose=False)
+        if world > 1:
+            dist.barrier()
+        sd = synth.beats_state_dict(cfg, seed=0)
+        enc = K.BeatsEncoder(cfg, sd, operand_dtype=args.dtype, max_chunk_clips=args.chunk, residual=args.residual)
 
     B = args.batch
     # synthetic clips keyed by global clip index (rank r owns clips [r*B, (r+1)*B))
@@ -118,14 +136,14 @@ def main():
         out = step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -136,7 +154,7 @@ def main():
     # ---- roofline of the dominant kernel (rank 0): HIP events around every launch, same stream ----
     roof = None
     stages = None
-    if rank == 0:
+    if rank == 0 and not dry:
         enc.set_profiling(True)
         enc.forward(wav, want_features=False, want_pooled=True)
         prof = enc.last_profile()
@@ -178,7 +196,9 @@ def main():
                        "model_frac_of_mfma_peak": round(value * FLOP_PER_CLIP / 1e12 / (PEAK_TFLOPS * world), 4)},
             "roofline": roof, "stages_ms": stages,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            line["data"] = "cpu dry run (control flow only, not a measurement)"
+        if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(sd, cfg)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -55,3 +55,23 @@ def test_two_rank_gloo_all_gather(tmp_path, n_clips):
 def test_single_process_is_a_no_op():
     wav = torch.randn(3, 100)
     assert torch.equal(adist.extract_embeddings_sharded(_embed, wav), _embed(wav))
+
+
+def test_bench_multi_rank_control_flow(tmp_path):
+    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per device), on the CPU
+    with gloo and a stub encoder (--cpu-dry-run): rendezvous, rank-0-builds barrier, warm-up, barrier-bracketed timing, MAX over
+    ranks, the per-step all-gather of pooled rows and the single JSON line from rank 0."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--cpu-dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "clips/s"
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert "RCCL all-gather" in d["config"]["workload"]
