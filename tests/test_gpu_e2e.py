@@ -22,7 +22,7 @@ def base_sd():
     return synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0)
 
 
-@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres"])
+@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres"])
 def encoder(request, built_lib, base_sd):
     from avex_amd import kernels as K
     dt = request.param.split("-")[0]
