@@ -26,6 +26,11 @@ class FbankConfig(C.Structure):
                 ("log_floor", C.c_float), ("norm_mean", C.c_float), ("norm_div", C.c_float)]
 
 
+class MelspecConfig(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("hop_length", C.c_int32), ("win_length", C.c_int32), ("n_mels", C.c_int32),
+                ("center", C.c_int32), ("normalize", C.c_int32)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
@@ -63,6 +68,11 @@ SYMBOLS = {
     "avexhip_fbank_plan_destroy": (None, [_P]),
     "avexhip_fbank_num_frames": (C.c_int, [_P, C.c_int64]),
     "avexhip_fbank_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
+    "avexhip_melspec_plan_create": (_P, [C.POINTER(MelspecConfig), _P, _P]),
+    "avexhip_melspec_plan_destroy": (None, [_P]),
+    "avexhip_melspec_num_frames": (C.c_int, [_P, C.c_int64]),
+    "avexhip_melspec_num_bins": (C.c_int, [_P]),
+    "avexhip_melspec_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P]),
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),

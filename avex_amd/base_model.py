@@ -26,8 +26,10 @@ logger = logging.getLogger(__name__)
 class AudioProcessor:
     """Waveform pre-processing selected by an ``AudioConfig`` (reference: data/audio_utils.py:76-179).
 
-    Only ``representation="raw"`` (identity; what every BEATs spec uses) is built in this round;
-    spectrogram representations belong to the EfficientNet row of the scope table and raise.
+    ``"raw"`` is the identity (what every BEATs spec uses).  ``"spectrogram"`` / ``"mel_spectrogram"`` (the EfficientNet
+    frontend: ``torch.stft`` -> power -> ``MelScale`` -> log + per-clip min-max) run on the GPU through
+    ``avexhip_melspec_forward`` (fp32-MFMA DFT, ``avex_amd/csrc/melspec.hip``); like the reference, the result comes back on
+    the device of the input.  There is no CPU implementation: without a GPU these representations raise ``AvexHipError``.
     """
 
     def __init__(self, cfg: AudioConfig) -> None:
@@ -43,16 +45,25 @@ class AudioProcessor:
         self.target_length_seconds = cfg.target_length_seconds
         self.window_selection = cfg.window_selection
         self.center = cfg.center
+        self._plan = None
 
     def __call__(self, waveform: torch.Tensor) -> torch.Tensor:
         if waveform.dim() == 1:
             waveform = waveform.unsqueeze(0)
         if self.representation == "raw":
             return waveform
-        raise NotImplementedError(
-            f"AudioProcessor representation={self.representation!r} is not built in avex_amd yet "
-            "(only 'raw'; the STFT/mel AudioProcessor is the EfficientNet frontend, a later scope row)"
-        )
+        if self.representation not in ("spectrogram", "mel_spectrogram"):
+            raise ValueError(f"Unknown representation: {self.representation}")
+        from . import kernels                     # the HIP library is only needed for the spectrogram representations
+        if self._plan is None:
+            if self.window_type not in ("hann", "hamming"):
+                raise ValueError(f"Unknown window type: {self.window_type}")
+            self._plan = kernels.MelspecPlan(n_fft=self.n_fft, hop_length=self.hop_length, win_length=self.win_length,
+                                             window=self.window_type, n_mels=self.n_mels, sample_rate=self.sr,
+                                             mel=self.representation == "mel_spectrogram", center=self.center, normalize=self.normalize)
+        original = waveform.device
+        x = waveform if waveform.is_cuda else waveform.to(torch.device("cuda", torch.cuda.current_device()))
+        return self._plan(x.to(torch.float32)).to(original)
 
 
 class ModelBase(nn.Module):

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import AvexHipError, BeatsConfig, FbankConfig, GemmArgs, Tensor, check, dtype_code, lib
+from ._capi import AvexHipError, BeatsConfig, FbankConfig, GemmArgs, MelspecConfig, Tensor, check, dtype_code, lib
 
 F32_EPS = 1.1920929e-07
 
@@ -142,6 +142,71 @@ class FbankPlan:
 # ---------------------------------------------------------------------------------------
 # Building blocks (used by the parity tests; the encoder handle calls the same launchers in C++)
 # ---------------------------------------------------------------------------------------
+def stft_window(kind: str, win_length: int) -> np.ndarray:
+    """``torch.hann_window(N)`` / ``torch.hamming_window(N)`` (periodic), fp32 (reference: audio_utils.py:159-164)."""
+    n = np.arange(win_length, dtype=np.float64)
+    if kind == "hann":
+        return (0.5 - 0.5 * np.cos(2.0 * math.pi * n / win_length)).astype(np.float32)
+    if kind == "hamming":
+        return (0.54 - 0.46 * np.cos(2.0 * math.pi * n / win_length)).astype(np.float32)
+    raise ValueError(f"Unknown window type: {kind}")
+
+
+def htk_mel_filterbank(n_freqs: int, n_mels: int, sample_rate: int, f_min: float = 0.0, f_max: Optional[float] = None) -> np.ndarray:
+    """``torchaudio.functional.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk")``
+    = the ``fb`` buffer of ``torchaudio.transforms.MelScale`` as the reference builds it (audio_utils.py:97-101): ``[n_freqs, n_mels]``."""
+    f_max = float(sample_rate // 2) if f_max is None else f_max
+    all_freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    hz2mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    mel2hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    f_pts = mel2hz(np.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2))
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up)).astype(np.float32)
+
+
+class MelspecPlan:
+    """STFT power / mel spectrogram of the reference's ``AudioProcessor`` (audio_utils.py:77-172) on the GPU."""
+
+    def __init__(self, *, n_fft: int, hop_length: int, win_length: Optional[int] = None, window: str = "hann", n_mels: int = 128,
+                 sample_rate: int = 16000, mel: bool = True, center: bool = True, normalize: bool = True) -> None:
+        _capi.require_gpu()
+        win_length = win_length or n_fft
+        self.n_fft, self.hop_length, self.n_bins = n_fft, hop_length, (n_mels if mel else n_fft // 2 + 1)
+        w = stft_window(window, win_length)
+        fb = htk_mel_filterbank(n_fft // 2 + 1, n_mels, sample_rate) if mel else None
+        cfg = MelspecConfig(n_fft, hop_length, win_length, n_mels if mel else 0, int(center), int(normalize))
+        self._normalize = normalize
+        self._h = lib().avexhip_melspec_plan_create(C.byref(cfg), w.ctypes.data, fb.ctypes.data if fb is not None else None)
+        if not self._h:
+            raise AvexHipError(f"melspec_plan_create failed: {_capi.last_error()}")
+
+    def num_frames(self, T: int) -> int:
+        return int(lib().avexhip_melspec_num_frames(self._h, T))
+
+    def __call__(self, wav: torch.Tensor) -> torch.Tensor:
+        _need_cuda(wav)
+        if wav.dim() != 2 or wav.dtype != torch.float32:
+            raise ValueError("wav must be a [B, T] float32 tensor")
+        wav = wav.contiguous()
+        B, T = wav.shape
+        frames = self.num_frames(T)
+        out = torch.empty((B, self.n_bins, frames), dtype=torch.float32, device=wav.device)
+        mm = torch.empty((B, 2), dtype=torch.int32, device=wav.device) if self._normalize else None
+        check(lib().avexhip_melspec_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(out), _ptr(mm), _stream()), "melspec_forward")
+        return out
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().avexhip_melspec_plan_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def wavconv0(wav: torch.Tensor, w: torch.Tensor, gn_w: torch.Tensor, gn_b: torch.Tensor, frames_pad: int, slack_rows: int = 8,
              eps: float = 1e-5, dtype="f16") -> torch.Tensor:
     """wav2vec2 conv layer 0 (Conv1d(1,512,10,5) + GroupNorm over time + GELU) -> half ``[B * frames_pad + slack_rows, 512]``

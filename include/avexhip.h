@@ -80,6 +80,31 @@ int avexhip_fbank_forward_padded(const avexhip_fbank_plan* plan, const float* wa
                                  int64_t wav_stride, const float* clip_offset_dev, int out_frames,
                                  float* out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Frontend: STFT power spectrogram / mel spectrogram of the reference's AudioProcessor
+ * (avex/data/audio_utils.py:77-172): torch.stft(n_fft, hop, win_length, window, center (reflect pad)) -> |.|^2 ->
+ * optional MelScale matrix -> optional _normalize: log(x + 1e-6), then per-clip (x - min) / (max - min + 1e-8).
+ * The transform is a dense fp32-MFMA product with a precomputed, window-folded DFT matrix, so n_fft need not be a
+ * power of two (EfficientNet: 800).  Output [B, n_bins, frames] fp32, n_bins = n_mels or n_fft/2 + 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_melspec_plan avexhip_melspec_plan;
+typedef struct {
+    int32_t n_fft;        /* even, 64..1024 */
+    int32_t hop_length;
+    int32_t win_length;   /* <= n_fft; the window is centre-padded to n_fft like torch.stft */
+    int32_t n_mels;       /* 0: power spectrogram */
+    int32_t center;       /* 1: reflect-pad n_fft/2 on both sides */
+    int32_t normalize;    /* 1: log + per-clip min-max (audio_utils.py:166-172) */
+} avexhip_melspec_config;
+/* window [win_length] fp32; mel_fb [n_fft/2+1, n_mels] fp32 row-major (torchaudio MelScale.fb) or NULL. */
+avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melspec_config* cfg, const float* window, const float* mel_fb);
+void avexhip_melspec_plan_destroy(avexhip_melspec_plan* plan);
+int avexhip_melspec_num_frames(const avexhip_melspec_plan* plan, int64_t T);
+int avexhip_melspec_num_bins(const avexhip_melspec_plan* plan);
+/* minmax_dev: [B, 2] int32 scratch (needed when normalize = 1). */
+int avexhip_melspec_forward(const avexhip_melspec_plan* plan, const float* wav_dev, int B, int64_t T, int64_t wav_stride,
+                            float* out_dev, int* minmax_dev, void* stream);
+
 /* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
  * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):
  *   Conv1d(1, 512, k=10, s=5) -> GroupNorm(512, 512, eps) over time per (clip, channel) -> GELU

@@ -101,6 +101,50 @@ def beats_preprocess(wav: np.ndarray, cfg: Mapping[str, object]) -> np.ndarray:
     return ((fb - mean) / (np.float32(2.0) * std)).astype(np.float32)
 
 
+def stft_power(wav: np.ndarray, n_fft: int, hop: int, win_length: int, window: np.ndarray, center: bool = True) -> np.ndarray:
+    """``torch.stft(..., return_complex=True).abs().pow(2)`` (audio_utils.py:139-148): reflect padding of n_fft // 2 when
+    ``center``, window centre-padded to n_fft, one-sided.  ``[B, T]`` -> ``[B, n_fft // 2 + 1, frames]`` fp32."""
+    x = np.asarray(wav, np.float32)
+    if center:
+        x = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+    w = np.zeros(n_fft, np.float32)
+    lo = (n_fft - win_length) // 2
+    w[lo:lo + win_length] = window
+    frames = 1 + (x.shape[1] - n_fft) // hop
+    idx = np.arange(frames)[:, None] * hop + np.arange(n_fft)[None, :]
+    spec = np.fft.rfft((x[:, idx] * w).astype(np.float32), axis=-1).astype(np.complex64)
+    return (np.abs(spec).astype(np.float32) ** np.float32(2.0)).transpose(0, 2, 1)
+
+
+def htk_mel_fb(n_freqs: int, n_mels: int, sample_rate: int) -> np.ndarray:
+    """``torchaudio.transforms.MelScale(n_mels, sample_rate, n_stft).fb`` (audio_utils.py:97-101; torchaudio defaults f_min 0,
+    f_max sr // 2, norm None, mel_scale "htk"), restated from torchaudio's documented ``melscale_fbanks``: triangles on points
+    equally spaced in mel(f) = 2595 log10(1 + f / 700), evaluated at the linear bin frequencies.  UNPINNED (torchaudio absent)."""
+    all_freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    m = np.linspace(0.0, 2595.0 * np.log10(1.0 + (sample_rate // 2) / 700.0), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    return np.maximum(0.0, np.minimum(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:])).astype(np.float32)
+
+
+def audio_processor(wav: np.ndarray, *, n_fft: int, hop: int, win_length: Optional[int] = None, window: str = "hann", n_mels: int = 128,
+                    sample_rate: int = 16000, representation: str = "mel_spectrogram", center: bool = True,
+                    normalize: bool = True) -> np.ndarray:
+    """``AudioProcessor.__call__`` (audio_utils.py:106-172) for the spectrogram representations."""
+    win_length = win_length or n_fft
+    n = np.arange(win_length, dtype=np.float64)
+    w = ((0.5 - 0.5 * np.cos(2 * np.pi * n / win_length)) if window == "hann" else (0.54 - 0.46 * np.cos(2 * np.pi * n / win_length))).astype(np.float32)
+    x = stft_power(wav, n_fft, hop, win_length, w, center)
+    if representation == "mel_spectrogram":
+        x = np.einsum("fm,bft->bmt", htk_mel_fb(n_fft // 2 + 1, n_mels, sample_rate), x).astype(np.float32)     # MelScale: fb^T @ spec
+    if normalize:
+        x = np.log(x + np.float32(1e-6)).astype(np.float32)
+        mn = x.min(axis=(1, 2), keepdims=True); mx = x.max(axis=(1, 2), keepdims=True)
+        x = (x - mn) / (mx - mn + np.float32(1e-8))
+    return x.astype(np.float32)
+
+
 def eat_preprocess(wav: np.ndarray, *, sample_rate: int = 16000, target_length: int = 1024, n_mels: int = 128,
                    norm_mean: float = -4.268, norm_std: float = 4.569, frame_shift_ms: int = 10) -> np.ndarray:
     """``EATAudioProcessor.__call__`` (avex/models/eat/audio_processor.py:72-143): per clip ``mono - mono.mean()`` (:107),

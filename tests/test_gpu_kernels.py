@@ -459,3 +459,47 @@ def test_aves_encoder_matches_oracle(built_lib, samples):
     for i in (0, 1):
         name = f"model.encoder.transformer.layers.{i}.feed_forward.output_dense"
         assert rel_l2(r["hooks"][i].cpu().numpy().mean(1), taps[name].mean(1)) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Spectrogram / mel frontend of the reference's AudioProcessor
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("samples", [16000, 160000])
+def test_melspec_matches_oracle_effnet_config(built_lib, samples):
+    """EfficientNet settings (n_fft 800, hop 160, periodic Hann, 128 HTK mels, centre, log + min-max) through the C ABI vs
+    the NumPy restatement whose STFT stage is pinned against torch.stft; and the torch.stft power directly for the plain
+    spectrogram."""
+    from avex_amd import kernels as K
+    x = synth.noise_clips(2, samples, seed=61) * np.float32(3.0)
+    xd = _dev(x)
+    plan = K.MelspecPlan(n_fft=800, hop_length=160, n_mels=128, normalize=True)
+    y = plan(xd)
+    ref = O.audio_processor(x, n_fft=800, hop=160)
+    assert y.shape == ref.shape == (2, 128, 1 + samples // 160)
+    assert np.abs(y.cpu().numpy() - ref).max() < 2e-4            # values in [0, 1] after min-max
+    raw = K.MelspecPlan(n_fft=800, hop_length=160, n_mels=128, normalize=False)(xd).cpu().numpy()
+    ref_raw = O.audio_processor(x, n_fft=800, hop=160, normalize=False)
+    assert rel_l2(raw, ref_raw) < 2e-5
+    spec = K.MelspecPlan(n_fft=800, hop_length=160, mel=False, normalize=False)(xd).cpu().numpy()
+    ts = torch.stft(torch.from_numpy(x), n_fft=800, hop_length=160, win_length=800, window=torch.hann_window(800), center=True,
+                    return_complex=True).abs().pow(2).numpy()
+    assert spec.shape == ts.shape == (2, 401, 1 + samples // 160)
+    assert np.abs(spec - ts).max() <= 3e-5 * ts.max()
+
+
+def test_melspec_other_configs_and_processor_mirror(built_lib):
+    from avex_amd import kernels as K
+    from avex_amd.base_model import AudioProcessor
+    from avex_amd.configs import AudioConfig
+    x = synth.noise_clips(3, 20000, seed=62)
+    y = K.MelspecPlan(n_fft=512, hop_length=128, win_length=400, window="hamming", n_mels=64, center=False, normalize=True)(_dev(x)).cpu().numpy()
+    ref = O.audio_processor(x, n_fft=512, hop=128, win_length=400, window="hamming", n_mels=64, center=False)
+    assert y.shape == ref.shape and np.abs(y - ref).max() < 2e-4
+    proc = AudioProcessor(AudioConfig(sample_rate=16000, n_fft=800, hop_length=160, win_length=800, window="hann", n_mels=128,
+                                      representation="mel_spectrogram", normalize=True, center=True))
+    out = proc(torch.from_numpy(x))                                  # CPU in -> CPU out, like the reference
+    assert not out.is_cuda and out.shape == (3, 128, 126)
+    assert np.abs(out.numpy() - O.audio_processor(x, n_fft=800, hop=160)).max() < 2e-4
+    from avex_amd._capi import AvexHipError
+    with pytest.raises(AvexHipError):
+        K.MelspecPlan(n_fft=2048, hop_length=512)                     # beyond the built sizes: refuses loudly

@@ -159,3 +159,25 @@ def test_eat_frontend_oracle_known_answers():
     z = O.eat_preprocess(x, norm_mean=0.0, norm_std=1.0)          # per-sample statistics branch
     assert abs(float(z[0].mean())) < 1e-5 and abs(float(z[0].std(ddof=1)) - 0.5) < 1e-4
 
+
+
+def test_stft_oracle_matches_torch_stft():
+    """The STFT stage of the spectrogram frontend is pinned against torch.stft itself (the call the reference makes,
+    audio_utils.py:139-148): EfficientNet settings (n_fft 800, hop 160, periodic Hann, centre / reflect) and a hamming,
+    uncentred, shorter-window variant.  The MelScale matrix has no such pin (torchaudio absent): shape and partition checks."""
+    import torch
+    from avex_amd import synth
+    x = synth.noise_clips(2, 16000, seed=51)
+    for n_fft, hop, win, kind, center in ((800, 160, 800, "hann", True), (512, 128, 400, "hamming", False)):
+        tw = torch.hann_window(win) if kind == "hann" else torch.hamming_window(win)
+        ref = torch.stft(torch.from_numpy(x), n_fft=n_fft, hop_length=hop, win_length=win, window=tw, center=center, return_complex=True).abs().pow(2).numpy()
+        got = O.stft_power(x, n_fft, hop, win, tw.numpy(), center)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-5 * ref.max()
+    fb = O.htk_mel_fb(401, 128, 16000)
+    assert fb.shape == (401, 128) and (fb >= 0).all() and fb.max() <= 1.0
+    assert (fb > 0).sum(0).min() >= 1                       # every triangle reaches at least one bin at n_fft 800
+    peaks = fb.argmax(0)
+    assert (np.diff(peaks) >= 0).all() and peaks[0] >= 0 and peaks[-1] <= 400
+    y = O.audio_processor(x, n_fft=800, hop=160)
+    assert y.shape == (2, 128, 101) and abs(float(y[0].min())) < 1e-7 and abs(float(y[0].max()) - 1.0) < 1e-6
