@@ -73,6 +73,9 @@ SYMBOLS = {
     "avexhip_melspec_num_frames": (C.c_int, [_P, C.c_int64]),
     "avexhip_melspec_num_bins": (C.c_int, [_P]),
     "avexhip_melspec_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P]),
+    "avexhip_effnet_stem": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "avexhip_effnet_dwconv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
+    "avexhip_effnet_se": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),

@@ -108,10 +108,26 @@ static __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 u = (f32x2)(0.5f) - q;
     return __builtin_elementwise_fma(ax, u, x * (f32x2)(0.5f));
 }
+// SiLU x * sigmoid(x) = x / (1 + 2^(-x log2 e)) (EfficientNet's activation), two elements at a time
+static __device__ __forceinline__ f32x2 silu2(f32x2 x) {
+    const f32x2 t = x * (f32x2)(-1.4426950408889634f);
+    f32x2 d;
+    d[0] = 1.0f + __builtin_amdgcn_exp2f(t[0]); d[1] = 1.0f + __builtin_amdgcn_exp2f(t[1]);
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(d[0]); r[1] = __builtin_amdgcn_rcpf(d[1]);
+    return x * r;
+}
+// activation selector of the GEMM epilogues: 1 = exact-erf GELU, 2 = SiLU
+static __device__ __forceinline__ f32x4 act4(f32x4 v, int act);
 static __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
     const f32x2 a = gelu_erf2((f32x2){v[0], v[1]}), b = gelu_erf2((f32x2){v[2], v[3]});
     return (f32x4){a[0], a[1], b[0], b[1]};
 }
+static __device__ __forceinline__ f32x4 silu4(f32x4 v) {
+    const f32x2 a = silu2((f32x2){v[0], v[1]}), b = silu2((f32x2){v[2], v[3]});
+    return (f32x4){a[0], a[1], b[0], b[1]};
+}
+static __device__ __forceinline__ f32x4 act4(f32x4 v, int act) { return act == 2 ? silu4(v) : gelu_erf4(v); }
 
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

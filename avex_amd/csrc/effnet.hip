@@ -1,0 +1,249 @@
+// EfficientNet-B0 building blocks that are not GEMMs (avex/models/efficientnet.py:55-66 -> torchvision efficientnet_b0),
+// for gfx950.  Activations are NHWC in the operand type with the channel count padded to a multiple of 128 (padding channels
+// stay exactly zero through every layer), so the 1x1 convolutions are plain avexhip_gemm calls over [B*H*W, C] rows with
+// BatchNorm folded into weight and bias and SiLU / residual in the epilogue.  What remains is bandwidth-bound:
+//   stem_conv      Conv2d(3 -> 32, 3x3, stride 2, pad 1) on the mel image whose three input channels are copies of one
+//                  (efficientnet.py:133-135: x.repeat(1, 3, 1, 1)), i.e. a 1-channel convolution with channel-summed weights,
+//                  + folded BatchNorm + SiLU, fp32 [B, H, W] in -> NHWC half out
+//   dwconv         depthwise k x k (3 or 5), stride 1 or 2, "same" padding, folded BatchNorm + SiLU, and the
+//                  squeeze-excitation average pool accumulated on the way out (fp32 atomics per clip and channel)
+//   se_fc          the two tiny fully connected layers of squeeze-excitation per clip: sigmoid(W2 silu(W1 mean + b1) + b2)
+//   scale_channels x[b, p, c] *= s[b, c] (the excitation), in place
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu1(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+
+// one thread: one output pixel x 8 consecutive output channels
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, int H, int W, int Ho, int Wo,
+                                                        const float* __restrict__ w /*[9][Cp]*/, const float* __restrict__ bias,
+                                                        int Cp, T* __restrict__ out, float* __restrict__ raw /*[B,Ho,Wo,Cp] or null*/) {
+    typedef typename Half<T>::v8 v8;
+    const int cg = Cp >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t npix = (int64_t)gridDim.y * 0 + (int64_t)Ho * Wo;
+    const int b = blockIdx.y;
+    if (idx >= npix * cg) return;
+    const int c8 = (int)(idx % cg) * 8;
+    const int64_t pix = idx / cg;
+    const int oy = (int)(pix / Wo), ox = (int)(pix - (int64_t)oy * Wo);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const float* src = img + (int64_t)b * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 + kx - 1;
+            if (ix < 0 || ix >= W) continue;
+            const float x = src[(int64_t)iy * W + ix];
+            const f32x4 w0 = *(const f32x4*)(w + (ky * 3 + kx) * Cp + c8), w1 = *(const f32x4*)(w + (ky * 3 + kx) * Cp + c8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = __builtin_fmaf(x, w0[e], acc[e]); acc[4 + e] = __builtin_fmaf(x, w1[e], acc[4 + e]); }
+        }
+    }
+    const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * Cp + c8;
+    v8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float y = acc[e] + bias[c8 + e];
+        if (raw) raw[o + e] = y;
+        h[e] = Half<T>::from(silu1(y));
+    }
+    *(v8*)(out + o) = h;
+}
+
+// one thread: 8 channels, PIX consecutive output pixels along x of one row; squeeze sums via atomics
+template <typename T, int KS, int ST>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
+                                                     const float* __restrict__ w /*[KS*KS][Cp]*/, const float* __restrict__ bias,
+                                                     T* __restrict__ out, float* __restrict__ pool /*[B][Cp]*/) {
+    typedef typename Half<T>::v8 v8;
+    constexpr int PAD = (KS - 1) / 2, PIX = 4;
+    const int cg = Cp >> 3;
+    const int xg = (Wo + PIX - 1) / PIX;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const bool active = idx < (int64_t)Ho * xg * cg;
+    const int c8 = (int)(idx % cg) * 8;
+    const int64_t t = idx / cg;
+    const int oy = (int)(t / xg), ox0 = (int)(t - (int64_t)oy * xg) * PIX;
+    float psum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+    if (active) {
+        float acc[PIX][8];
+#pragma unroll
+        for (int p = 0; p < PIX; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+        const T* src = in + (int64_t)b * H * W * Cp + c8;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = oy * ST + ky - PAD;
+            if (iy < 0 || iy >= H) continue;
+            // the input columns this thread touches: ox0*ST - PAD .. (ox0+PIX-1)*ST - PAD + KS - 1
+            constexpr int NCOL = (PIX - 1) * ST + KS;
+            v8 col[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) {
+                const int ix = ox0 * ST - PAD + q;
+                if (ix >= 0 && ix < W) col[q] = *(const v8*)(src + ((int64_t)iy * W + ix) * Cp);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) col[q][e] = (T)0.0f;
+                }
+            }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 w0 = *(const f32x4*)(w + (ky * KS + kx) * Cp + c8), w1 = *(const f32x4*)(w + (ky * KS + kx) * Cp + c8 + 4);
+#pragma unroll
+                for (int p = 0; p < PIX; ++p) {
+                    const v8 x = col[p * ST + kx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[p][e] = __builtin_fmaf((float)x[e], w0[e], acc[p][e]);
+                        acc[p][4 + e] = __builtin_fmaf((float)x[4 + e], w1[e], acc[p][4 + e]);
+                    }
+                }
+            }
+        }
+        const f32x4 b0 = *(const f32x4*)(bias + c8), b1 = *(const f32x4*)(bias + c8 + 4);
+#pragma unroll
+        for (int p = 0; p < PIX; ++p) {
+            const int ox = ox0 + p;
+            if (ox >= Wo) break;
+            v8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = silu1(acc[p][e] + (e < 4 ? b0[e] : b1[e - 4]));
+                h[e] = Half<T>::from(y);
+                psum[e] += (float)h[e];                    // the pool sees what the next layer will read
+            }
+            *(v8*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * Cp + c8) = h;
+        }
+    }
+    // squeeze: lanes of a wave hold different channel groups when cg < 64, the same group every cg lanes
+    if (pool) {
+        __shared__ float red[256 * 8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = psum[e];
+        __syncthreads();
+        // thread j < min(256, cg) * 8 sums one (channel group, e) column over the block's threads with the same idx % cg
+        const int ncol = (cg < 256 ? cg : 256) * 8;
+        const int first = (int)(((int64_t)blockIdx.x * 256) % cg);      // channel group of thread 0
+        for (int j = threadIdx.x; j < ncol; j += 256) {
+            const int g = j >> 3, e = j & 7;                            // g: offset from thread 0's group
+            float s = 0.f;
+            for (int q = g; q < 256; q += cg) s += red[q * 8 + e];
+            const int grp = (first + g) % cg;
+            if (s != 0.f) atomicAdd(pool + (int64_t)b * Cp + grp * 8 + e, s);
+        }
+    }
+}
+
+// s[b][c] = sigmoid(W2[c,:] . silu(W1 mean_b + b1) + b2[c]);   one workgroup per clip
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pool, float inv_hw, int C, int Cp, int Cs,
+                                                    const float* __restrict__ w1 /*[Cs][C]*/, const float* __restrict__ b1,
+                                                    const float* __restrict__ w2 /*[C][Cs]*/, const float* __restrict__ b2,
+                                                    float* __restrict__ scale /*[B][Cp]*/) {
+    __shared__ float mean[2048];
+    __shared__ float hid[512];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) mean[c] = pool[(int64_t)b * Cp + c] * inv_hw;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < Cs; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = __builtin_fmaf(w1[(int64_t)j * C + c], mean[c], s);
+        s = wave_sum(s);
+        if (lane == 0) hid[j] = silu1(s + b1[j]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cp; c += 256) {
+        float v = 0.f;
+        if (c < C) {
+            float s = b2[c];
+            for (int j = 0; j < Cs; ++j) s = __builtin_fmaf(w2[(int64_t)c * Cs + j], hid[j], s);
+            v = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * s));
+        }
+        scale[(int64_t)b * Cp + c] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, int64_t hw, int Cp, const float* __restrict__ scale) {
+    typedef typename Half<T>::v8 v8;
+    const int cg = Cp >> 3;
+    const int b = blockIdx.y;
+    const int64_t n = hw * cg;
+    T* p = x + (int64_t)b * hw * Cp;
+    const float* s = scale + (int64_t)b * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(i % cg) * 8;
+        v8 v = *(v8*)(p + i * 8);
+        const f32x4 s0 = *(const f32x4*)(s + c8), s1 = *(const f32x4*)(s + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = Half<T>::from((float)v[e] * s0[e]); v[4 + e] = Half<T>::from((float)v[4 + e] * s1[e]); }
+        *(v8*)(p + i * 8) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int avexhip_effnet_stem(const float* img_dev, int B, int H, int W, const float* w_dev, const float* bias_dev, int Cp,
+                                   void* out_dev, float* raw_dev, int dtype, void* stream) {
+    AVX_REQUIRE(img_dev && w_dev && bias_dev && out_dev, "effnet_stem: null argument");
+    AVX_REQUIRE(B > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "effnet_stem: bad shape");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t n = (int64_t)Ho * Wo * (Cp / 8);
+    const dim3 grid((unsigned)((n + 255) / 256), B);
+    if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(stem_conv_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, img_dev, H, W, Ho, Wo, w_dev, bias_dev, Cp, (__bf16*)out_dev, raw_dev);
+    else hipLaunchKernelGGL(stem_conv_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, img_dev, H, W, Ho, Wo, w_dev, bias_dev, Cp, (_Float16*)out_dev, raw_dev);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+template <typename T>
+static int dw_launch(const void* in, int B, int H, int W, int Cp, int k, int st, const float* w, const float* bias, void* out, float* pool, hipStream_t s) {
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
+    const int64_t n = (int64_t)Ho * ((Wo + 3) / 4) * (Cp / 8);
+    const dim3 grid((unsigned)((n + 255) / 256), B);
+    if (pool) AVX_HIP_CHECK(hipMemsetAsync(pool, 0, sizeof(float) * (size_t)B * Cp, s));
+#define AVX_DW(KS, ST) hipLaunchKernelGGL((dwconv_kernel<T, KS, ST>), grid, dim3(256), 0, s, (const T*)in, H, W, Ho, Wo, Cp, w, bias, (T*)out, pool)
+    if (k == 3 && st == 1) AVX_DW(3, 1);
+    else if (k == 3 && st == 2) AVX_DW(3, 2);
+    else if (k == 5 && st == 1) AVX_DW(5, 1);
+    else if (k == 5 && st == 2) AVX_DW(5, 2);
+    else { avexhip_set_error("effnet_dwconv: kernel %d stride %d not built (3 or 5, stride 1 or 2)", k, st); return AVEXHIP_ERR_INVALID; }
+#undef AVX_DW
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+extern "C" int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, int Cp, int k, int stride, const float* w_dev,
+                                     const float* bias_dev, void* out_dev, float* pool_dev, int dtype, void* stream) {
+    AVX_REQUIRE(in_dev && w_dev && bias_dev && out_dev, "effnet_dwconv: null argument");
+    AVX_REQUIRE(B > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "effnet_dwconv: bad shape");
+    if (dtype == AVEXHIP_BF16) return dw_launch<__bf16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, (hipStream_t)stream);
+    return dw_launch<_Float16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, int Cs, const float* w1_dev, const float* b1_dev,
+                                 const float* w2_dev, const float* b2_dev, float* scale_dev, void* x_dev, int dtype, void* stream) {
+    AVX_REQUIRE(pool_dev && w1_dev && b1_dev && w2_dev && b2_dev && scale_dev && x_dev, "effnet_se: null argument");
+    AVX_REQUIRE(B > 0 && hw > 0 && C > 0 && C <= 2048 && Cp >= C && Cp % 8 == 0 && Cs > 0 && Cs <= 512, "effnet_se: bad shape C=%d Cp=%d Cs=%d", C, Cp, Cs);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), 0, s, pool_dev, 1.0f / (float)hw, C, Cp, Cs, w1_dev, b1_dev, w2_dev, b2_dev, scale_dev);
+    const dim3 grid(512, B);
+    if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(scale_channels_kernel<__bf16>, grid, dim3(256), 0, s, (__bf16*)x_dev, hw, Cp, scale_dev);
+    else hipLaunchKernelGGL(scale_channels_kernel<_Float16>, grid, dim3(256), 0, s, (_Float16*)x_dev, hw, Cp, scale_dev);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}

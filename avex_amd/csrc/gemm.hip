@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
                 const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v = r * alpha + v;
             }
-            if (p.gelu) v = gelu_erf4(v);
+            if (p.gelu) v = act4(v, p.gelu);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
                 v4 h;
@@ -242,7 +242,7 @@ static __device__ __forceinline__ float seg8_sum(float v) {
     return v;
 }
 
-template <typename T, bool GELU, bool LNA>
+template <typename T, int GELU, bool LNA>   // GELU: 0 none, 1 exact-erf GELU, 2 SiLU
 static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid, int wm,
                                                      int wn, int lane, int m0, int n0) {
     typedef typename Half<T>::v8 v8;
@@ -275,7 +275,7 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
                 } else {
                     v = acc[4 * ih + i][j] + bv[i];
                 }
-                if (GELU) v = gelu_erf4(v);
+                if (GELU) v = (GELU == 2) ? silu4(v) : gelu_erf4(v);
                 v4 h;
                 h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
                 *(v4*)(slab + (16 * j + lc) * HP_LD + 16 * i + 4 * lg) = h;
@@ -510,11 +510,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     if (p.out_half && p.bias && !p.out_f32 && !p.out_raw && !p.resid && !p.resid_half && !p.lnr_y && !p.stats_out && !p.row_zero) {
         // Half-only outputs with bias and no residual (QKV, fc1 = 3/4 of the K = 768 work).
         if (p.ln_stats) {
-            if (p.gelu) epilogue_half<T, true, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else epilogue_half<T, false, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            if (p.gelu == 1) epilogue_half<T, 1, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else if (p.gelu == 2) epilogue_half<T, 2, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else epilogue_half<T, 0, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
         } else {
-            if (p.gelu) epilogue_half<T, true, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else epilogue_half<T, false, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            if (p.gelu == 1) epilogue_half<T, 1, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else if (p.gelu == 2) epilogue_half<T, 2, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
+            else epilogue_half<T, 0, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
         }
     } else if (p.out_half && p.bias && (p.resid_half || p.lnr_y) && !p.ln_stats && !p.gelu && !p.out_f32 && !p.out_raw && !p.resid && !p.row_zero) {
         if (p.lnr_y) {
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                             v1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[4 + e], st.x, st.y), lg1[e], __builtin_fmaf(alpha, lb1[e], b1[e])) + a1[e];
                         }
                     }
-                    if (p.gelu) { v0 = gelu_erf4(v0); v1 = gelu_erf4(v1); }
+                    if (p.gelu) { v0 = act4(v0, p.gelu); v1 = act4(v1, p.gelu); }
                     if (p.out_f32) {
                         *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb) = v0;
                         *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4) = v1;
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         f32x4 v = acc[4 * ih + i][j] + bv[i];
-                        if (p.gelu) v = gelu_erf4(v);
+                        if (p.gelu) v = act4(v, p.gelu);
                         v4 h;
                         h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
                         *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;

@@ -207,6 +207,45 @@ class MelspecPlan:
             pass
 
 
+def effnet_stem(img: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, dtype="f16", want_raw: bool = False):
+    """``[B, H, W]`` fp32 image -> NHWC half ``[B, Ho, Wo, Cp]`` (3x3 stride-2 stem with folded BatchNorm + SiLU); ``w [9, Cp]``."""
+    _need_cuda(img, w, bias)
+    code = dtype_code(dtype)
+    img = img.contiguous()
+    B, H, W = img.shape
+    Cp = w.shape[1]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B, Ho, Wo, Cp), dtype=half_torch_dtype(code), device=img.device)
+    raw = torch.empty((B, Ho, Wo, Cp), dtype=torch.float32, device=img.device) if want_raw else None
+    check(lib().avexhip_effnet_stem(_ptr(img), B, H, W, _ptr(w.contiguous()), _ptr(bias), Cp, _ptr(out), _ptr(raw), code, _stream()), "effnet_stem")
+    return (out, raw) if want_raw else out
+
+
+def effnet_dwconv(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int, stride: int, want_pool: bool = True):
+    """Depthwise ``k x k`` conv (+ folded BN + SiLU) on NHWC half ``[B, H, W, Cp]``; returns (out, channel sums ``[B, Cp]`` fp32)."""
+    _need_cuda(x, w, bias)
+    code = _capi.F16 if x.dtype == torch.float16 else _capi.BF16
+    x = x.contiguous()
+    B, H, W, Cp = x.shape
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cp), dtype=x.dtype, device=x.device)
+    pool = torch.empty((B, Cp), dtype=torch.float32, device=x.device) if want_pool else None
+    check(lib().avexhip_effnet_dwconv(_ptr(x), B, H, W, Cp, k, stride, _ptr(w.contiguous()), _ptr(bias), _ptr(out), _ptr(pool), code, _stream()), "effnet_dwconv")
+    return out, pool
+
+
+def effnet_se(x: torch.Tensor, pool: torch.Tensor, C: int, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """Squeeze-excitation on NHWC half ``x`` IN PLACE from its channel sums; returns the ``[B, Cp]`` scales."""
+    _need_cuda(x, pool, w1, w2)
+    code = _capi.F16 if x.dtype == torch.float16 else _capi.BF16
+    B, H, W, Cp = x.shape
+    scale = torch.empty((B, Cp), dtype=torch.float32, device=x.device)
+    check(lib().avexhip_effnet_se(_ptr(pool), B, H * W, C, Cp, w1.shape[0], _ptr(w1.contiguous()), _ptr(b1), _ptr(w2.contiguous()), _ptr(b2),
+                                  _ptr(scale), _ptr(x), code, _stream()), "effnet_se")
+    return scale
+
+
 def wavconv0(wav: torch.Tensor, w: torch.Tensor, gn_w: torch.Tensor, gn_b: torch.Tensor, frames_pad: int, slack_rows: int = 8,
              eps: float = 1e-5, dtype="f16") -> torch.Tensor:
     """wav2vec2 conv layer 0 (Conv1d(1,512,10,5) + GroupNorm over time + GELU) -> half ``[B * frames_pad + slack_rows, 512]``
@@ -242,7 +281,7 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          resid: Optional[torch.Tensor] = None, resid_half: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         gelu: bool = False,
+         gelu: bool = False, silu: bool = False,
          out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0,
          ln_stats: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
          lnr_y: Optional[torch.Tensor] = None, lnr_stats: Optional[torch.Tensor] = None,
@@ -278,7 +317,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     elif resid_half is not None:
         resid_half = resid_half.contiguous()
         args.resid_half, args.ldrh = _ptr(resid_half), N
-    args.alpha, args.gelu, args.variant = alpha, int(gelu), variant
+    args.alpha, args.gelu, args.variant = alpha, (2 if silu else int(gelu)), variant
     if out_f32:
         res["f32"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
         args.out_f32, args.ldo = _ptr(res["f32"]), N

@@ -216,6 +216,51 @@ def aves_state_dict(cfg: Mapping[str, object] = AVES_BASE_CFG, seed: int = 0) ->
     return sd
 
 
+# torchvision efficientnet_b0: (expand ratio, kernel, stride, in, out, layers) per stage
+EFFNET_B0_STAGES = [(1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3), (6, 5, 1, 80, 112, 3),
+                    (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1)]
+
+
+def effnet_b0_state_dict(seed: int = 0, stages=EFFNET_B0_STAGES, head: int = 1280) -> Dict[str, np.ndarray]:
+    """Synthetic EfficientNet-B0 ``features`` state dict (fp32 numpy) with torchvision's key names under the wrapper's ``model.``
+    prefix (efficientnet.py:57): Conv2dNormActivation = ``.0`` conv (no bias) + ``.1`` BatchNorm2d; MBConv ``block`` =
+    [expand], depthwise, SqueezeExcitation (fc1 / fc2 1x1 convs with bias, squeeze = in // 4), project.  BatchNorm running
+    statistics and affines are non-trivial so the folding is exercised."""
+    sd: Dict[str, np.ndarray] = {}
+    pre = "model."
+
+    def conv(name, cout, cin, k):
+        sd[pre + name + ".weight"] = normal("effnet." + name, (cout, cin, k, k), math.sqrt(2.0 / (cin * k * k)), seed)
+
+    def bn(name, c):
+        sd[pre + name + ".weight"] = (1.0 + normal("effnet." + name + ".w", (c,), 0.1, seed)).astype(np.float32)
+        sd[pre + name + ".bias"] = normal("effnet." + name + ".b", (c,), 0.1, seed)
+        sd[pre + name + ".running_mean"] = normal("effnet." + name + ".m", (c,), 0.1, seed)
+        sd[pre + name + ".running_var"] = (1.0 + 0.3 * np.abs(normal("effnet." + name + ".v", (c,), 1.0, seed))).astype(np.float32)
+        sd[pre + name + ".num_batches_tracked"] = np.zeros((), np.int64)
+
+    conv("features.0.0", stages[0][3], 3, 3); bn("features.0.1", stages[0][3])
+    for si, (er, k, _s, cin, cout, n) in enumerate(stages, start=1):
+        for j in range(n):
+            ci = cin if j == 0 else cout
+            ce = ci * er
+            p = f"features.{si}.{j}.block."
+            d = 0
+            if er != 1:
+                conv(p + "0.0", ce, ci, 1); bn(p + "0.1", ce); d = 1
+            sd[pre + p + f"{d}.0.weight"] = normal("effnet." + p + "dw", (ce, 1, k, k), math.sqrt(2.0 / (k * k)), seed)
+            bn(p + f"{d}.1", ce)
+            cs = max(1, ci // 4)
+            sd[pre + p + f"{d + 1}.fc1.weight"] = normal("effnet." + p + "fc1", (cs, ce, 1, 1), math.sqrt(1.0 / ce), seed)
+            sd[pre + p + f"{d + 1}.fc1.bias"] = normal("effnet." + p + "fc1b", (cs,), 0.1, seed)
+            sd[pre + p + f"{d + 1}.fc2.weight"] = normal("effnet." + p + "fc2", (ce, cs, 1, 1), math.sqrt(1.0 / cs), seed)
+            sd[pre + p + f"{d + 1}.fc2.bias"] = normal("effnet." + p + "fc2b", (ce,), 0.5, seed)
+            conv(p + f"{d + 2}.0", cout, ce, 1); bn(p + f"{d + 2}.1", cout)
+    last = len(stages) + 1
+    conv(f"features.{last}.0", head, stages[-1][4], 1); bn(f"features.{last}.1", head)
+    return sd
+
+
 # ----------------------------------------------------------------------------------
 # Synthetic clips (BASELINE.md §3 "Inputs")
 # ----------------------------------------------------------------------------------

@@ -105,6 +105,22 @@ int avexhip_melspec_num_bins(const avexhip_melspec_plan* plan);
 int avexhip_melspec_forward(const avexhip_melspec_plan* plan, const float* wav_dev, int B, int64_t T, int64_t wav_stride,
                             float* out_dev, int* minmax_dev, void* stream);
 
+/* EfficientNet-B0 building blocks that are not GEMMs (avex/models/efficientnet.py:55-66 -> torchvision efficientnet_b0).
+ * Activations are NHWC half with channels padded to Cp (multiple of 128; padding channels stay zero); 1x1 convolutions
+ * are avexhip_gemm calls with BatchNorm folded into weight/bias and gelu = 2 (SiLU).
+ *  stem:   img [B, H, W] fp32 (the mel image; the reference feeds three copies of it, efficientnet.py:133-135) ->
+ *          Conv2d(3->32, 3x3, s2, p1) with channel-summed, BN-folded weights w [9, Cp] + bias [Cp] + SiLU -> [B, Ho, Wo, Cp];
+ *          raw_dev (optional, fp32 [B, Ho, Wo, Cp]) receives the pre-activation values.
+ *  dwconv: depthwise k x k (3 | 5), stride (1 | 2), padding (k-1)/2, w [k*k, Cp] BN-folded, + SiLU; pool_dev [B, Cp] fp32
+ *          (optional) receives the per-clip channel sums of the output (squeeze of squeeze-excitation).
+ *  se:     scale[b, c] = sigmoid(W2 silu(W1 (pool / hw) + b1) + b2), then x[b, :, c] *= scale[b, c] in place. */
+int avexhip_effnet_stem(const float* img_dev, int B, int H, int W, const float* w_dev, const float* bias_dev, int Cp,
+                        void* out_dev, float* raw_dev, int dtype, void* stream);
+int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, int Cp, int k, int stride, const float* w_dev,
+                          const float* bias_dev, void* out_dev, float* pool_dev, int dtype, void* stream);
+int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, int Cs, const float* w1_dev, const float* b1_dev,
+                      const float* w2_dev, const float* b2_dev, float* scale_dev, void* x_dev, int dtype, void* stream);
+
 /* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
  * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):
  *   Conv1d(1, 512, k=10, s=5) -> GroupNorm(512, 512, eps) over time per (clip, channel) -> GELU
@@ -137,7 +153,7 @@ typedef struct {
     const float* bias;
     const float* resid; int64_t ldr; float alpha;   /* fp32 residual, or ... */
     const void*  resid_half; int64_t ldrh;          /* ... residual in the operand type (resid == NULL) */
-    int32_t gelu;
+    int32_t gelu;                      /* activation after bias (+ residual): 0 none, 1 exact-erf GELU, 2 SiLU */
     float* out_f32;  int64_t ldo;
     void*  out_half; int64_t ldh;
     float* out_raw;  int64_t ldraw;

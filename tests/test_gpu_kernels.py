@@ -503,3 +503,57 @@ def test_melspec_other_configs_and_processor_mirror(built_lib):
     from avex_amd._capi import AvexHipError
     with pytest.raises(AvexHipError):
         K.MelspecPlan(n_fft=2048, hop_length=512)                     # beyond the built sizes: refuses loudly
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# EfficientNet-B0: parity unpinned vs torchvision (absent); checker = oracle/effnet_oracle.py
+# ------------------------------------------------------------------------------------------------------------------------
+def test_effnet_blocks_match_oracle(built_lib):
+    """Stem, depthwise (3x3 s1, 5x5 s2) + squeeze pool, squeeze-excitation against NumPy on the same folded parameters."""
+    from avex_amd import kernels as K
+    from oracle import effnet_oracle as EO
+    B, H, W, C, Cp = 2, 20, 37, 40, 128
+    img = synth.normal("eimg", (B, H, W), 1.0)
+    w = synth.normal("estem", (C, 3, 3), 0.4); bias = synth.normal("estemb", (C,), 0.2)
+    ws = np.zeros((9, Cp), np.float32); ws[:, :C] = w.reshape(C, 9).T
+    bs = np.zeros((Cp,), np.float32); bs[:C] = bias
+    y = K.effnet_stem(_dev(img), _dev(ws), _dev(bs)).float().cpu().numpy()
+    ref = EO.silu(EO.conv2d(img[:, None], w[:, None], 2, 1) + bias[None, :, None, None]).transpose(0, 2, 3, 1)
+    assert y.shape == (B, 10, 19, Cp) and rel_l2(y[..., :C], ref) < 6e-4 and np.all(y[..., C:] == 0)
+    x = round_half(np.pad(ref, ((0, 0), (0, 0), (0, 0), (0, Cp - C))), "f16")
+    for k, s in ((3, 1), (5, 2), (3, 2), (5, 1)):
+        wd = synth.normal(f"edw{k}{s}", (C, k, k), 0.3); bd = synth.normal("edwb", (C,), 0.1)
+        wdp = np.zeros((k * k, Cp), np.float32); wdp[:, :C] = wd.reshape(C, k * k).T
+        bdp = np.zeros((Cp,), np.float32); bdp[:C] = bd
+        out, pool = K.effnet_dwconv(_dev(x, torch.float16), _dev(wdp), _dev(bdp), k, s)
+        r = EO.silu(EO.conv2d(x[..., :C].transpose(0, 3, 1, 2), wd[:, None], s, (k - 1) // 2, groups=C) + bd[None, :, None, None]).transpose(0, 2, 3, 1)
+        o = out.float().cpu().numpy()
+        assert o.shape[:3] == r.shape[:3] and rel_l2(o[..., :C], r) < 6e-4 and np.all(o[..., C:] == 0)
+        assert np.allclose(pool.cpu().numpy()[:, :C], o[..., :C].sum((1, 2)), rtol=1e-4, atol=1e-2)
+        Cs = 10
+        w1 = synth.normal("ese1", (Cs, C), 0.3); b1 = synth.normal("ese1b", (Cs,), 0.1); w2 = synth.normal("ese2", (C, Cs), 0.5); b2 = synth.normal("ese2b", (C,), 0.3)
+        xs = out.clone()
+        sc = K.effnet_se(xs, pool, C, _dev(w1), _dev(b1), _dev(w2), _dev(b2)).cpu().numpy()
+        m = o[..., :C].mean((1, 2))
+        e = 1.0 / (1.0 + np.exp(-(EO.silu(m @ w1.T + b1) @ w2.T + b2)))
+        assert np.allclose(sc[:, :C], e, rtol=2e-4, atol=2e-5) and np.all(sc[:, C:] == 0)
+        assert rel_l2(xs.float().cpu().numpy()[..., :C], o[..., :C] * e[:, None, None, :]) < 6e-4
+
+
+def test_effnet_b0_matches_oracle(built_lib):
+    """The whole features stack (all 16 MBConv blocks, real widths) on a small mel image vs the NumPy restatement."""
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    from oracle import effnet_oracle as EO
+    sd = synth.effnet_b0_state_dict()
+    enc = EfficientNetB0Encoder(sd)
+    mel = np.abs(synth.normal("emel", (2, 64, 101), 0.5)).astype(np.float32)
+    ref, taps = EO.effnet_features(mel, sd, synth.EFFNET_B0_STAGES)
+    names = enc.tap_names()
+    assert names == list(taps.keys()) and len(names) == 17
+    r = enc.forward(_dev(mel), hook_layers=[names[0], names[3], names[-1]], want_features=True, want_pooled=True)
+    assert r["features"].shape == ref.shape == (2, 1280, 2, 4)
+    assert rel_l2(r["features"].cpu().numpy(), ref) < 2e-2                      # 50 layers of f16 operands / activations
+    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 2e-2
+    assert rel_l2(r["hooks"][names[0]].cpu().numpy(), taps[names[0]]) < 2e-5     # stem tap: fp32
+    assert rel_l2(r["hooks"][names[3]].cpu().numpy(), taps[names[3]]) < 1e-2
+    assert rel_l2(r["hooks"][names[-1]].cpu().numpy(), taps[names[-1]]) < 2e-2
