@@ -2,7 +2,7 @@
 ``model_spec`` values, default checkpoint URI and label-map URI
 (reference data files: avex/api/configs/official_models/*.yml).
 
-Only the ``beats`` class is built in this package so far; the EAT / EfficientNet ids are registered
+The ``beats``, ``efficientnet`` and ``aves`` classes are built in this package; the EAT ids are registered
 so that ``list_models()`` / ``get_model_spec()`` answer like the reference, and loading them raises
 ``KeyError`` ("model class ... is not registered") exactly as the reference does for a class it
 could not import.

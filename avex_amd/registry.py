@@ -146,6 +146,8 @@ def initialize_registry() -> None:
     _MODEL_CLASSES.setdefault("beats", BeatsModel)
     from .aves_model import Model as AvesModel
     _MODEL_CLASSES.setdefault("aves", AvesModel)
+    from .efficientnet import Model as EfficientNetModel
+    _MODEL_CLASSES.setdefault("efficientnet", EfficientNetModel)
 
 
 initialize_registry()

@@ -282,3 +282,38 @@ def test_aves_class_contract_cpu():
         m(torch.zeros(1, 16000))
     with pytest.raises(FileNotFoundError):
         Model(device="cpu", pretrained=True)
+
+
+def test_efficientnet_class_contract_cpu():
+    """EfficientNet mirror (reference: avex/models/efficientnet.py:21-322) without a GPU: torchvision efficientnet_b0 key names,
+    the 17 hookable convolutions (stem, every block.3.0, head), prefix-less checkpoints, variants, refusal to run on the CPU."""
+    import pytest
+    import torch
+    import avex_amd
+    from avex_amd import synth
+    from avex_amd._capi import AvexHipError
+    from avex_amd.efficientnet import Model
+    assert "efficientnet" in avex_amd.list_model_classes()
+    m = Model(device="cpu", return_features_only=True)
+    sd = synth.effnet_b0_state_dict()
+    feat_keys = {k for k in m.state_dict() if k.startswith("model.features.")}
+    assert feat_keys == set(sd) and len(sd) == 358
+    assert {"model.classifier.1.weight", "model.classifier.1.bias"} <= set(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.load_state_dict({k[len("model."):]: torch.from_numpy(v) for k, v in sd.items()}, strict=False)     # as torchvision saves it
+    layers = m.register_hooks_for_layers(["all"])
+    assert len(layers) == 17 and layers[0] == "model.features.0.0" and layers[-1] == "model.features.8.0"
+    assert layers[1] == "model.features.2.0.block.3.0" and all(n.endswith(".block.3.0") for n in layers[1:-1])
+    assert m.register_hooks_for_layers(["last_layer"]) == ["model.features.8.0"] or len(m.register_hooks_for_layers(["last_layer"])) == 1
+    m.deregister_all_hooks()
+    assert Model(device="cpu", num_classes=7).model.classifier[1].out_features == 7
+    with pytest.raises(NotImplementedError):
+        Model(device="cpu", efficientnet_variant="b1")
+    with pytest.raises(ValueError):
+        Model(device="cpu", efficientnet_variant="b9")
+    with pytest.raises(FileNotFoundError):
+        Model(device="cpu", pretrained=True)
+    with pytest.raises((AvexHipError, RuntimeError)):
+        m(torch.zeros(1, 3, 16, 16))
+    spec = avex_amd.get_model_spec("esp_aves2_effnetb0_all")
+    assert spec.name == "efficientnet" and spec.audio_config.n_fft == 800 and spec.audio_config.representation == "mel_spectrogram"

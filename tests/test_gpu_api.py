@@ -182,6 +182,32 @@ def test_aves_model_on_gpu(built_lib):
     m.deregister_all_hooks()
 
 
+def test_efficientnet_model_on_gpu(built_lib, tmp_path):
+    """EfficientNet mirror end to end through load_model with a local checkpoint: waveform -> GPU mel frontend -> B0 features,
+    vs the NumPy restatements of both stages (1 s clips keep the CPU side short); hook taps through extract_embeddings."""
+    from safetensors.numpy import save_file
+    from oracle import beats_oracle as BO
+    from oracle import effnet_oracle as EO
+    sd = synth.effnet_b0_state_dict()
+    path = tmp_path / "effnet.safetensors"
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items() if not k.endswith("num_batches_tracked")}, str(path))
+    m = avex_amd.load_model("esp_aves2_effnetb0_all", device="cuda", checkpoint_path=str(path), return_features_only=True).eval()
+    x = synth.noise_clips(2, 16000, seed=71)
+    mel = BO.audio_processor(x, n_fft=800, hop=160)
+    ref, taps = EO.effnet_features(mel, sd, synth.EFFNET_B0_STAGES)
+    f = m(torch.from_numpy(x))
+    assert f.shape == ref.shape == (2, 1280, 4, 4) and f.is_cuda
+    assert rel_l2(f.cpu().numpy(), ref) < 2e-2
+    names = m.register_hooks_for_layers([0, -1])
+    assert names == ["model.features.0.0", "model.features.8.0"]
+    e = m.extract_embeddings({"raw_wav": torch.from_numpy(x)}, aggregation="mean")
+    want = np.concatenate([taps[names[0]].mean(-1).reshape(2, -1), taps[names[1]].mean(-1).reshape(2, -1)], 1)
+    assert e.shape == want.shape == (2, 32 * 64 + 1280 * 4) and rel_l2(e.cpu().numpy(), want) < 2e-2
+    lst = m.extract_embeddings(torch.from_numpy(x), aggregation="none")
+    assert isinstance(lst, list) and lst[0].shape == (2, 32, 64, 51)
+    m.deregister_all_hooks()
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
