@@ -51,11 +51,11 @@ class EfficientNetB0Encoder:
         def t32(a):
             return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(dev)
 
-        def pw(conv, bn):                         # 1x1 conv + BN -> ([Np, Kp] half weight, [Np] fp32 bias, scale, shift)
+        def pw(conv, bn, kp=None):                # 1x1 conv + BN -> ([Np, Kp] half weight, [Np] fp32 bias, scale, shift)
             w = get(conv + ".weight")[:, :, 0, 0]
             sc, sh = bnfold(bn)
             N, Kd = w.shape
-            wp = np.zeros((_pad128(N), _pad128(Kd)), np.float32)
+            wp = np.zeros((_pad128(N), kp or _pad128(Kd)), np.float32)      # Kp = channel padding of the activation it reads
             wp[:N, :Kd] = w * sc[:, None]
             bp = np.zeros((_pad128(N),), np.float32); bp[:N] = sh
             return K.to_half(t32(wp), operand_dtype), t32(bp), sc, sh
@@ -64,8 +64,11 @@ class EfficientNetB0Encoder:
         w0 = get("features.0.0.weight").sum(axis=1)                                      # [32, 3, 3]
         sc, sh = bnfold("features.0.1")
         c0 = w0.shape[0]
-        ws = np.zeros((9, _pad128(c0)), np.float32); ws[:, :c0] = (w0 * sc[:, None, None]).reshape(c0, 9).T
-        bs = np.zeros((_pad128(c0),), np.float32); bs[:c0] = sh
+        # GEMM outputs need a channel count that is a multiple of 128 (N), GEMM inputs only a multiple of 64 (K): the stem and
+        # the depthwise layer behind it (the highest-resolution tensors of the network) carry 64 channels, not 128
+        cp = ((c0 + 63) // 64) * 64
+        ws = np.zeros((9, cp), np.float32); ws[:, :c0] = (w0 * sc[:, None, None]).reshape(c0, 9).T
+        bs = np.zeros((cp,), np.float32); bs[:c0] = sh
         self.stem = (t32(ws), t32(bs), c0, sc, sh)
         self.blocks = []
         for si, (er, k, s, cin, cout, n) in enumerate(self.stages, start=1):
@@ -76,20 +79,22 @@ class EfficientNetB0Encoder:
                 d = 1 if er != 1 else 0
                 blk = dict(name=prefix + p, k=k, stride=s if j == 0 else 1, cin=ci, cexp=ce, cout=cout, tap=(d == 1))
                 if d:
-                    blk["expand"] = pw(p + "0.0", p + "0.1")[:2]
+                    blk["expand"] = pw(p + "0.0", p + "0.1", kp=cp)[:2]
+                    cp = _pad128(ce)
                 wd = get(p + f"{d}.0.weight")[:, 0]                                      # [ce, k, k]
                 scd, shd = bnfold(p + f"{d}.1")
-                wdp = np.zeros((k * k, _pad128(ce)), np.float32); wdp[:, :ce] = (wd * scd[:, None, None]).reshape(ce, k * k).T
-                bdp = np.zeros((_pad128(ce),), np.float32); bdp[:ce] = shd
+                wdp = np.zeros((k * k, cp), np.float32); wdp[:, :ce] = (wd * scd[:, None, None]).reshape(ce, k * k).T
+                bdp = np.zeros((cp,), np.float32); bdp[:ce] = shd
                 blk["dw"] = (t32(wdp), t32(bdp))
                 blk["se"] = (t32(get(p + f"{d + 1}.fc1.weight")[:, :, 0, 0]), t32(get(p + f"{d + 1}.fc1.bias")),
                              t32(get(p + f"{d + 1}.fc2.weight")[:, :, 0, 0]), t32(get(p + f"{d + 1}.fc2.bias")))
-                wp_, bp_, scp, shp = pw(p + f"{d + 2}.0", p + f"{d + 2}.1")
+                wp_, bp_, scp, shp = pw(p + f"{d + 2}.0", p + f"{d + 2}.1", kp=cp)
+                cp = _pad128(cout)
                 blk["project"] = (wp_, bp_)
                 blk["project_bn"] = (t32(scp), t32(shp))
                 self.blocks.append(blk)
         last = len(self.stages) + 1
-        wh, bh, sch, shh = pw(f"features.{last}.0", f"features.{last}.1")
+        wh, bh, sch, shh = pw(f"features.{last}.0", f"features.{last}.1", kp=cp)
         self.head = (wh, bh, t32(sch), t32(shh), int(sch.shape[0]))
         self.head_name = prefix + f"features.{last}.0"
         self.stem_name = prefix + "features.0.0"
