@@ -18,8 +18,8 @@
 namespace {
 
 struct MelDev {
-    int n_fft, hop, n_freq, half, nc, n_out, center, skew, use_mel;
-    const float* dft;        // [n_fft][nc]
+    int n_fft, hop, n_freq, half, nc, n_out, center, skew, use_mel, kfold, fold;
+    const float* dft;        // [kfold][nc], kfold = n_fft/2 + 1 rounded up to even: the folded contraction (see the kernel)
     const int* mel_start;    // [n_out] CSR over frequency bins (mel) -- unused for plain spectrograms
     const int* mel_len;
     const int* mel_off;
@@ -62,10 +62,26 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelDev md, const float* __
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const float* bcol = md.dft + halfsel * md.half + wpair * NTW * 32 + fr;
     const int abase = md.hop * fr;
-    for (int ks = 0; ks < md.n_fft / 2; ++ks) {
+    // Real input and a window symmetric about n_fft / 2 (periodic Hann / Hamming are): fold sample n with sample N - n,
+    //   Re X[k] = sum_{n=0}^{N/2} w[n] (x[n] + x[N-n]) cos(2 pi k n / N),   Im X[k] = -sum w[n] (x[n] - x[N-n]) sin(2 pi k n / N)
+    // (n = 0 and n = N/2 have no partner), which halves the contraction length.  The real-part waves form the sums, the
+    // imaginary-part waves the differences, on the fly from the same LDS samples.
+    const int nhalf = md.n_fft / 2;
+    const float sgn = halfsel ? -1.f : 1.f;
+    for (int ks = 0; ks < md.kfold / 2; ++ks) {
         const int n = 2 * ks + kh;
-        const int ai = abase + n;
-        const float a = xs[ai + (md.skew ? ai / md.hop : 0)];
+        float a = 0.f;
+        if (!md.fold) {                                   // asymmetric window: plain contraction over all n_fft samples
+            const int ai = abase + n;
+            a = xs[ai + (md.skew ? ai / md.hop : 0)];
+        } else if (n <= nhalf) {
+            const int ai = abase + n;
+            a = xs[ai + (md.skew ? ai / md.hop : 0)];
+            if (n > 0 && n < nhalf) {
+                const int aj = abase + md.n_fft - n;
+                a = __builtin_fmaf(sgn, xs[aj + (md.skew ? aj / md.hop : 0)], a);
+            }
+        }
         const float* brow = bcol + (int64_t)n * md.nc;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[t * 32], acc[t], 0, 0, 0);
@@ -164,10 +180,15 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
         }
     }
     // DFT matrix with the (centre-padded, torch.stft) window folded in: X[k] = sum_n w[n] x[n] exp(-2 pi i k n / N)
-    std::vector<float> dft((size_t)N * nc, 0.f);
     const int wl = (N - win) / 2;
-    for (int n = 0; n < N; ++n) {
-        const float w = (n >= wl && n < wl + win) ? hwin[n - wl] : 0.f;
+    auto wat = [&](int n) { return (n >= wl && n < wl + win) ? hwin[n - wl] : 0.f; };
+    bool sym = true;      // symmetric about n_fft / 2 (periodic Hann of any length; Hamming when win_length == n_fft)
+    for (int n = 1; n < N / 2; ++n)
+        if (fabsf(wat(n) - wat(N - n)) > 1e-6f * fmaxf(1.f, fabsf(wat(n)))) sym = false;
+    const int kfold = sym ? (((N / 2 + 1) + 1) & ~1) : N;
+    std::vector<float> dft((size_t)kfold * nc, 0.f);
+    for (int n = 0; n < (sym ? N / 2 + 1 : N); ++n) {
+        const float w = wat(n);
         for (int k = 0; k < nf; ++k) {
             const long long kn = ((long long)k * n) % N;             // exact argument reduction
             const double a = -2.0 * M_PI * (double)kn / (double)N;
@@ -194,7 +215,7 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
     char* base = (char*)d;
     MelDev& md = p->dev;
     md.n_fft = N; md.hop = hop; md.n_freq = nf; md.half = half; md.nc = nc; md.n_out = n_out; md.center = cfg->center ? 1 : 0;
-    md.skew = (hop % 2 == 0) ? 1 : 0; md.use_mel = cfg->n_mels > 0 ? 1 : 0;
+    md.skew = (hop % 2 == 0) ? 1 : 0; md.use_mel = cfg->n_mels > 0 ? 1 : 0; md.kfold = kfold; md.fold = sym ? 1 : 0;
     md.dft = (const float*)(base + o_dft); md.mel_start = (const int*)(base + o_st); md.mel_len = (const int*)(base + o_ln);
     md.mel_off = (const int*)(base + o_of); md.mel_w = (const float*)(base + o_w);
     const int nseg = hop * 31 + N;
