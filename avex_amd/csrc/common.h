@@ -216,6 +216,7 @@ struct GemmArgs {
     const float* lnr_gamma;   // [N]
     const float* lnr_beta;    // [N]
     float* stats_out;         // [M][N/64][2] or NULL
+    int tile_order;           // 256-tile kernel: 0 = grouped walk (default), 1 = row-major (A/B experiments)
     int stagger_ticks;        // variant 5: workgroups of odd slot start this many 10-ns ticks late (desynchronised epilogues)
     int stagger_groups;       // variant 5: number of start phases (>= 1)
 };

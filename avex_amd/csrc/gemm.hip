@@ -197,6 +197,21 @@ __device__ int g_gemm_stamps_on = 0;
 __device__ unsigned long long g_gemm_clk[2 * 8192];   // s_memtime (shader clock) at loop start / end, variant 5
 
 constexpr int T2 = 256;
+// Tile walk of the 256-tile kernels: consecutive logical tile ids (each XCD owns a contiguous range of them, and its 32 CUs
+// run 32 consecutive ids at a time) go DOWN groups of GROUP_M row panels before moving one column to the right, so an XCD
+// keeps a group's A panels (GROUP_M x 393 KB at K = 768; GROUP_M = 8) in its 4 MiB L2 while the weight column panels stream past once per
+// group.  With the row-major walk every row panel re-fetched the whole weight matrix (4.7 MB for fc1, more than the L2), and
+// the PMC passes showed 1.59 GB fetched per fc1 launch against 0.2 GB of activations (profiles/r01g_gemm_tile_order.txt).
+static __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int GROUP_M, int& tm, int& tn) {
+    const int per_group = GROUP_M * tiles_n;
+    const int gid = tile / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int r = tile - gid * per_group;
+    tn = r / gsz;
+    tm = first_m + (r - tn * gsz);
+}
+
 constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32 KiB)
 constexpr int LNS_OFF = 2 * STAGE2;        // (mu, rstd) of the tile's 256 rows: A-side statistics, then residual-side (2 x 2 KiB)
 constexpr int LDS2 = 2 * STAGE2 + 4096;
@@ -390,7 +405,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     const int tiles_n = p.N / T2;
     const int tiles_m = (p.M + T2 - 1) / T2;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    // grouped walk where a group of 8 A panels fits the L2 (K < 2048: QKV, out_proj, fc1); measured inside one call against the
+    // row-major walk: fc1 +3 %, out_proj +3 %, QKV +-0, whole step +1.4 %; HBM fetch per fc1 launch 1.57 -> 0.97 GB
+    // (profiles/r01g_gemm_tile_order.txt).  At K = 3072 a group would be 12.6 MB: row-major there.
+    const bool grouped = p.tile_order >= 2 || (p.tile_order == 0 && p.K < 2048);
+    const int group_m = p.tile_order >= 2 ? p.tile_order : 8;
+    int tm, tn;
+    if (!grouped) { tm = tile / tiles_n; tn = tile - tm * tiles_n; } else tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
     const int m0 = tm * T2, n0 = tn * T2;
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
@@ -664,8 +685,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             wdst[h][q] = (128 * q + 64 * h + 8 * wid) * 128;
             xdst[h][q] = T2 * BK * 2 + (128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3)) * 128;
         }
+    const bool grouped = p.K < 2048;      // as in gemm256_kernel
+    const int group_m = 8;
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        int tm, tn;
+        if (grouped) tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
+        else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
         m0 = tm * T2; n0 = tn * T2;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -741,7 +766,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_READ_W(0, st);
             if (kt + 1 < nk) dma_w(1, kt + 1, st ^ 1);
             else if (has_next) dma_w(1, 0, st ^ 1);                  // pointers already switched (below, one iteration ago)
-            if (kt == nk - 2 && has_next) { set_tile(next_tile); dma_bias(n0, (it + 1) & 1); }   // last use of this tile's pointers was the line above
+            if (kt == nk - 2 && has_next) set_tile(next_tile);       // last use of this tile's pointers was the line above
+            // next tile's bias row: in the LAST K-tile, i.e. at least four barriers into this tile, when the lagging wave group
+            // has left the previous tile's epilogue (which read the slot this overwrites); it is older than the six DMAs of the
+            // B phase below, so wave 0's vmcnt(6) there and the two barriers that follow publish it before the epilogue
+            if (kt == nk - 1 && has_next) dma_bias(n0, (it + 1) & 1);
             AVX_LGKM0();
             AVX_BAR();
             AVX_HALF(0);
@@ -921,7 +950,10 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
             attr_set = true;
         }
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
-        hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), LDS2, s, a);
+        static const int order = getenv("AVEX_AMD_GEMM_TILE_ORDER") ? atoi(getenv("AVEX_AMD_GEMM_TILE_ORDER")) : 0;
+        avx::GemmArgs a2 = a;
+        a2.tile_order = order;
+        hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), LDS2, s, a2);
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }
