@@ -78,6 +78,9 @@ SYMBOLS = {
     "avexhip_effnet_se": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),
+    "avexhip_layer_mix": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_int64, _P, _P]),
+    "avexhip_dense_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
+    "avexhip_mha_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
     "avexhip_fbank_forward_padded": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
     "avexhip_cast_f32_to_half": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),

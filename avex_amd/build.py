@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libavexhip.so")
-SOURCES = ["api.cpp", "gemm.hip", "elementwise.hip", "fbank.hip", "attention.hip", "posconv.hip", "wavconv.hip", "melspec.hip", "effnet.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "elementwise.hip", "fbank.hip", "attention.hip", "posconv.hip", "wavconv.hip", "melspec.hip", "effnet.hip", "probe.hip"]
 ARCH = "gfx950"
 
 

@@ -261,6 +261,66 @@ def wavconv0(wav: torch.Tensor, w: torch.Tensor, gn_w: torch.Tensor, gn_b: torch
     return out
 
 
+PROBE_ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3}
+
+
+def layer_mix(taps: Sequence[torch.Tensor], layer_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``sum_l softmax(layer_weights)_l * taps[l]`` (weights of 1.0 without ``layer_weights``), the reference's
+    ``_BaseProbe._sum`` (base_probes.py:197-206), in one pass over the taps."""
+    import ctypes as C
+    taps = [t.contiguous() for t in taps]
+    _need_cuda(*taps)
+    if not 1 <= len(taps) <= 16 or any(t.shape != taps[0].shape or t.dtype != torch.float32 for t in taps):
+        raise ValueError("layer_mix: need 1..16 fp32 taps of one shape")
+    if layer_weights is not None:
+        _need_cuda(layer_weights)
+        if layer_weights.numel() != len(taps):
+            raise ValueError("layer_mix: one weight per tap")
+        layer_weights = layer_weights.contiguous().float()
+    out = torch.empty_like(taps[0])
+    arr = (C.c_void_p * len(taps))(*[t.data_ptr() for t in taps])
+    check(lib().avexhip_layer_mix(arr, len(taps), _ptr(layer_weights), out.numel(), _ptr(out), _stream()), "layer_mix")
+    return out
+
+
+def dense_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
+              resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 ``act(x @ w.T + bias) (+ resid)`` over the last dim of ``x`` (nn.Linear semantics) on the fp32 matrix core."""
+    _need_cuda(x, w)
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    w = w.contiguous()
+    M, K = x2.shape
+    N = w.shape[0]
+    if w.shape[1] != K or x2.dtype != torch.float32 or w.dtype != torch.float32:
+        raise ValueError(f"dense_f32: x [..., {K}] fp32 against w {tuple(w.shape)}")
+    r2 = None
+    if resid is not None:
+        r2 = resid.reshape(-1, N).contiguous()
+        if r2.shape[0] != M:
+            raise ValueError("dense_f32: residual shape")
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib().avexhip_dense_f32(_ptr(x2), K, _ptr(w), K, _ptr(bias.contiguous() if bias is not None else None), _ptr(r2), N, M, N, K,
+                                  PROBE_ACT[act], _ptr(out), N, _stream()), "dense_f32")
+    return out.reshape(*lead, N)
+
+
+def mha_f32(qkv: torch.Tensor, num_heads: int, key_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention core of ``nn.MultiheadAttention`` (eval, self attention): ``qkv [B, T, 3E]`` -> ``[B, T, E]``."""
+    _need_cuda(qkv)
+    qkv = qkv.contiguous()
+    B, T, E3 = qkv.shape
+    E = E3 // 3
+    kp = None
+    if key_pad is not None:
+        kp = key_pad.to(device=qkv.device, dtype=torch.uint8).contiguous()
+        if kp.shape != (B, T):
+            raise ValueError("mha_f32: key_pad must be [B, T]")
+    out = torch.empty((B, T, E), dtype=torch.float32, device=qkv.device)
+    check(lib().avexhip_mha_f32(_ptr(qkv), B, T, E, num_heads, _ptr(kp), _ptr(out), _stream()), "mha_f32")
+    return out
+
+
 def to_half(x: torch.Tensor, dtype="f16") -> torch.Tensor:
     _need_cuda(x)
     code = dtype_code(dtype)

@@ -1,0 +1,278 @@
+"""Probe heads evaluated on the device: forward-only mirrors of the reference's online probes.
+
+Reference: ``avex/models/probes/{base_probes,linear_probe,mlp_probe,attention_probe}.py``.  The reference probes are
+``nn.Module`` s trained by autograd on top of ``base_model.extract_embeddings``; with this package's models that call already returns
+device tensors, so the reference's own probe classes train on them unchanged and nothing crosses PCIe.  What is mirrored here is the
+EVALUATION forward -- layer mixing (``_sum``), the 2-D / 3-D reshaping rules and the three heads -- running on this library's fp32
+kernels (``avexhip_layer_mix``, ``avexhip_dense_f32``, ``avexhip_mha_f32``, ``avexhip_layernorm``, ``avexhip_mean_pool``) with the
+reference's constructor arguments and ``state_dict`` key names, so a probe trained with the reference loads with
+``load_state_dict`` and scores batches right behind the encoder.  Training (``.train()``) is refused loudly; embedding projectors
+(taps of different widths, base_probes.py:262-289) are not built: every model on this path has equal-width taps.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+TensorOrList = Union[torch.Tensor, List[torch.Tensor]]
+
+
+class _DeviceProbe(nn.Module):
+    """Shared scaffolding (base_probes.py:20-206): where the embeddings come from and how several taps are combined."""
+
+    rank = 2                       # 2: (batch, features) heads; 3: (batch, sequence, features) heads
+
+    def __init__(self, base_model, layers: Sequence[str], num_classes: int, device: str = "cuda", feature_mode: bool = False,
+                 input_dim=None, aggregation: str = "mean", target_length: Optional[int] = None, freeze_backbone: bool = True) -> None:
+        super().__init__()
+        if not freeze_backbone:
+            raise NotImplementedError("avex_amd probes are evaluation heads on a frozen backbone")
+        if not feature_mode and base_model is None:
+            raise ValueError("a base_model is required unless feature_mode=True")
+        if feature_mode and base_model is None and input_dim is None:
+            raise ValueError("input_dim must be provided when feature_mode=True and base_model is None")
+        self.device = device
+        self.base_model = base_model
+        self.layers = list(layers)
+        self.num_classes = num_classes
+        self.feature_mode = feature_mode
+        self.aggregation = aggregation
+        self.target_length = target_length
+        self.freeze_backbone = True
+        shapes = self._probe_input_shapes(input_dim)
+        feats = {self._feature_dim(s) for s in shapes}
+        if len(feats) != 1:
+            raise NotImplementedError(f"taps of different widths {sorted(feats)} need embedding projectors, which are not built")
+        if len(shapes) > 1:                                         # base_probes.py:150-152: only for several embeddings
+            self.register_buffer("layer_weights", torch.zeros(len(shapes)))
+        self.inferred_dim = feats.pop()
+        self.build_head(self.inferred_dim)
+        self.to(device)
+        super().train(False)
+
+    # -- construction ------------------------------------------------------------------------------------------------------
+    def _probe_input_shapes(self, input_dim) -> List[tuple]:
+        """Per-embedding shapes without the batch dim (base_probes.py:93-163)."""
+        if self.feature_mode and input_dim is not None:
+            if isinstance(input_dim, list):
+                return [tuple(s) for s in input_dim]
+            if isinstance(input_dim, tuple):
+                return [input_dim]
+            return [(1, int(input_dim))] if self.rank == 3 else [(int(input_dim),)]
+        ap = self.base_model.audio_processor
+        if self.target_length is not None:
+            n = int(self.target_length)
+        elif hasattr(ap, "target_length_seconds"):
+            n = int(ap.target_length_seconds * ap.sr)
+        elif hasattr(ap, "target_length"):
+            n = int(ap.target_length)
+        else:
+            raise ValueError("target_length must be provided when base_model.audio_processor does not have target_length or "
+                             "target_length_seconds")
+        with torch.no_grad():
+            emb = self.base_model.extract_embeddings(torch.randn(1, n, device=self.device), aggregation=self.aggregation)
+        return [tuple(e.shape[1:]) for e in (emb if isinstance(emb, list) else [emb])]
+
+    def _feature_dim(self, shape: tuple) -> int:
+        n = 1
+        if self.rank == 2:                                          # base_probes.py:263-272,291-298
+            for s in shape:
+                n *= s
+            return n
+        if len(shape) == 2:                                         # base_probes.py:336-343,380-387
+            return shape[1]
+        if len(shape) == 3:
+            return shape[0] * shape[1]
+        if len(shape) == 1:
+            return 1
+        raise ValueError(f"unsupported embedding shape {shape}")
+
+    def build_head(self, inferred_dim: int) -> None:
+        raise NotImplementedError
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("avex_amd probes are forward-only; train the reference's probe class on this model's "
+                                      "device-resident embeddings and load its state_dict here")
+        return super().train(False)
+
+    # -- embeddings --------------------------------------------------------------------------------------------------------
+    def _get_embeddings(self, x, padding_mask) -> TensorOrList:
+        """base_probes.py:166-195."""
+        if self.feature_mode:
+            if isinstance(x, dict):
+                if "raw_wav" in x:
+                    return x["raw_wav"]
+                keys = [k for k in x if k not in ("label", "padding_mask")]
+                return x[keys[0]] if len(keys) == 1 else [x[k] for k in keys]
+            return x
+        if isinstance(x, dict):
+            padding_mask = x.get("padding_mask")
+            x = x["raw_wav"]
+        return self.base_model.extract_embeddings(x, padding_mask=padding_mask, aggregation=self.aggregation)
+
+    def _mix(self, taps: List[torch.Tensor]) -> torch.Tensor:
+        return K.layer_mix([t.float() for t in taps], getattr(self, "layer_weights", None))
+
+    def _combine(self, emb: TensorOrList) -> torch.Tensor:
+        if self.rank == 2:                                          # base_probes.py:299-322
+            if isinstance(emb, list):
+                return self._mix([e.reshape(e.shape[0], -1) for e in emb])
+            return emb.reshape(emb.shape[0], -1).float()
+        fmt = self._seq_feat                                        # base_probes.py:389-414
+        if isinstance(emb, list):
+            taps = [fmt(e) for e in emb]
+            if len({t.shape[1] for t in taps}) > 1:
+                raise NotImplementedError("taps of different sequence lengths (linear interpolation) are not built")
+            return self._mix(taps)
+        return fmt(emb).float()
+
+    @staticmethod
+    def _seq_feat(e: torch.Tensor) -> torch.Tensor:                 # base_probes.py:369-378
+        if e.dim() == 3:
+            return e
+        if e.dim() == 4:
+            b, c, h, w = e.shape
+            return e.transpose(1, 3).reshape(b, w, c * h)
+        if e.dim() == 2:
+            return e.unsqueeze(2)
+        raise ValueError(f"Unsupported embedding dim {e.dim()} for 3D probe")
+
+    def get_learned_weights_table(self) -> str:                     # base_probes.py:208-244
+        lw = getattr(self, "layer_weights", None)
+        if lw is None:
+            return "No learned weights found. This probe does not use weighted sum of embeddings."
+        raw = lw.detach().cpu()
+        norm = torch.softmax(raw, dim=0)
+        rows = ["Learned Layer Weights:", "=" * 50, f"{'Layer':<15} {'Raw Weight':<12} {'Normalized':<12} {'Percentage':<12}", "-" * 50]
+        rows += [f"{'Layer_%d' % i:<15} {r:<12.4f} {n:<12.4f} {n * 100:<12.2f}%" for i, (r, n) in enumerate(zip(raw.tolist(), norm.tolist()))]
+        rows += ["-" * 50, "Sum of normalized weights: %.6f" % float(norm.sum()), "Number of layers: %d" % len(raw)]
+        return "\n".join(rows)
+
+    def _buf(self, name: str, *shape: int) -> None:
+        mod, _, leaf = name.rpartition(".")
+        owner = self
+        for part in mod.split(".") if mod else []:
+            if not hasattr(owner, part):
+                owner.add_module(part, nn.Module())
+            owner = getattr(owner, part)
+        owner.register_buffer(leaf, torch.zeros(*shape))
+
+    def _p(self, name: str) -> torch.Tensor:
+        return self.get_buffer(name)
+
+
+class LinearProbe(_DeviceProbe):
+    """linear_probe.py:16-68: ``classifier = Linear(inferred_dim, num_classes)`` on the combined embedding."""
+
+    def build_head(self, inferred_dim: int) -> None:
+        self._buf("classifier.weight", self.num_classes, inferred_dim)
+        self._buf("classifier.bias", self.num_classes)
+
+    @torch.no_grad()
+    def forward(self, x, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        emb = self._combine(self._get_embeddings(x, padding_mask))
+        return K.dense_f32(emb, self._p("classifier.weight"), self._p("classifier.bias"))
+
+
+class MLPProbe(_DeviceProbe):
+    """mlp_probe.py:16-91: ``Linear -> activation -> Dropout`` per hidden width, then ``Linear`` to the classes.  State-dict indices
+    follow the reference's ``nn.Sequential`` (a Dropout slot exists only for ``dropout_rate > 0``)."""
+
+    def __init__(self, base_model, layers, num_classes, device="cuda", feature_mode=False, input_dim=None, aggregation="mean",
+                 hidden_dims: Optional[List[int]] = None, dropout_rate: float = 0.1, activation: str = "relu", target_length=None,
+                 freeze_backbone=True) -> None:
+        self.hidden_dims = hidden_dims or [512, 256]
+        self.dropout_rate = dropout_rate
+        self.activation = activation
+        if activation not in ("relu", "gelu", "tanh"):
+            raise ValueError(f"Unsupported activation: {activation}")
+        super().__init__(base_model, layers, num_classes, device, feature_mode, input_dim, aggregation, target_length, freeze_backbone)
+
+    def build_head(self, inferred_dim: int) -> None:
+        self._linear_slots: List[int] = []
+        slot, cur = 0, inferred_dim
+        for h in self.hidden_dims:
+            self._buf(f"mlp.{slot}.weight", h, cur)
+            self._buf(f"mlp.{slot}.bias", h)
+            self._linear_slots.append(slot)
+            slot += 3 if self.dropout_rate > 0 else 2
+            cur = h
+        self._buf(f"mlp.{slot}.weight", self.num_classes, cur)
+        self._buf(f"mlp.{slot}.bias", self.num_classes)
+        self._linear_slots.append(slot)
+
+    @torch.no_grad()
+    def forward(self, x, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = self._combine(self._get_embeddings(x, padding_mask))
+        for n, slot in enumerate(self._linear_slots):
+            last = n + 1 == len(self._linear_slots)
+            h = K.dense_f32(h, self._p(f"mlp.{slot}.weight"), self._p(f"mlp.{slot}.bias"), act=None if last else self.activation)
+        return h
+
+
+class AttentionProbe(_DeviceProbe):
+    """attention_probe.py:16-134: optional sinusoidal positions, ``num_layers`` x [self attention -> LayerNorm(x + attn)], mean over
+    the sequence, classifier.  ``embed_dim`` is the tap width (``attention_dim`` is carried but unused, as in the reference)."""
+
+    rank = 3
+
+    def __init__(self, base_model, layers, num_classes, device="cuda", feature_mode=False, input_dim=None, aggregation="mean",
+                 num_heads: int = 8, attention_dim: int = 512, num_layers: int = 2, dropout_rate: float = 0.1,
+                 max_sequence_length: Optional[int] = None, use_positional_encoding: bool = False, target_length=None,
+                 freeze_backbone=True) -> None:
+        self.num_heads = num_heads
+        self.attention_dim = attention_dim
+        self.num_layers = num_layers
+        self.dropout_rate = dropout_rate
+        self.max_sequence_length = max_sequence_length
+        self.use_positional_encoding = use_positional_encoding
+        super().__init__(base_model, layers, num_classes, device, feature_mode, input_dim, aggregation, target_length, freeze_backbone)
+
+    def build_head(self, d: int) -> None:
+        if d % self.num_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        for i in range(self.num_layers):
+            self._buf(f"attention_layers.{i}.in_proj_weight", 3 * d, d)
+            self._buf(f"attention_layers.{i}.in_proj_bias", 3 * d)
+            self._buf(f"attention_layers.{i}.out_proj.weight", d, d)
+            self._buf(f"attention_layers.{i}.out_proj.bias", d)
+            self._buf(f"layer_norms.{i}.weight", d)
+            self._buf(f"layer_norms.{i}.bias", d)
+            self.get_buffer(f"layer_norms.{i}.weight").fill_(1.0)
+        if self.use_positional_encoding:                           # attention_probe.py:72-82
+            n = self.max_sequence_length or 1000
+            pe = torch.zeros(n, d)
+            pos = torch.arange(0, n, dtype=torch.float).unsqueeze(1)
+            div = torch.exp(torch.arange(0, d, 2).float() * (-torch.log(torch.tensor(10000.0)) / d))
+            pe[:, 0::2] = torch.sin(pos * div)
+            pe[:, 1::2] = torch.cos(pos * div)
+            self.register_buffer("pos_encoding", pe.unsqueeze(0))
+        else:
+            self.pos_encoding = None
+        self._buf("classifier.weight", self.num_classes, d)
+        self._buf("classifier.bias", self.num_classes)
+
+    @torch.no_grad()
+    def forward(self, x, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = self._combine(self._get_embeddings(x, padding_mask))
+        B, T, D = h.shape
+        if self.pos_encoding is not None:
+            h = h + self.pos_encoding[:, :T]
+        if padding_mask is not None and padding_mask.shape[1] != T:   # attention_probe.py:124-125
+            padding_mask = None
+        for i in range(self.num_layers):
+            qkv = K.dense_f32(h, self._p(f"attention_layers.{i}.in_proj_weight"), self._p(f"attention_layers.{i}.in_proj_bias"))
+            att = K.mha_f32(qkv, self.num_heads, padding_mask)
+            y = K.dense_f32(att, self._p(f"attention_layers.{i}.out_proj.weight"), self._p(f"attention_layers.{i}.out_proj.bias"), resid=h)
+            h = K.layernorm(y.reshape(B * T, D), self._p(f"layer_norms.{i}.weight"), self._p(f"layer_norms.{i}.bias"), eps=1e-5,
+                            want_f32=True, want_half=False)[0].reshape(B, T, D)
+        pooled = K.mean_pool(h)
+        return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))
+
+
+PROBES: Dict[str, type] = {"linear": LinearProbe, "mlp": MLPProbe, "attention": AttentionProbe}

@@ -132,6 +132,21 @@ int avexhip_wavconv0(const float* wav_dev, int B, int64_t T, int64_t wav_stride,
                      const float* gn_w_dev, const float* gn_b_dev, float eps, float* stats_dev, void* out_dev,
                      int frames_pad, int dtype, void* stream);
 
+/* Probe heads on the device: the forward of the reference's online probes after extract_embeddings(), fp32.
+ *   avexhip_layer_mix  base_probes.py:197-206 `_sum`: out[i] = sum_l softmax(layer_weights)_l * taps[l][i] (every weight 1.0 when
+ *                      layer_weights_dev is NULL, as the reference does without learned weights); `taps` is a HOST array of L <= 16
+ *                      device pointers, each to n floats;
+ *   avexhip_dense_f32  nn.Linear with an optional activation (0 none, 1 ReLU, 2 erf-GELU, 3 Tanh) and an optional residual added
+ *                      after it: out[m][n] = act(bias[n] + sum_k x[m][k] w[n][k]) + resid[m][n]   (linear_probe.py:44-46,66;
+ *                      mlp_probe.py:51-73,91; attention_probe.py:59-86,128-134);
+ *   avexhip_mha_f32    the attention core of nn.MultiheadAttention(batch_first=True) in eval (attention_probe.py:128): qkv
+ *                      [B*T, 3E] = in_proj output (q | k | v thirds, head h at columns h*E/H..), key_pad optional [B, T] uint8
+ *                      (1 = ignore key), out [B*T, E] (to be fed to out_proj).  E/H a multiple of 4, <= 128; T <= 2048. */
+int avexhip_layer_mix(const float* const* taps, int L, const float* layer_weights_dev, int64_t n, float* out_dev, void* stream);
+int avexhip_dense_f32(const float* x_dev, int64_t ldx, const float* w_dev, int64_t ldw, const float* bias_dev, const float* resid_dev,
+                      int64_t ldr, int M, int N, int K, int act, float* out_dev, int64_t ldo, void* stream);
+int avexhip_mha_f32(const float* qkv_dev, int B, int T, int E, int H, const uint8_t* key_pad_dev, float* out_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Building blocks (exported so every kernel can be parity-tested in isolation through the ABI).
  * `dtype` selects the half operand type of the half buffers.

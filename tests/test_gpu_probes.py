@@ -1,0 +1,129 @@
+"""Device probe heads against the reference's probe classes (committed goldens) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from _util import rel_l2
+from avex_amd import synth
+from oracle import probe_oracle as PO
+
+pytestmark = pytest.mark.gpu
+
+
+def _sd(g, prefix, dev="cuda"):
+    return {k[len(prefix) + 4:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith(prefix + ".sd.")}
+
+
+def test_layer_mix_bit_exact(built_lib):
+    from avex_amd import kernels as K
+    g = torch.Generator().manual_seed(0)
+    taps = [torch.randn(7, 333, generator=g).cuda() for _ in range(5)]
+    out = K.layer_mix(taps)                                       # no weights: ones, sequential fp32 adds
+    ref = torch.zeros_like(taps[0])
+    for t in taps:
+        ref = ref + 1.0 * t
+    assert torch.equal(out, ref)
+    lw = torch.randn(5, generator=g).cuda()
+    w = torch.softmax(lw, 0)
+    ref = torch.zeros_like(taps[0])
+    for t, wl in zip(taps, w):
+        ref = ref + wl * t
+    assert rel_l2(K.layer_mix(taps, lw).cpu().numpy(), ref.cpu().numpy()) < 3e-7
+    with pytest.raises(ValueError):
+        K.layer_mix([taps[0], taps[1][:, :10]])
+
+
+@pytest.mark.parametrize("M,N,K_", [(5, 37, 768), (1, 1, 1), (130, 129, 19), (300, 2304, 768), (257, 64, 4099)])
+@pytest.mark.parametrize("act", [None, "relu", "gelu", "tanh"])
+def test_dense_f32(built_lib, M, N, K_, act):
+    from avex_amd import kernels as K
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K_, generator=g)
+    w = torch.randn(N, K_, generator=g) * K_ ** -0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    y = x.double() @ w.double().T + b.double()
+    y = {None: y, "relu": torch.relu(y), "gelu": torch.nn.functional.gelu(y), "tanh": torch.tanh(y)}[act] + r.double()
+    out = K.dense_f32(x.cuda(), w.cuda(), b.cuda(), act=act, resid=r.cuda())
+    assert rel_l2(out.cpu().numpy(), y.numpy()) < 2e-6
+    out = K.dense_f32(x.cuda(), w.cuda())                          # no bias, no residual
+    assert rel_l2(out.cpu().numpy(), (x.double() @ w.double().T).numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("B,T,E,H", [(2, 24, 128, 4), (3, 496, 768, 8), (1, 17, 96, 2), (2, 100, 64, 16), (2, 200, 512, 8), (1, 130, 256, 2), (1, 129, 96, 1)])
+def test_mha_f32(built_lib, B, T, E, H):
+    from avex_amd import kernels as K
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, E, generator=g)
+    mha = torch.nn.MultiheadAttention(E, H, batch_first=True).eval()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[-1, T // 2:] = True
+    for kp in (None, pad):
+        with torch.no_grad():
+            ref, _ = mha.double()(x.double(), x.double(), x.double(), key_padding_mask=kp)
+        mha.float()
+        qkv = K.dense_f32(x.cuda(), mha.in_proj_weight.detach().float().cuda(), mha.in_proj_bias.detach().float().cuda())
+        att = K.mha_f32(qkv, H, None if kp is None else kp.cuda())
+        out = K.dense_f32(att, mha.out_proj.weight.detach().float().cuda(), mha.out_proj.bias.detach().float().cuda())
+        assert rel_l2(out.cpu().numpy(), ref.numpy()) < 3e-6
+
+
+def test_probes_match_reference_goldens(built_lib, golden_dir):
+    from avex_amd import probes as P
+    g = np.load(f"{golden_dir}/probes.npz")
+    embs = [torch.from_numpy(e).cuda() for e in g["embs"]]
+    lin = P.LinearProbe(None, [], 37, feature_mode=True, input_dim=[(768,)] * 4)
+    lin.load_state_dict(_sd(g, "lin"))
+    assert rel_l2(lin({f"l{i}": e for i, e in enumerate(embs)}).cpu().numpy(), g["lin.logits"]) < 3e-6
+    lin1 = P.LinearProbe(None, [], 37, feature_mode=True, input_dim=768)
+    lin1.load_state_dict(_sd(g, "lin1"))
+    assert rel_l2(lin1(embs[0]).cpu().numpy(), g["lin1.logits"]) < 3e-6
+    for act in ("relu", "gelu", "tanh"):
+        mlp = P.MLPProbe(None, [], 37, feature_mode=True, input_dim=[(768,)] * 4, hidden_dims=[256, 64], dropout_rate=0.1, activation=act)
+        mlp.load_state_dict(_sd(g, f"mlp_{act}"))
+        assert rel_l2(mlp(embs).cpu().numpy(), g[f"mlp_{act}.logits"]) < 3e-6
+    seqs = [torch.from_numpy(e).cuda() for e in g["seqs"]]
+    att = P.AttentionProbe(None, [], 37, feature_mode=True, input_dim=[(24, 128)] * 3, aggregation="none", num_heads=4, num_layers=2,
+                           dropout_rate=0.0, max_sequence_length=64, use_positional_encoding=True)
+    att.load_state_dict(_sd(g, "att"))
+    assert rel_l2(att(seqs).cpu().numpy(), g["att.logits"]) < 1e-5
+
+
+@pytest.fixture(scope="module")
+def beats_model(built_lib, tmp_path_factory):
+    import avex_amd
+    from safetensors.numpy import save_file
+    path = tmp_path_factory.mktemp("ckpt") / "synthetic_beats.safetensors"
+    save_file({k: np.ascontiguousarray(v) for k, v in synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0).items()}, str(path))
+    return avex_amd.load_model("esp_aves2_sl_beats_all", device="cuda", checkpoint_path=str(path), return_features_only=True).eval()
+
+
+def test_probe_with_base_model(built_lib, beats_model):
+    """The online-probing shape: the BEATs model mirror as base_model, hooks on three layers, logits without leaving the device;
+    checked against the probe oracle applied to the same device embeddings."""
+    from avex_amd import probes as P
+    layers = beats_model.register_hooks_for_layers(["backbone.encoder.layers.3.fc2", "backbone.encoder.layers.7.fc2", "last_layer"])
+    try:
+        wav = torch.from_numpy(synth.noise_clips(3, 32000, seed=3)).cuda()
+        gen = torch.Generator().manual_seed(5)
+        # aggregation "mean": one (B, 768 * 3) tensor -> Linear(2304, C)
+        lin = P.LinearProbe(beats_model, layers, 11, aggregation="mean", target_length=32000)
+        assert lin.inferred_dim == 768 * len(layers)
+        sd = {"classifier.weight": torch.randn(11, lin.inferred_dim, generator=gen) * 0.03, "classifier.bias": torch.randn(11, generator=gen)}
+        lin.load_state_dict({k: v.cuda() for k, v in sd.items()}, strict=False)   # base_model.* keys stay, as in the reference
+        logits = lin({"raw_wav": wav, "padding_mask": None})
+        emb = beats_model.extract_embeddings(wav, aggregation="mean")
+        assert logits.is_cuda and logits.shape == (3, 11)
+        assert rel_l2(logits.cpu().numpy(), PO.linear_probe(emb.cpu().numpy(), {k: v.numpy() for k, v in sd.items()})) < 3e-6
+        # aggregation "none": a list of (B, T', 768) taps -> learned mix -> attention probe
+        att = P.AttentionProbe(beats_model, layers, 11, aggregation="none", num_heads=8, num_layers=1, dropout_rate=0.0, target_length=32000)
+        sd = {k: (torch.randn(v.shape, generator=gen) * (0.5 if v.dim() == 1 else v.shape[-1] ** -0.5)) for k, v in att.state_dict().items()
+              if not k.startswith("base_model.")}
+        att.load_state_dict({k: v.cuda() for k, v in sd.items()}, strict=False)
+        logits = att(wav)
+        taps = beats_model.extract_embeddings(wav, aggregation="none")
+        assert isinstance(taps, list) and len(taps) == len(layers)
+        ref = PO.attention_probe([t.cpu().numpy() for t in taps], {k: v.numpy() for k, v in sd.items()}, num_heads=8)
+        assert rel_l2(logits.cpu().numpy(), ref) < 1e-5
+    finally:
+        beats_model.deregister_all_hooks()

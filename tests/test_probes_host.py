@@ -1,0 +1,47 @@
+"""Host side of the device probe heads: constructor surface, state_dict key names identical to the reference's probe
+classes (from the committed goldens), loud failures without a GPU / for training."""
+import numpy as np
+import pytest
+import torch
+
+from avex_amd import probes as P
+
+
+def _keys(g, prefix):
+    return {k[len(prefix) + 4:] for k in g.files if k.startswith(prefix + ".sd.")}
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    g = np.load(f"{golden_dir}/probes.npz")
+    lin = P.LinearProbe(None, [], 37, device="cpu", feature_mode=True, input_dim=[(768,)] * 4)
+    assert set(lin.state_dict()) == _keys(g, "lin")
+    lin1 = P.LinearProbe(None, [], 37, device="cpu", feature_mode=True, input_dim=768)
+    assert set(lin1.state_dict()) == _keys(g, "lin1") and not hasattr(lin1, "layer_weights")
+    mlp = P.MLPProbe(None, [], 37, device="cpu", feature_mode=True, input_dim=[(768,)] * 4, hidden_dims=[256, 64], dropout_rate=0.1)
+    assert set(mlp.state_dict()) == _keys(g, "mlp_relu")
+    assert {k: tuple(v.shape) for k, v in mlp.state_dict().items()} == {k[12:]: g[k].shape for k in g.files if k.startswith("mlp_relu.sd.")}
+    mlp0 = P.MLPProbe(None, [], 3, device="cpu", feature_mode=True, input_dim=16, hidden_dims=[8], dropout_rate=0.0)
+    assert set(mlp0.state_dict()) == {"mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"}      # no Dropout slot
+    att = P.AttentionProbe(None, [], 37, device="cpu", feature_mode=True, input_dim=[(24, 128)] * 3, aggregation="none", num_heads=4,
+                           num_layers=2, max_sequence_length=64, use_positional_encoding=True)
+    assert set(att.state_dict()) == _keys(g, "att")
+    assert torch.allclose(att.pos_encoding, torch.from_numpy(g["att.sd.pos_encoding"]), atol=1e-6)
+    att.load_state_dict({k: torch.from_numpy(g["att.sd." + k]) for k in _keys(g, "att")})
+    assert "Number of layers: 3" in att.get_learned_weights_table()
+
+
+def test_refusals():
+    lin = P.LinearProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=32)
+    with pytest.raises(NotImplementedError):
+        lin.train()
+    assert lin.eval() is lin
+    with pytest.raises(RuntimeError):                                         # no CPU fallback: the kernels need device tensors
+        lin(torch.zeros(2, 32))
+    with pytest.raises(ValueError):
+        P.LinearProbe(None, [], 5, device="cpu", feature_mode=True)
+    with pytest.raises(NotImplementedError):
+        P.LinearProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=[(32,), (64,)])
+    with pytest.raises(NotImplementedError):
+        P.LinearProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=32, freeze_backbone=False)
+    with pytest.raises(ValueError):
+        P.MLPProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=32, activation="swish")
