@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libavexhip.so")
+LIB_PATH = os.environ.get("AVEX_AMD_LIB") or os.path.join(HERE, "lib", "libavexhip.so")   # AVEX_AMD_LIB: A/B builds of the same ABI
 
 F16, BF16 = 0, 1
 DTYPE_NAMES = {"f16": F16, "fp16": F16, "float16": F16, "bf16": BF16, "bfloat16": BF16}

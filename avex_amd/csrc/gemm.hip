@@ -231,12 +231,19 @@ constexpr int LDS2 = 2 * STAGE2 + 4096;
         xf[j][0] = *(const v8*)(r + foff0);                                                    \
         xf[j][1] = *(const v8*)(r + foff1);                                                    \
     }
+// AVX_SNAKE: walk the 4 x 4 MFMA grid boustrophedon so that consecutive MFMAs share one operand register (the B fragment stays when
+// the A fragment changes): operand toggling is worth a few percent of MFMA power (profiles/r01h_mfma_power.txt)
+#ifndef AVX_SNAKE
+#define AVX_SNAKE 1
+#endif
 #define AVX_HALF(hw)                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
+        const int j = AVX_SNAKE && (i & 1) ? 3 - jj : jj;                                      \
         acc[4 * (hw) + i][j] = mfma16(wf[i][ks], xf[j][ks], acc[4 * (hw) + i][j]);             \
+    }                                                                                          \
     __builtin_amdgcn_s_setprio(0);
 #define AVX_BAR()                                   \
     __builtin_amdgcn_sched_barrier(0);              \
