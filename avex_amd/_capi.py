@@ -96,6 +96,7 @@ SYMBOLS = {
     "avexhip_debug_lds_canary": (C.c_int, [C.c_int, C.c_int, _P, _P]),
     "avexhip_debug_gemm_stamps": (C.c_int, [C.c_int, _P, C.c_int]),
     "avexhip_debug_gemm_clocks": (C.c_int, [_P, C.c_int]),
+    "avexhip_debug_gemm_kclocks": (C.c_int, [_P, C.c_int]),
     "avexhip_beats_create": (_P, [C.POINTER(BeatsConfig), C.POINTER(Tensor), C.c_int]),
     "avexhip_beats_destroy": (None, [_P]),
     "avexhip_beats_num_tokens": (C.c_int, [_P, C.c_int64]),

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 // ---------------------------------------------------------------------------------------------
 __device__ unsigned long long g_gemm_stamps[4 * 8192];
 __device__ int g_gemm_stamps_on = 0;
-__device__ unsigned long long g_gemm_clk[2 * 8192];   // s_memtime (shader clock) at loop start / end, variant 5
+__device__ unsigned long long g_gemm_clk[2 * 8192];
+__device__ unsigned long long g_gemm_kclk[256 * 64];   // s_memtime at the top of every K-tile of each workgroup's third tile, variant 5   // s_memtime (shader clock) at loop start / end, variant 5
 
 constexpr int T2 = 256;
 // Tile walk of the 256-tile kernels: consecutive logical tile ids (each XCD owns a contiguous range of them, and its 32 CUs
@@ -233,6 +234,16 @@ constexpr int LDS2 = 2 * STAGE2 + 4096;
     }
 // AVX_SNAKE: walk the 4 x 4 MFMA grid boustrophedon so that consecutive MFMAs share one operand register (the B fragment stays when
 // the A fragment changes): operand toggling is worth a few percent of MFMA power (profiles/r01h_mfma_power.txt)
+// GEMM_NT: the 256-tile kernels' output stores carry the non-temporal hint.  Outputs are hundreds of MB per launch and are read next by
+// another kernel: letting them allocate in the 4 MiB L2 evicts the A / weight panels the next K-tiles need (profiles/r01h_gemm_nt.txt)
+#ifndef GEMM_NT
+#define GEMM_NT 1
+#endif
+template <typename V>
+static __device__ __forceinline__ void st_out(V* ptr, const V& v) {
+    if (GEMM_NT) __builtin_nontemporal_store(v, ptr);
+    else *ptr = v;
+}
 #ifndef AVX_SNAKE
 #define AVX_SNAKE 1
 #endif
@@ -310,7 +321,7 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
             const int ml = 8 * ps + er;
             const int m = m0 + wn * 64 + ml;
             const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
-            if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+            if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
         }
         asm volatile("" ::: "memory");
     }
@@ -384,7 +395,7 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
-                if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
                 if (STATS) {
                     // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
                     // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
@@ -600,8 +611,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                         v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
                     }
                     if (p.out_raw) {
-                        *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb) = v0;
-                        *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4) = v1;
+                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0);
+                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1);
                     }
                     if (p.resid) {
                         const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
@@ -624,14 +635,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                     }
                     if (p.gelu) { v0 = act4(v0, p.gelu); v1 = act4(v1, p.gelu); }
                     if (p.out_f32) {
-                        *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb) = v0;
-                        *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4) = v1;
+                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0);
+                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1);
                     }
                     if (p.out_half) {
                         v8 h;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
-                        *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                        st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
                     }
                     if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
                         const f32x4 q0 = v0 * v0, q1 = v1 * v1;     // same order as the branch-free epilogue
@@ -663,6 +674,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
 // per-tile cost is not a pipeline-drain cost; kept as a diagnostic vehicle (scripts/gemm_stamps5.py), variant 2 stays default.
 // ---------------------------------------------------------------------------------------------
 constexpr int LDS5 = 2 * STAGE2 + 32768;
+#ifndef GEMM_NOSTORE
+#define GEMM_NOSTORE 0   // diagnostic builds: 1 drops the half-only epilogue's global stores of variant 5 (is the tile start waiting for them?)
+#endif
 
 template <typename T, int EPI>   // EPI: 0 generic epilogue, 1 half + bias (+GELU), 2 half + bias + half residual
 __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
@@ -769,6 +783,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         if (stamp) { g_gemm_stamps[4 * tile + 0] = g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); }
         for (int kt = 0; kt < nk; ++kt) {
             const int st = (g0 + kt) & 1;
+            if (stamp && it == 2 && kt < 63 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + kt] = __builtin_amdgcn_s_memtime();
             AVX_READ_X(st);
             AVX_READ_W(0, st);
             if (kt + 1 < nk) dma_w(1, kt + 1, st ^ 1);
@@ -797,6 +812,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_HALF(1);
             AVX_BAR();
         }
+        if (stamp && it == 2 && nk < 64 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + nk] = __builtin_amdgcn_s_memtime();
         g0 += nk;
         if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); }
 
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         const int ml = 8 * ps + er;
                         const int m = em0 + wn * 64 + 16 * j + ml;
                         const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
-                        if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                        if (m < p.M && !GEMM_NOSTORE) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next chunk overwrites it
                 }
@@ -888,7 +904,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                             h[e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][e], alpha, v0[e]));
                             h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][4 + e], alpha, v1[e]));
                         }
-                        if (m < p.M) *(v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb) = h;
+                        if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
@@ -1023,5 +1039,13 @@ extern "C" int avexhip_debug_gemm_clocks(unsigned long long* host_out, int n_til
     if (!host_out || n_tiles <= 0) return -1;
     if (n_tiles > 8192) n_tiles = 8192;
     if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_clk), sizeof(unsigned long long) * 2 * n_tiles) != hipSuccess) return -2;
+    return 0;
+}
+
+// debug: shader-clock readings at the top of each K-tile (and after the last) of every workgroup's third tile, variant 5: [256][64]
+extern "C" int avexhip_debug_gemm_kclocks(unsigned long long* host_out, int n_blocks) {
+    if (!host_out || n_blocks <= 0) return -1;
+    if (n_blocks > 256) n_blocks = 256;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_kclk), sizeof(unsigned long long) * 64 * n_blocks) != hipSuccess) return -2;
     return 0;
 }

@@ -232,6 +232,9 @@ int avexhip_debug_gemm_stamps(int enable, unsigned long long* host_out, int n_bl
 /* Debug aid: shader-clock counter (s_memtime) at the start and end of each tile's K loop in the persistent GEMM
  * (variant 5), host_out[2*tile + {0,1}]; with the stamps above this gives the clock the chip held in the loop. */
 int avexhip_debug_gemm_clocks(unsigned long long* host_out, int n_tiles);
+/* Debug aid: s_memtime at the top of every K-tile (and after the last one) of each workgroup's third tile in the persistent GEMM
+ * (variant 5, stamps enabled): host_out[64 * block + kt], blocks < 256, kt < 64. */
+int avexhip_debug_gemm_kclocks(unsigned long long* host_out, int n_blocks);
 
 /* T5 bidirectional bucket of a relative position (backbone.py:438-473).  Pure host function. */
 int avexhip_rel_bucket(int rel, int num_buckets, int max_distance);

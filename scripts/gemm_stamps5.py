@@ -31,3 +31,11 @@ print(f"K={Kd} N={N} {mode}: tiles {nt}; span {t[:,3].max() - t[:,0].min():.1f} 
 for name, col in (("wait", 0), ("loop", 1), ("epilogue", 2), ("tile", 3)):
     print(f"  {name:9s} median {np.median(d[:, col]):6.2f}  p10 {np.percentile(d[:, col], 10):6.2f}  p90 {np.percentile(d[:, col], 90):6.2f} us")
 print(f"  loop clock median {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz,10):.3f}, p90 {np.percentile(ghz,90):.3f}); loop cycles/K-tile {np.median(c[:,1]-c[:,0])/(Kd//64):.0f}")
+kc = np.zeros(256 * 64, np.uint64)
+L.avexhip_debug_gemm_kclocks(kc.ctypes.data, 256)
+kc = kc.reshape(256, 64).astype(np.float64)
+nk = Kd // 64
+if nk < 64:
+    dk = np.diff(kc[:, : nk + 1], axis=1)
+    print("  cycles per K-tile by position in the tile (median over 256 workgroups, third tile):")
+    print("   ", " ".join(f"{v:.0f}" for v in np.median(dk, axis=0)))
