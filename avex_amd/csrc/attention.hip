@@ -420,7 +420,10 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
                     typedef int i32x4_t __attribute__((ext_vector_type(4)));
                     const i32x4_t w = {x0, x1, y0, y1};
-                    if (qi[u] < Tn) *(i32x4_t*)(orow + 32 * oh + 16 * gp) = w;
+                    if (qi[u] < Tn) {
+                        if (dbg == 8) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(orow + 32 * oh + 16 * gp), "v"(w) : "memory");   // A/B: AVEX_AMD_ATT_DEBUG=8
+                        else *(i32x4_t*)(orow + 32 * oh + 16 * gp) = w;
+                    }
                 }
             }
         }

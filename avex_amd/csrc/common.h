@@ -219,6 +219,7 @@ struct GemmArgs {
     int tile_order;           // 256-tile kernel: 0 = grouped walk (default), 1 = row-major (A/B experiments)
     int stagger_ticks;        // variant 5: workgroups of odd slot start this many 10-ns ticks late (desynchronised epilogues)
     int stagger_groups;       // variant 5: number of start phases (>= 1)
+    int nt;                   // set by the launcher: bit 0 non-temporal output stores (256-tile kernels)
 };
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // exactly one of in / in_half is non-null

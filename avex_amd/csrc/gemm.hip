@@ -240,9 +240,19 @@ constexpr int LDS2 = 2 * STAGE2 + 4096;
 #define GEMM_NT 1
 #endif
 template <typename V>
-static __device__ __forceinline__ void st_out(V* ptr, const V& v) {
-    if (GEMM_NT) __builtin_nontemporal_store(v, ptr);
+static __device__ __forceinline__ void st_out(V* ptr, const V& v, int nt) {
+    static_assert(sizeof(V) == 16, "16-byte stores only");
+    typedef int i32x4_st __attribute__((ext_vector_type(4)));
+    // the hinted store is inline asm: written as a builtin next to the plain store, the two branches are merged into ONE plain store
+    // (the !nontemporal metadata is dropped) and the hint silently disappears
+    if (GEMM_NT && (nt & 1)) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(__builtin_bit_cast(i32x4_st, v)) : "memory");
     else *ptr = v;
+}
+// AVEX_AMD_GEMM_NT: 0 no hints, 1 (default) non-temporal output stores, 5 = only for outputs wider than 768 columns (diagnostics)
+static int gemm_nt_mode(const avx::GemmArgs& a) {
+    static const int mode = getenv("AVEX_AMD_GEMM_NT") ? atoi(getenv("AVEX_AMD_GEMM_NT")) : 1;
+    if ((mode & 4) && a.N <= 768) return 0;
+    return mode & 1;
 }
 #ifndef AVX_SNAKE
 #define AVX_SNAKE 1
@@ -321,7 +331,7 @@ static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32
             const int ml = 8 * ps + er;
             const int m = m0 + wn * 64 + ml;
             const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
-            if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
+            if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
         }
         asm volatile("" ::: "memory");
     }
@@ -395,7 +405,7 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
-                if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
+                if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                 if (STATS) {
                     // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
                     // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
@@ -611,8 +621,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                         v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
                     }
                     if (p.out_raw) {
-                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0);
-                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1);
+                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0, p.nt);
+                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1, p.nt);
                     }
                     if (p.resid) {
                         const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
@@ -635,14 +645,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
                     }
                     if (p.gelu) { v0 = act4(v0, p.gelu); v1 = act4(v1, p.gelu); }
                     if (p.out_f32) {
-                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0);
-                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1);
+                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0, p.nt);
+                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1, p.nt);
                     }
                     if (p.out_half) {
                         v8 h;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
-                        st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
+                        st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                     }
                     if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
                         const f32x4 q0 = v0 * v0, q1 = v1 * v1;     // same order as the branch-free epilogue
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         const int ml = 8 * ps + er;
                         const int m = em0 + wn * 64 + 16 * j + ml;
                         const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
-                        if (m < p.M && !GEMM_NOSTORE) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
+                        if (m < p.M && !GEMM_NOSTORE) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next chunk overwrites it
                 }
@@ -904,7 +914,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                             h[e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][e], alpha, v0[e]));
                             h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][4 + e], alpha, v1[e]));
                         }
-                        if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h);
+                        if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
@@ -957,6 +967,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
         avx::GemmArgs a5 = a;
         a5.stagger_ticks = 0; a5.stagger_groups = 1;
+        a5.nt = gemm_nt_mode(a);
         int grid = tiles < n_cu ? ((tiles + 7) / 8) * 8 : (n_cu / 8) * 8;
         if (grid < 8) grid = 8;
         if (const char* fg = getenv("AVEX_AMD_GEMM_GRID")) { const int g = atoi(fg); if (g >= 8) grid = (g / 8) * 8; }   // tests: force many tiles per workgroup
@@ -976,6 +987,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         static const int order = getenv("AVEX_AMD_GEMM_TILE_ORDER") ? atoi(getenv("AVEX_AMD_GEMM_TILE_ORDER")) : 0;
         avx::GemmArgs a2 = a;
         a2.tile_order = order;
+        a2.nt = gemm_nt_mode(a);
         hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), LDS2, s, a2);
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;

@@ -10,7 +10,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 2304
 mode = sys.argv[3] if len(sys.argv) > 3 else "half"
 M = 256 * 496
 x = torch.randn(M, Kd, device="cuda").half(); w = (torch.randn(N, Kd, device="cuda") * 0.05).half(); bias = torch.randn(N, device="cuda")
-kw = dict(bias=bias, out_f32=False, out_half=True, variant=5)
+variant = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+kw = dict(bias=bias, out_f32=False, out_half=True, variant=variant)
 if mode == "gelu": kw["gelu"] = True
 if mode == "resid": kw["resid_half"] = torch.randn(M, N, device="cuda").half(); kw["alpha"] = 2.2
 L = _capi.lib()
@@ -27,7 +28,7 @@ t = buf.reshape(nt, 4).astype(np.float64) / 100.0
 c = clk.reshape(nt, 2).astype(np.float64)
 d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]], 1)
 ghz = (c[:, 1] - c[:, 0]) / (t[:, 2] - t[:, 1]) / 1e3
-print(f"K={Kd} N={N} {mode}: tiles {nt}; span {t[:,3].max() - t[:,0].min():.1f} us")
+print(f"variant {variant} K={Kd} N={N} {mode}: tiles {nt}; span {t[:,3].max() - t[:,0].min():.1f} us")
 for name, col in (("wait", 0), ("loop", 1), ("epilogue", 2), ("tile", 3)):
     print(f"  {name:9s} median {np.median(d[:, col]):6.2f}  p10 {np.percentile(d[:, col], 10):6.2f}  p90 {np.percentile(d[:, col], 90):6.2f} us")
 print(f"  loop clock median {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz,10):.3f}, p90 {np.percentile(ghz,90):.3f}); loop cycles/K-tile {np.median(c[:,1]-c[:,0])/(Kd//64):.0f}")
@@ -35,7 +36,7 @@ kc = np.zeros(256 * 64, np.uint64)
 L.avexhip_debug_gemm_kclocks(kc.ctypes.data, 256)
 kc = kc.reshape(256, 64).astype(np.float64)
 nk = Kd // 64
-if nk < 64:
+if nk < 64 and variant == 5:
     dk = np.diff(kc[:, : nk + 1], axis=1)
     print("  cycles per K-tile by position in the tile (median over 256 workgroups, third tile):")
     print("   ", " ".join(f"{v:.0f}" for v in np.median(dk, axis=0)))
