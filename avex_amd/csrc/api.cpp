@@ -814,7 +814,9 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->fast = c.residual_dtype != 0;
     {
         const char* e = getenv("AVEX_AMD_LN_FOLD");
-        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && !(e && atoi(e) == 0);
+        // AVEX_AMD_LN_FOLD=1 folds the encoder's LayerNorms into the GEMM epilogues (tile-per-workgroup kernel).  Off by default since the
+        // streaming GEMM (which has the plain epilogues only) overtook it: 9 132-9 157 vs 9 035-9 048 clips/s (profiles/r01h_gemm_stream.txt)
+        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && (e && atoi(e) != 0);
     }
     {
         // Independent chunks of a batch can overlap on several HIP streams: one chunk's HBM-bound kernels

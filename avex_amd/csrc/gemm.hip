@@ -353,6 +353,19 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
     const int ldres = LNR ? p.ldy : p.ldrh;
     const float2* lnr = (const float2*)(smem + LNS_OFF + 2048);
     const int nseg_out = p.N >> 6;
+    // All residual rows of the wave's 128 x 64 outputs up front (16 x 16 bytes per lane = 64 VGPRs, free now that the operand fragments
+    // are dead): issued per chunk they exposed the memory latency four times per tile (epilogue 8-10 us against 3.3 us for the plain one)
+    v8 rh[2][2][4];
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                int m = m0 + wn * 64 + 32 * jh + 8 * ps + er;
+                m = m < p.M ? m : p.M - 1;
+                rh[ih][jh][ps] = *(const v8*)(resid + (int64_t)m * ldres + n0 + wm * 128 + 64 * ih + 8 * ec);
+            }
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih) {
         const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;
@@ -367,14 +380,6 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
         }
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh) {
-            // residual rows of this chunk: issued first so their latency hides under the slab round trip
-            v8 rh[4];
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                int m = m0 + wn * 64 + 32 * jh + 8 * ps + er;
-                m = m < p.M ? m : p.M - 1;
-                rh[ps] = *(const v8*)(resid + (int64_t)m * ldres + nb);
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -393,14 +398,14 @@ static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& 
                     const float2 st = lnr[wn * 64 + 32 * jh + ml];      // (rstd, -mu * rstd)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ps][e], st.x, st.y), ga0[e], b0[e]) + v0[e];
-                        o1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ps][4 + e], st.x, st.y), ga1[e], b1[e]) + v1[e];
+                        o0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ih][jh][ps][e], st.x, st.y), ga0[e], b0[e]) + v0[e];
+                        o1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ih][jh][ps][4 + e], st.x, st.y), ga1[e], b1[e]) + v1[e];
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        o0[e] = __builtin_fmaf((float)rh[ps][e], alpha, v0[e] + b0[e]);
-                        o1[e] = __builtin_fmaf((float)rh[ps][4 + e], alpha, v1[e] + b1[e]);
+                        o0[e] = __builtin_fmaf((float)rh[ih][jh][ps][e], alpha, v0[e] + b0[e]);
+                        o1[e] = __builtin_fmaf((float)rh[ih][jh][ps][4 + e], alpha, v1[e] + b1[e]);
                     }
                 }
 #pragma unroll
@@ -775,6 +780,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     AVX_BAR();
     if (wm == 1) { AVX_BAR(); }      // stagger: waves 4-7 run one barrier behind, for the whole tile walk
     int g0 = 0;                      // global K-tile index of the tile's first K-tile: its stage parity
+    constexpr bool early_w1 = EPI == 1 && !GEMM_NOSTORE;
+    bool prev_full = false;
 
     // One continuous K stream over this workgroup's tiles: the DMA for the next tile's first K-tiles is issued by the
     // LAST iterations of the current tile exactly as if they were K-tiles nk, nk + 1 of the same product (the source
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             if (stamp && it == 2 && kt < 63 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + kt] = __builtin_amdgcn_s_memtime();
             AVX_READ_X(st);
             AVX_READ_W(0, st);
-            if (kt + 1 < nk) dma_w(1, kt + 1, st ^ 1);
+            if (kt + 1 < nk) { if (!(early_w1 && kt == 0 && it > 0)) dma_w(1, kt + 1, st ^ 1); }   // (issued before the epilogue, see below)
             else if (has_next) dma_w(1, 0, st ^ 1);                  // pointers already switched (below, one iteration ago)
             if (kt == nk - 2 && has_next) set_tile(next_tile);       // last use of this tile's pointers was the line above
             // next tile's bias row: in the LAST K-tile, i.e. at least four barriers into this tile, when the lagging wave group
@@ -810,7 +817,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_READ_W(1, st);
             if (kt + 2 < nk) {
                 dma_w(0, kt + 2, st); dma_x(0, kt + 2, st); dma_x(1, kt + 2, st);
-                AVX_VMCNT(6);
+                // first K-tile after an epilogue: its 16 global stores sit between K-tile 1's DMAs (older) and these six; count past them
+                // instead of waiting for them to retire (only when the previous tile stored all of its rows, so that the count is exact)
+                if (early_w1 && kt == 0 && it > 0 && prev_full) { AVX_VMCNT(22); }
+                else { AVX_VMCNT(6); }
             } else if (has_next) {
                 dma_w(0, kt + 2 - nk, st); dma_x(0, kt + 2 - nk, st); dma_x(1, kt + 2 - nk, st);
                 AVX_VMCNT(6);
@@ -823,6 +833,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_BAR();
         }
         if (stamp && it == 2 && nk < 64 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + nk] = __builtin_amdgcn_s_memtime();
+        // Re-align the two wave groups for the epilogue (as the tile-per-workgroup kernel does): left staggered, the lagging group cannot
+        // pass its last loop barrier before the leading group reaches the next tile's first one, i.e. the two epilogues run one after the other.
+        if (wm == 0) { AVX_BAR(); }
+        // every wave is past the loop now: the W1 half of the stage K-tile 1 of the next tile goes to is free.  Issued here, ahead of the
+        // epilogue's stores, the first K-tile's counted wait does not have to wait for those stores.
+        if (early_w1 && has_next) dma_w(1, 1, ((g0 + nk) & 1) ^ 1);
         g0 += nk;
         if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); }
 
@@ -922,6 +938,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         }
         if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime();
         if (!has_next) break;
+        prev_full = em0 + T2 <= p.M;
+        if (wm == 1) { AVX_BAR(); }      // stagger again for the next tile's loop
         tile = next_tile;
     }
 }
@@ -942,9 +960,9 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         variant = 2;
     }
     if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
-    if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 2 : 3;
-    if (variant == 2 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
-    if (variant == 5 && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8) || a.K < 2 * BK)) variant = 3;
+    if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? (ln_fold ? 2 : 5) : 3;   // 5 falls back to 2 for epilogues it does not have
+    if (variant == 5 && a.K < 2 * BK) variant = 2;
+    if ((variant == 2 || variant == 5) && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
     if (variant == 5) {
         // the streaming kernel has the two branch-free epilogues only; everything else runs the tile-per-workgroup kernel
         const bool fast_half = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.resid_half && !a.row_zero && !ln_fold;

@@ -11,7 +11,7 @@ for name, sub, scale in (("fetch", f"{tag}_pmc_fetch", 2.0 * 1024), ("write", f"
     for f in files:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            for short in ("gemm256_kernel", "gemm_nt_kernel", "attention_kernel", "attention2_kernel", "layernorm_half_kernel", "layernorm_kernel", "posconv_kernel", "fbank_kernel", "mean_pool_kernel"):
+            for short in ("gemm256p_kernel", "gemm256_kernel", "gemm_nt_kernel", "attention_kernel", "attention2_kernel", "layernorm_half_kernel", "layernorm_kernel", "posconv_kernel", "fbank_kernel", "mean_pool_kernel"):
                 if short in k:
                     per[short].append(float(r["Counter_Value"]) * scale)
     for k, v in per.items():

@@ -22,12 +22,24 @@ def base_sd():
     return synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0)
 
 
-@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres"])
+@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres", "f16-halfres-fold", "bf16-halfres-fold"])
 def encoder(request, built_lib, base_sd):
+    """f32 residual stream (generic GEMM epilogues), half residual stream (default: streaming GEMM + LayerNorm kernels) and half
+    residual stream with the LayerNorms folded into the GEMM epilogues (AVEX_AMD_LN_FOLD=1, read when the handle is created)."""
+    import os
     from avex_amd import kernels as K
     dt = request.param.split("-")[0]
-    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype=dt, max_chunk_clips=3,
-                         residual="half" if request.param.endswith("halfres") else "f32")
+    old = os.environ.get("AVEX_AMD_LN_FOLD")
+    if request.param.endswith("fold"):
+        os.environ["AVEX_AMD_LN_FOLD"] = "1"
+    try:
+        enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype=dt, max_chunk_clips=3,
+                             residual="half" if "halfres" in request.param else "f32")
+    finally:
+        if old is None:
+            os.environ.pop("AVEX_AMD_LN_FOLD", None)
+        else:
+            os.environ["AVEX_AMD_LN_FOLD"] = old
     enc.dtype_name = dt
     yield enc
     enc.close()
