@@ -127,3 +127,22 @@ def test_probe_with_base_model(built_lib, beats_model):
         assert rel_l2(logits.cpu().numpy(), ref) < 1e-5
     finally:
         beats_model.deregister_all_hooks()
+
+
+def test_attention_probe_padding_mask(built_lib, golden_dir):
+    """key_padding_mask path of the attention probe (attention_probe.py:124-128): a mask of the sequence length masks keys, a mask of any
+    other length is dropped; against the oracle on the golden weights."""
+    from avex_amd import probes as P
+    g = np.load(f"{golden_dir}/probes.npz")
+    seqs = [torch.from_numpy(e).cuda() for e in g["seqs"]]
+    att = P.AttentionProbe(None, [], 37, feature_mode=True, input_dim=[(24, 128)] * 3, aggregation="none", num_heads=4, num_layers=2,
+                           dropout_rate=0.0, max_sequence_length=64, use_positional_encoding=True)
+    att.load_state_dict(_sd(g, "att"))
+    sd = {k[7:]: g[k] for k in g.files if k.startswith("att.sd.")}
+    pad = np.zeros((3, 24), bool); pad[1, 15:] = True; pad[2, :3] = True
+    ref = PO.attention_probe(list(g["seqs"]), sd, num_heads=4, key_pad=pad)
+    out = att(seqs, padding_mask=torch.from_numpy(pad).cuda())
+    assert rel_l2(out.cpu().numpy(), ref) < 1e-5
+    assert rel_l2(out.cpu().numpy(), g["att.logits"]) > 1e-3                       # the mask changed something
+    dropped = att(seqs, padding_mask=torch.zeros(3, 160000, dtype=torch.bool).cuda())   # sample-level mask: ignored, as in the reference
+    assert rel_l2(dropped.cpu().numpy(), g["att.logits"]) < 1e-5
