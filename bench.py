@@ -182,7 +182,8 @@ def main():
                 "launches_per_step": n_gemm_launch, "avg_launch_ms": round(gemm_ms / n_gemm_launch, 4),
                 "gemm_share_of_step": round(gemm_ms / total_ms, 3),
                 "note": "peak is the 2.4 GHz dense MFMA figure; this kernel (and the step as a whole) runs at the board's 1400 W power cap, "
-                        "shader clock 1.5-1.9 GHz on random operands (profiles/r01c_gemm_power.txt, profiles/r01e_step_power.txt)"}
+                        "shader clock 1.5-1.9 GHz on random operands (profiles/r01c_gemm_power.txt, profiles/r01e_step_power.txt); a register-only MFMA loop "
+                        "on random halves sustains 1.8 PFLOP/s under that cap, 1.4 with this kernel's LDS traffic (profiles/r01h_mfma_power.txt)"}
 
     if rank == 0:
         clips = world * B * args.steps
