@@ -715,7 +715,13 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             float* xo = nullptr;
             if (last) xo = features_out ? features_out + (size_t)c0 * Tt * E : ((pooled_out || !fast) ? x32 : nullptr);
             else if (!fast) xo = x32;
-            if (!fold) {
+            // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
+            const bool fused_pool = last && pooled_out && !features_out && !fold && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
+            if (fused_pool) {
+                prof.begin("layernorm+mean_pool", 0.0);
+                RC(avx::layernorm_pool(preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, Bc, Tt, E, pooled_out + (size_t)c0 * E, dt, cs));
+                prof.end();
+            } else if (!fold) {
                 prof.begin("layernorm", 0.0);
                 if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
                 prof.end();
@@ -724,7 +730,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
                 RC(avx::layernorm(nullptr, w.xh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, nullptr, E, dt, cs));
                 prof.end();
             }
-            if (last && pooled_out) {
+            if (last && pooled_out && !fused_pool) {
                 prof.begin("mean_pool", 0.0);
                 RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, cs));
                 prof.end();

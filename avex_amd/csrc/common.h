@@ -229,6 +229,9 @@ int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s
 int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t s);
 int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s);
 int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s);
+// final LayerNorm + mean over tokens in one pass (half rows in, [B, C] fp32 out); C % 8 == 0, C <= 768
+int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int B, int T, int C, float* out, int dtype,
+                   hipStream_t s);
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
               hipStream_t s);

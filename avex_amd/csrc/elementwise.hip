@@ -161,6 +161,94 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(const T* __restrict
     }
 }
 
+// Final LayerNorm + mean over tokens in one pass (features.mean(dim=1) of the last LayerNorm's output, beats_model.py:275 / README:80), for
+// callers that want the pooled embedding only: the fp32 feature tensor (390 MB at 256 clips) is neither written nor read back.
+// One 1024-thread workgroup per clip; a half-wave owns a row (same per-row arithmetic as layernorm_half_kernel: two-pass statistics in
+// registers), two rows in flight per half-wave; column sums of (v - mean) * rstd stay in registers, the 32 half-waves are combined through
+// LDS in a fixed order (deterministic), weight and bias are applied once at the end:  mean_t(LN(x)_t) = w * mean_t((x_t - mu_t) rstd_t) + b.
+template <typename T>
+__global__ __launch_bounds__(1024) void layernorm_pool_kernel(const T* __restrict__ in_h, int64_t ld_in, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float eps, int Tn, int C,
+                                                              float* __restrict__ out) {
+    typedef typename Half<T>::v8 v8;
+    __shared__ float part[16][768];
+    const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+    const int nc = C >> 3;
+    const T* base = in_h + (int64_t)blockIdx.x * Tn * ld_in;
+    float acc[3][8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    for (int r0 = hw; r0 < Tn; r0 += 64) {
+        float v[2][3][8];
+        float s[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = r0 + 32 * u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = l32 + 32 * i;
+                if (row < Tn && c < nc) {
+                    const v8 hv = *(const v8*)(base + (int64_t)row * ld_in + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[u][i][e] = (float)hv[e]; s[u] += v[u][i][e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[u][i][e] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float su = s[u];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) su += __shfl_xor(su, o, 32);
+            const float mean = su / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = l32 + 32 * i;
+                if (c < nc) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[u][i][e] -= mean; q += v[u][i][e] * v[u][i][e]; }
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 32);
+            const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+            if (r0 + 32 * u < Tn) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][e] += v[u][i][e] * rstd;
+            }
+        }
+    }
+    // the two half-waves of a wave, then the 16 waves through LDS
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] += __shfl_xor(acc[i][e], 32, 64);
+    if ((threadIdx.x & 63) < 32) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = l32 + 32 * i;
+            if (c < nc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part[wave][c * 8 + e] = acc[i][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += part[k][c];
+        out[(int64_t)blockIdx.x * C + c] = tot / (float)Tn * w[c] + b[c];
+    }
+}
+
 // in [B,T,C] -> out [B,C]; block (64 columns x 4 token phases), grid (C/64, B).
 // With frame_pad: masked mean over non-padded tokens (beats_model.py:269-273).
 __global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ in, int T, int C,
@@ -341,6 +429,23 @@ int layernorm(const float* in, const void* in_half, int64_t ld_in, const float* 
 int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s) {
     AVX_REQUIRE(in && out && B > 0 && T > 0 && C > 0, "mean_pool: bad arguments");
     hipLaunchKernelGGL(mean_pool_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, in, T, C, frame_pad, out);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+// LayerNorm over C (C % 8 == 0, C <= 768) of half rows [B*T, C] followed by the mean over each clip's T rows -> out [B, C] fp32
+int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int B, int T, int C, float* out, int dtype,
+                   hipStream_t s) {
+    AVX_REQUIRE(in_half && w && b && out && B > 0 && T > 0, "layernorm_pool: bad arguments");
+    AVX_REQUIRE(C % 8 == 0 && C <= 768 && ld_in % 8 == 0, "layernorm_pool: C = %d (need a multiple of 8, <= 768)", C);
+    if (dtype == AVEXHIP_F16)
+        hipLaunchKernelGGL(layernorm_pool_kernel<_Float16>, dim3(B), dim3(1024), 0, s, (const _Float16*)in_half, ld_in, w, b, eps, T, C, out);
+    else if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(layernorm_pool_kernel<__bf16>, dim3(B), dim3(1024), 0, s, (const __bf16*)in_half, ld_in, w, b, eps, T, C, out);
+    else {
+        avexhip_set_error("layernorm_pool: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }

@@ -132,4 +132,9 @@ def test_full_size_properties(built_lib, base_sd):
     p2 = enc.forward(wav[perm], want_features=False, want_pooled=True)["pooled"]
     assert torch.equal(p2, p[perm])
     assert torch.isfinite(p).all()
+    # pooled-only batches of >= 32 clips take the fused final LayerNorm + mean kernel; it must agree with pooling the fp32 features
+    sub = wav[:40]
+    f = enc.forward(sub, want_features=True, want_pooled=True)
+    assert rel_l2(p[:40].cpu().numpy(), f["features"].mean(1).cpu().numpy()) < 2e-6
+    assert rel_l2(p[:40].cpu().numpy(), f["pooled"].cpu().numpy()) < 2e-6
     enc.close()
