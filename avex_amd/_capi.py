@@ -113,6 +113,17 @@ SYMBOLS = {
 _lib: Optional[C.CDLL] = None
 
 
+def header_abi_version() -> int:
+    """AVEXHIP_ABI_VERSION as include/avexhip.h declares it (the one place the number is written)."""
+    import re
+    hdr = os.path.join(os.path.dirname(HERE), "include", "avexhip.h")
+    with open(hdr) as f:
+        m = re.search(r"^#define\s+AVEXHIP_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise AvexHipError(f"{hdr} does not define AVEXHIP_ABI_VERSION")
+    return int(m.group(1))
+
+
 def lib() -> C.CDLL:
     """Load libavexhip.so (once).  Raises AvexHipError if it has not been built."""
     global _lib

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
 
 
 def test_host_only_entry_points(built_lib):
-    assert built_lib.avexhip_abi_version() == 2
+    assert built_lib.avexhip_abi_version() == _capi.header_abi_version()
     assert built_lib.avexhip_device_count() >= 0
     assert built_lib.avexhip_rel_bucket(0, 320, 800) == 0
     assert built_lib.avexhip_rel_bucket(1, 320, 800) == 161
@@ -68,3 +68,29 @@ def test_no_cpu_fallback_without_gpu(built_lib):
         kernels.FbankPlan()
     with pytest.raises(_capi.AvexHipError):
         kernels.gemm(torch.zeros(8, 64, dtype=torch.float16), torch.zeros(128, 64, dtype=torch.float16))
+
+
+def test_rel_bucket_product_function_matches_reference_golden(built_lib, golden_dir):
+    """The library's own bucket function (what the Toeplitz bias tables are built from) against the reference's
+    _relative_positions_bucket (backbone.py:438-473) for every offset a 496-token clip has -- bit-exact -- and against the
+    oracle restatement beyond it (the > 512-token range has no golden)."""
+    import numpy as np
+    from oracle import beats_oracle as O
+    g = np.load(f"{golden_dir}/base_api.npz")["bucket_rel_-495..495"]
+    got = np.array([built_lib.avexhip_rel_bucket(d, 320, 800) for d in range(-495, 496)], dtype=np.int64)
+    assert np.array_equal(got, g.astype(np.int64))
+    rel = np.arange(-4000, 4001)
+    want = O.relative_position_bucket(rel, 320, 800)
+    got = np.array([built_lib.avexhip_rel_bucket(int(d), 320, 800) for d in rel], dtype=np.int64)
+    assert np.array_equal(got, np.asarray(want, dtype=np.int64))
+    for nb, md in ((32, 64), (32, 128), (64, 256)):
+        want = O.relative_position_bucket(np.arange(-300, 301), nb, md)
+        got = np.array([built_lib.avexhip_rel_bucket(int(d), nb, md) for d in range(-300, 301)], dtype=np.int64)
+        assert np.array_equal(got, np.asarray(want, dtype=np.int64)), (nb, md)
+
+
+def test_graft_entry_build():
+    """The driver's build entry: compiles/links if stale, loads the library, checks the ABI number against the header."""
+    import importlib
+    g = importlib.import_module("__graft_entry__")
+    g.build()

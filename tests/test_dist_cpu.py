@@ -75,3 +75,29 @@ def test_bench_multi_rank_control_flow(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "clips/s"
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert "RCCL all-gather" in d["config"]["workload"]
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_shell(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver starts the 1-GPU run, with N > 1): the parent starts
+    torch.distributed.run as a child before anything touches a GPU, relays rank 0's single JSON line and the exit code.  The dry run also
+    checks the gathered matrix against the clip-index-keyed generator (row r*B + i = clip r*B + i)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--cpu-dry-run"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["gathered_rows_in_clip_order"] is True and d["config"]["global_batch"] == 6
+
+
+def test_bench_refuses_mismatched_world(tmp_path):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run"], capture_output=True, text=True,
+                       timeout=300, cwd=str(tmp_path), env=env)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
