@@ -77,6 +77,7 @@ SYMBOLS = {
     "avexhip_effnet_dwconv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_effnet_se": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
+    "avexhip_wavconv0_stats_floats": (C.c_int64, [C.c_int, C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),
     "avexhip_layer_mix": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_int64, _P, _P]),
     "avexhip_dense_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),

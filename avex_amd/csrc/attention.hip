@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                     typedef int i32x4_t __attribute__((ext_vector_type(4)));
                     const i32x4_t w = {x0, x1, y0, y1};
                     if (qi[u] < Tn) {
-                        if (dbg == 8) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(orow + 32 * oh + 16 * gp), "v"(w) : "memory");   // A/B: AVEX_AMD_ATT_DEBUG=8
+                        if (dbg == 8) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(orow + 32 * oh + 16 * gp), "v"(w) : "memory");   // A/B: AVEX_AMD_ATT_DEBUG=8
                         else *(i32x4_t*)(orow + 32 * oh + 16 * gp) = w;
                     }
                 }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                             pb = __builtin_elementwise_fma((f32x2){wb[2], wb[3]}, q23, pb);
                         }
                     }
-                    float sa = pa[0] + pa[1], sb = pb[0] + pb[1];
+                    float sa = hsum2(pa), sb = hsum2(pb);
                     sa += __shfl_xor(sa, 32, 64);
                     sb += __shfl_xor(sb, 32, 64);
                     const float ga = 1.f / (1.f + __expf(-(sa + gw[128])));
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                         pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
                     }
                     // !(sum < 2^12) also catches the overflowed (inf) and the invalid (NaN) sum
-                    moves = moves || !ref_set[u] || !(ls[u][0] + ls[u][1] < 4096.f);
+                    moves = moves || !ref_set[u] || !(hsum2(ls[u]) < 4096.f);
                 }
                 if (__any(moves)) {
                     // a row's first unmasked tile sets its reference to the row maximum; later it moves when a tile has grown past it.
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) l_run[u] += ls[u][0] + ls[u][1];
+                for (int u = 0; u < NQ; ++u) l_run[u] += hsum2(ls[u]);
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
                                "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]));

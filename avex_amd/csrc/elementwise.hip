@@ -333,6 +333,18 @@ __global__ __launch_bounds__(256) void lds_canary_kernel(int iters, unsigned* __
     }
 }
 
+// rows m with pad[m] != 0 become zero in the fp32 and/or operand-type copy of x (the encoder's `x[padding_mask] = 0`,
+// backbone.py:169-170, on the path where no GEMM epilogue does it: embed_dim == encoder_embed_dim, no post_extract_proj)
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ x32, unsigned short* __restrict__ xh, int64_t ld32, int64_t ldh,
+                                                        int C, const uint8_t* __restrict__ pad) {
+    const int m = blockIdx.x;
+    if (!pad[m]) return;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (x32) x32[(int64_t)m * ld32 + c] = 0.f;
+        if (xh) xh[(int64_t)m * ldh + c] = 0;          // +0.0 in f16 and in bf16
+    }
+}
+
 // s[n] = sum_k float(W[n][k]) of a half matrix (fp32 accumulate): the column-sum vector of a LayerNorm-folded weight
 template <typename T>
 __global__ __launch_bounds__(256) void row_sum_half_kernel(const T* __restrict__ w, int N, int K, float* __restrict__ out) {
@@ -446,6 +458,13 @@ int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const flo
         avexhip_set_error("layernorm_pool: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;
     }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int zero_rows(float* x32, int64_t ld32, void* x_half, int64_t ldh, int M, int C, const uint8_t* pad, hipStream_t s) {
+    if (!pad || M <= 0 || (!x32 && !x_half)) return AVEXHIP_OK;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(M), dim3(256), 0, s, x32, (unsigned short*)x_half, ld32, ldh, C, pad);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }

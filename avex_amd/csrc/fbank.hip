@@ -50,6 +50,16 @@ constexpr int ZROW = 72;  // complex elements per LDS row (64 + 8 pad)
 // workgroup barrier, only the compiler kept from moving LDS accesses across the exchange points.
 #define AVX_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// Diagnostic build only (scripts/debug/conc_probe3.hip compiles this file with -DAVX_FBANK_TAPS): every wave dumps its
+// registers after each stage so a wrong result can be traced to the first stage that differs.  Never defined in the library.
+#ifdef AVX_FBANK_TAPS
+__device__ float2* g_fbank_taps;
+#define AVX_TAP(stage) do { float2* t_ = g_fbank_taps + ((((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + (stage)) * 64 + lane) * 8; \
+                            _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) t_[q_] = x[q_]; } while (0)
+#else
+#define AVX_TAP(stage) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const float* __restrict__ wav,
                                                     int64_t stride, int frames,
@@ -101,9 +111,29 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     }
 
     // ---- 512-point complex FFT: three radix-8 passes ------------------------------------------
+    AVX_TAP(0);
+#ifdef AVX_FBANK_TAPS
+    {   // the first dft8 spelled out with a tap after its first level (tap slot 7 = a0..a3, b0..b3; slot 1 = result)
+        const float c = 0.70710678118654752440f;
+        float2 y[8];
+        y[0] = x[0] + x[4]; y[1] = x[0] - x[4]; y[2] = x[2] + x[6]; y[3] = mul_mi(x[2] - x[6]);
+        y[4] = x[1] + x[5]; y[5] = x[1] - x[5]; y[6] = x[3] + x[7]; y[7] = mul_mi(x[3] - x[7]);
+        { float2* t_ = g_fbank_taps + ((((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + 7) * 64 + lane) * 8;
+          _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) t_[q_] = y[q_]; }
+        const float2 e0 = y[0] + y[2], e2 = y[0] - y[2], e1 = y[1] + y[3], e3 = y[1] - y[3];
+        const float2 o0 = y[4] + y[6], o2 = y[4] - y[6], o1 = y[5] + y[7], o3 = y[5] - y[7];
+        const float2 t1 = make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));
+        const float2 t2 = mul_mi(o2);
+        const float2 t3 = make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));
+        x[0] = e0 + o0; x[4] = e0 - o0; x[1] = e1 + t1; x[5] = e1 - t1; x[2] = e2 + t2; x[6] = e2 - t2; x[3] = e3 + t3; x[7] = e3 - t3;
+    }
+#else
     dft8(x);
+#endif
+    AVX_TAP(1);
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) x[k1] = cmul(x[k1], tw[lane * k1]);
+    AVX_TAP(2);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) z[k1 * ZROW + lane] = x[k1];
     AVX_WAVE_SYNC();
@@ -111,9 +141,11 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
         const int k1 = lane >> 3, m2 = lane & 7;
 #pragma unroll
         for (int m1 = 0; m1 < 8; ++m1) x[m1] = z[k1 * ZROW + 8 * m1 + m2];
+        AVX_TAP(3);
         dft8(x);
 #pragma unroll
         for (int j1 = 1; j1 < 8; ++j1) x[j1] = cmul(x[j1], tw[8 * m2 * j1]);
+        AVX_TAP(4);
         AVX_WAVE_SYNC();
 #pragma unroll
         for (int j1 = 0; j1 < 8; ++j1) z[k1 * ZROW + j1 * 8 + m2] = x[j1];
@@ -123,7 +155,9 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
         const int k1 = lane & 7, j1 = lane >> 3;
 #pragma unroll
         for (int m2 = 0; m2 < 8; ++m2) x[m2] = z[k1 * ZROW + j1 * 8 + m2];
+        AVX_TAP(5);
         dft8(x);
+        AVX_TAP(6);
         AVX_WAVE_SYNC();
 #pragma unroll
         for (int j2 = 0; j2 < 8; ++j2) z[lane + 64 * j2] = x[j2];  // natural order Z[k]

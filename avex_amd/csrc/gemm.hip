@@ -245,7 +245,7 @@ static __device__ __forceinline__ void st_out(V* ptr, const V& v, int nt) {
     typedef int i32x4_st __attribute__((ext_vector_type(4)));
     // the hinted store is inline asm: written as a builtin next to the plain store, the two branches are merged into ONE plain store
     // (the !nontemporal metadata is dropped) and the hint silently disappears
-    if (GEMM_NT && (nt & 1)) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(ptr), "v"(__builtin_bit_cast(i32x4_st, v)) : "memory");   // s_nop: the hazard recogniser does not see a store in an asm block (a VALU write of the data registers needs one wait state)
+    if (GEMM_NT && (nt & 1)) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(__builtin_bit_cast(i32x4_st, v)) : "memory");   // s_nop 1: the hazard recogniser does not see a store in an asm block; on gfx940+/gfx950 a VMEM store of more than 64 bits followed by a VALU write of its data registers needs TWO wait states
     else *ptr = v;
 }
 // AVEX_AMD_GEMM_NT: 0 no hints, 1 (default) non-temporal output stores, 5 = only for outputs wider than 768 columns (diagnostics)

@@ -4,7 +4,8 @@
 // extractor_mode "group_norm", conv_bias False): Conv1d(1, 512, kernel 10, stride 5) -> GroupNorm(512 groups, 512 channels,
 // affine, eps 1e-5: per clip and channel over time) -> GELU (erf).  One input channel and 10 taps is no MFMA shape, and the
 // normalisation needs every frame of the clip before any output: two passes over the waveform (640 KB per clip, L2-resident)
-// that both compute the convolution in fp32 -- the first only accumulates sum / sum of squares per (clip, channel), the second
+// that both compute the convolution in fp32 -- the first only writes each workgroup's partial sum / sum of squares per (clip,
+// channel) (no atomics: the second pass adds the partials in a fixed order, so results are bit-reproducible), the second
 // normalises, applies GELU and writes the operand-type activations [clip][frame][channel] that the following conv layers
 // consume as strided-row GEMMs.  Nothing of size frames x channels is ever written in fp32.
 #include "common.h"
@@ -30,11 +31,13 @@ __global__ __launch_bounds__(256) void wavconv0_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < WC_K; ++j) { w0[j] = w[c0 * WC_K + j]; w1[j] = w[(c0 + 1) * WC_K + j]; }
     float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f;
+    const int nblk = (frames + WC_FR - 1) / WC_FR;                          // partial statistics: [clip][block][channel][2]
     if (APPLY) {
         const float inv = 1.0f / (float)frames;
-        const float* st = stats + ((int64_t)b * WC_C + c0) * 2;
-        const float m0 = st[0] * inv, m1 = st[2] * inv;
-        const float v0 = fmaxf(__builtin_fmaf(-m0, m0, st[1] * inv), 0.f), v1 = fmaxf(__builtin_fmaf(-m1, m1, st[3] * inv), 0.f);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nblk; ++k) acc += *(const f32x4*)(stats + (((int64_t)b * nblk + k) * WC_C + c0) * 2);
+        const float m0 = acc[0] * inv, m1 = acc[2] * inv;
+        const float v0 = fmaxf(__builtin_fmaf(-m0, m0, acc[1] * inv), 0.f), v1 = fmaxf(__builtin_fmaf(-m1, m1, acc[3] * inv), 0.f);
         sc0 = gn_w[c0] / sqrtf(v0 + eps); sh0 = __builtin_fmaf(-m0, sc0, gn_b[c0]);
         sc1 = gn_w[c0 + 1] / sqrtf(v1 + eps); sh1 = __builtin_fmaf(-m1, sc1, gn_b[c0 + 1]);
     }
@@ -61,9 +64,8 @@ __global__ __launch_bounds__(256) void wavconv0_kernel(const float* __restrict__
         typedef T v2 __attribute__((ext_vector_type(2)));
         v2 z; z[0] = (T)0.0f; z[1] = (T)0.0f;
         for (int t = nf > 0 ? nf : 0; t < tend; ++t) *(v2*)(orow + (int64_t)t * WC_C) = z;
-    } else if (nf > 0) {
-        float* st = stats + ((int64_t)b * WC_C + c0) * 2;
-        atomicAdd(st + 0, s1a); atomicAdd(st + 1, s2a); atomicAdd(st + 2, s1b); atomicAdd(st + 3, s2b);
+    } else {
+        *(f32x4*)(stats + (((int64_t)b * nblk + blockIdx.x) * WC_C + c0) * 2) = (f32x4){s1a, s2a, s1b, s2b};
     }
 }
 
@@ -71,6 +73,12 @@ __global__ __launch_bounds__(256) void wavconv0_kernel(const float* __restrict__
 
 // frames of the first layer for T samples: (T - 10) / 5 + 1
 extern "C" int avexhip_wavconv0_frames(int64_t T) { return T < WC_K ? 0 : (int)((T - WC_K) / WC_S + 1); }
+
+// floats of scratch avexhip_wavconv0 needs for its partial statistics: B * ceil(frames / 1024) * 512 * 2
+extern "C" int64_t avexhip_wavconv0_stats_floats(int B, int64_t T) {
+    const int frames = avexhip_wavconv0_frames(T);
+    return (int64_t)(B > 0 ? B : 0) * ((frames + WC_FR - 1) / WC_FR) * WC_C * 2;
+}
 
 extern "C" int avexhip_wavconv0(const float* wav_dev, int B, int64_t T, int64_t wav_stride, const float* w_dev,
                                 const float* gn_w_dev, const float* gn_b_dev, float eps, float* stats_dev, void* out_dev,
@@ -81,7 +89,6 @@ extern "C" int avexhip_wavconv0(const float* wav_dev, int B, int64_t T, int64_t 
     AVX_REQUIRE(frames_pad >= frames, "wavconv0: frames_pad=%d < frames=%d", frames_pad, frames);
     if (wav_stride <= 0) wav_stride = T;
     hipStream_t s = (hipStream_t)stream;
-    AVX_HIP_CHECK(hipMemsetAsync(stats_dev, 0, sizeof(float) * (size_t)B * WC_C * 2, s));
     const dim3 g1((frames + WC_FR - 1) / WC_FR, B), g2((frames_pad + WC_FR - 1) / WC_FR, B);
     if (dtype == AVEXHIP_BF16) {
         hipLaunchKernelGGL((wavconv0_kernel<__bf16, false>), g1, dim3(256), 0, s, wav_dev, wav_stride, frames, w_dev, stats_dev, gn_w_dev, gn_b_dev, eps, (__bf16*)nullptr, frames_pad);

@@ -75,7 +75,14 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
                 batch, (wav, mask, ready) = nxt, staged
                 nxt = next(it, None)
                 if ready is not None:
-                    torch.cuda.current_stream(device).wait_event(ready)
+                    cur = torch.cuda.current_stream(device)
+                    cur.wait_event(ready)
+                    # the staged tensors were allocated on copy_stream's pool but are read by kernels on the compute stream: tell the
+                    # allocator, or dropping them at the next iteration hands the block to a later H2D copy that does not wait for
+                    # this batch's forward (silently overwritten audio when the host runs ahead)
+                    wav.record_stream(cur)
+                    if mask is not None:
+                        mask.record_stream(cur)
                 if nxt is not None:
                     staged = _stage(nxt, device, copy_stream)                        # overlaps the forward below
                 if mask is None:

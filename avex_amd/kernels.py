@@ -255,7 +255,7 @@ def wavconv0(wav: torch.Tensor, w: torch.Tensor, gn_w: torch.Tensor, gn_b: torch
     wav = wav.contiguous()
     B, T = wav.shape
     out = torch.empty((B * frames_pad + slack_rows, 512), dtype=half_torch_dtype(code), device=wav.device)
-    stats = torch.empty((B, 512, 2), dtype=torch.float32, device=wav.device)
+    stats = torch.empty((int(lib().avexhip_wavconv0_stats_floats(B, T)),), dtype=torch.float32, device=wav.device)
     check(lib().avexhip_wavconv0(_ptr(wav), B, T, wav.stride(0), _ptr(w.contiguous()), _ptr(gn_w), _ptr(gn_b), eps, _ptr(stats),
                                  _ptr(out), frames_pad, code, _stream()), "wavconv0")
     return out

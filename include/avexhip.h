@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 2
+#define AVEXHIP_ABI_VERSION 3
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -124,10 +124,12 @@ int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, i
 /* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
  * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):
  *   Conv1d(1, 512, k=10, s=5) -> GroupNorm(512, 512, eps) over time per (clip, channel) -> GELU
- * wav_dev [B, T] fp32; w_dev [512, 10] fp32; gn_w/gn_b [512]; stats_dev [B, 512, 2] fp32 scratch;
+ * wav_dev [B, T] fp32; w_dev [512, 10] fp32; gn_w/gn_b [512]; stats_dev: avexhip_wavconv0_stats_floats(B, T) floats of scratch
+ * (per-workgroup partial sums, combined in a fixed order: results are bit-reproducible);
  * out_dev [B, frames_pad, 512] half (rows >= frames are zero).  The other six conv layers are strided-row
  * avexhip_gemm calls (A row t of clip b = frames s*t .. s*t+k-1 of the previous layer: lda = s * 512, K = k * 512). */
 int avexhip_wavconv0_frames(int64_t T);
+int64_t avexhip_wavconv0_stats_floats(int B, int64_t T);
 int avexhip_wavconv0(const float* wav_dev, int B, int64_t T, int64_t wav_stride, const float* w_dev,
                      const float* gn_w_dev, const float* gn_b_dev, float eps, float* stats_dev, void* out_dev,
                      int frames_pad, int dtype, void* stream);

@@ -138,3 +138,26 @@ def test_full_size_properties(built_lib, base_sd):
     assert rel_l2(p[:40].cpu().numpy(), f["features"].mean(1).cpu().numpy()) < 2e-6
     assert rel_l2(p[:40].cpu().numpy(), f["pooled"].cpu().numpy()) < 2e-6
     enc.close()
+
+
+def test_model_without_post_extract_proj(built_lib):
+    """embed_dim == encoder_embed_dim: no post_extract_proj (beats.py:357-358).  The padded tokens must still be zeroed before the
+    pos-conv (backbone.py:169-170), hook 0 does not exist and asking for it is refused, not silently left unwritten."""
+    from avex_amd import kernels as K
+    from avex_amd._capi import AvexHipError
+    cfg = dict(synth.BEATS_BASE_CFG, embed_dim=768, encoder_layers=2)
+    sd = synth.beats_state_dict(cfg, seed=4)
+    assert "backbone.post_extract_proj.weight" not in sd
+    x = synth.noise_clips(2, 32000, seed=6)
+    pm = np.zeros((2, 32000), bool); pm[1, 20000:] = True
+    f_ref, taps = O.beats_forward(x, sd, cfg, padding_mask=pm)
+    frames = 1 + (32000 - 400) // 160
+    fpad = O.forward_padding_mask(96, O.forward_padding_mask(frames, pm))
+    for residual in ("half", "f32"):
+        enc = K.BeatsEncoder(cfg, sd, operand_dtype="f16", residual=residual)
+        r = enc.forward(torch.from_numpy(x).cuda(), hook_layers=[2], want_features=True, frame_pad=torch.from_numpy(fpad))
+        assert rel_l2(r["features"].cpu().numpy(), f_ref) < 3e-3
+        assert rel_l2(r["hooks"][2].cpu().numpy().mean(1), taps["backbone.encoder.layers.1.fc2"].mean(1)) < 1e-3
+        with pytest.raises(AvexHipError):
+            enc.forward(torch.from_numpy(x).cuda(), hook_layers=[0], want_features=True)
+        enc.close()
