@@ -500,8 +500,11 @@ Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
 }
 
 // how a batch is split: chunk size and number of concurrent lanes (streams)
-void plan_chunks(const avexhip_beats* h, int B, int* chunk, int* lanes) {
-    int c = B < h->chunk ? B : h->chunk;
+void plan_chunks(const avexhip_beats* h, int B, int Tt, int* chunk, int* lanes) {
+    // max_chunk_clips is sized for 10 s clips (<= 512 tokens); longer clips keep the same number of TOKEN rows per pass
+    int cap = h->chunk;
+    if (Tt > 512) { cap = (int)(((int64_t)h->chunk * 512) / Tt); if (cap < 1) cap = 1; }
+    int c = B < cap ? B : cap;
     int l = 1;
     if (h->nstreams > 1 && B > 1) {
         const int per = (B + h->nstreams - 1) / h->nstreams;
@@ -542,7 +545,6 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     const int nt = frames / P, nf = NM / P;
     const int Tt = nt * nf;
     AVX_REQUIRE(Tt >= 1, "beats_forward: input too short (%d frames -> 0 tokens)", frames);
-    AVX_REQUIRE(Tt <= 512, "beats_forward: %d tokens per clip unsupported (max 512, ~10.3 s of audio)", Tt);
     AVX_REQUIRE(hook_mask == 0 || hook_out, "beats_forward: hook_mask set but hook_out is NULL");
     AVX_REQUIRE((hook_mask >> (L + 1)) == 0, "beats_forward: hook_mask has bits beyond layer %d", L);
     // hook 0 is post_extract_proj's output; a model with embed_dim == encoder_embed_dim has no such layer (beats.py:357-358)
@@ -550,7 +552,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     for (int i = 0; i <= L; ++i)
         AVX_REQUIRE(!((hook_mask >> i) & 1u) || hook_out[i], "beats_forward: hook %d selected but hook_out[%d] is NULL", i, i);
     int chunk = 1, lanes = 1;
-    plan_chunks(h, B, &chunk, &lanes);
+    plan_chunks(h, B, Tt, &chunk, &lanes);
     const Ws need = carve(h, nullptr, chunk, Tt);
     if (!workspace || ws_bytes < need.total * (size_t)lanes) {
         avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total * (size_t)lanes);
@@ -878,7 +880,7 @@ extern "C" size_t avexhip_beats_workspace_bytes(const avexhip_beats* h, int B, i
     const int Tt = avexhip_beats_num_tokens(h, T);
     if (Tt <= 0) return 0;
     int chunk = 1, lanes = 1;
-    plan_chunks(h, B, &chunk, &lanes);
+    plan_chunks(h, B, Tt, &chunk, &lanes);
     return carve(h, nullptr, chunk, Tt).total * (size_t)lanes;
 }
 

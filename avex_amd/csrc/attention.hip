@@ -1,4 +1,4 @@
-// Gated relative-position-bias self-attention for BEATs (head_dim 64, T <= 512) on gfx950.
+// Gated relative-position-bias self-attention for BEATs (head_dim 64, any T) on gfx950.
 //
 // Restates _MultiheadAttention.forward (avex/models/beats/backbone.py:494-574) after the q/k/v
 // projections:  softmax( q k^T / 8 + gate(b,h,i) * bias[h, j-i]  [+ -inf on padded keys] ) v
@@ -273,6 +273,14 @@ constexpr int A2_TAB_OFF = 2 * A2_HALF;
 constexpr int A2_KADD_OFF = A2_TAB_OFF + TAB_BYTES;
 constexpr int A2_GW_OFF = A2_KADD_OFF + 2 * KADD_BYTES;
 constexpr int ATT2_LDS = A2_GW_OFF + GW_BYTES;
+// Long clips (more than 512 tokens): queries in blocks of 512, keys in blocks of 256; a phase is one (query block, key block)
+// pair and carries its own WINDOW of the bias row (the 767 offsets j - i that pair can meet, four shifted copies) and its own
+// 256-entry key mask, both double-buffered and written one phase ahead.  Nothing in LDS depends on T.
+constexpr int A2_WLD = 776;                               // floats per shifted copy of a window
+constexpr int A2_WIN_BYTES = 4 * A2_WLD * 4;              // 12 416
+constexpr int A2L_KADD_OFF = A2_TAB_OFF + 2 * A2_WIN_BYTES;
+constexpr int A2L_GW_OFF = A2L_KADD_OFF + 2 * 256 * 4;
+constexpr int ATT2L_LDS = A2L_GW_OFF + GW_BYTES;
 constexpr float A2_THR = 8.f;
 #ifndef ATT_STAMPS
 #define ATT_STAMPS 0     // diagnostic build: -DATT_STAMPS=1 prints one tile's cycle stamps (AVEX_AMD_ATT_DEBUG=4)
@@ -287,7 +295,7 @@ static __device__ __forceinline__ void a2_dma16(const void* src, const char* lds
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
 }
 
-template <typename T>
+template <typename T, bool LONG>
 __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block,
                                                         const float* __restrict__ bias_tab,
                                                         const float* __restrict__ grep_w,
@@ -300,8 +308,8 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     typedef typename Half<T>::v4 v4;
     constexpr int NQ = 2, NW = 8, NT = 512;              // 8 waves, two 32-query tiles each (tile wave + 8 u)
     float* tab = (float*)(smem + A2_TAB_OFF);
-    float* kadd = (float*)(smem + A2_KADD_OFF);
-    float* gw = (float*)(smem + A2_GW_OFF);
+    float* kadd = (float*)(smem + (LONG ? A2L_KADD_OFF : A2_KADD_OFF));
+    float* gw = (float*)(smem + (LONG ? A2L_GW_OFF : A2_GW_OFF));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,22 +320,28 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     const int E = H * 64;
     const int64_t ld = 3 * (int64_t)E;
     const float NEG_INF = -__builtin_inff();
-    const int nh = Tn > 256 ? 2 : 1;
-    const int np = (it1 - it0) * nh;
+    const int nh = LONG ? (Tn + 255) >> 8 : (Tn > 256 ? 2 : 1);      // key blocks of 256 per query block
+    const int nqb = LONG ? (Tn + 511) >> 9 : 1;                      // query blocks of 512 per item
+    const int np = (it1 - it0) * nqb * nh;
     const int nkt = (Tn + 31) >> 5;
     const int hh = lane >> 5, r32 = lane & 31;
     int qi[NQ], iq[NQ];
+    bool has_q = false;                                  // wave-uniform: tile u = 0 of the current query block exists
+    auto set_qblock = [&](int qb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        qi[u] = (wave + NW * u) * 32 + r32;
-        iq[u] = qi[u] < Tn ? qi[u] : Tn - 1;             // clamped for loads; stores are masked
-    }
-    const bool has_q = wave * 32 < Tn;                   // wave-uniform: tile u = 0 exists
+        for (int u = 0; u < NQ; ++u) {
+            qi[u] = qb * 512 + (wave + NW * u) * 32 + r32;
+            iq[u] = qi[u] < Tn ? qi[u] : Tn - 1;         // clamped for loads; stores are masked
+        }
+        has_q = qb * 512 + wave * 32 < Tn;
+    };
+    set_qblock(0);
 
     // Items are h * Bc + b, walked in order: (h, b) of the item being computed and of the one being loaded are kept
     // incrementally (no division in the loop).  A workgroup's range stays on one head, or two at a seam.
     int h_cur = it0 / Bc, b_cur = it0 - h_cur * Bc;      // item of the phase being computed
-    int h_ld = h_cur, b_ld = b_cur, half_ld = 0;         // (item, half) the next DMA fetches
+    int qb_cur = 0, half = 0;                            // its query block and key block
+    int h_ld = h_cur, b_ld = b_cur, half_ld = 0, qb_ld = 0;   // (item, query block, key block) the next DMA fetches
     int item_par = 0;                                    // parity of the item being computed: its kadd slot
 
     auto issue_next = [&](int ph) __attribute__((always_inline)) {      // DMA for phase ph = (h_ld, b_ld, half_ld), then advance
@@ -346,7 +360,26 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             const int ch = 4 * (lane >> 5) + (lane & 3);
             a2_dma16(base + (int64_t)vkey * ld + 2 * E + ch * 8, buf + A2_KBUF + ri * 1024);
         }
-        if (++half_ld == nh) { half_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } }
+        if (++half_ld == nh) { half_ld = 0; if (++qb_ld == nqb) { qb_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } } }
+    };
+    // LONG: bias window and key mask of phase ph = the load-side state (call BEFORE issue_next(ph) advances it)
+    auto write_window = [&](int ph) __attribute__((always_inline)) {
+        float* win = tab + (ph & 1) * (4 * A2_WLD);
+        const int r0 = half_ld * 256 - qb_ld * 512 - 511 + (Tn - 1);     // bias-row index of window entry 0
+        for (int r = tid; r < A2_WLD; r += NT) {
+            const int g = r0 + r;
+            float v = 0.f;
+            if (bias_tab && g >= 0 && g < 2 * Tn - 1) v = bias_tab[(int64_t)h_ld * (2 * Tn - 1) + g] * 1.4426950408889634f;
+#pragma unroll
+            for (int sft = 0; sft < 4; ++sft)
+                if (r - sft >= 0) win[sft * A2_WLD + (r - sft)] = v;
+        }
+        if (tid < 256) {
+            const int j = half_ld * 256 + tid;
+            bool ok = j < Tn;
+            if (ok && key_pad) ok = key_pad[(int64_t)b_ld * Tn + j] == 0;
+            kadd[(ph & 1) * 256 + tid] = ok ? 0.f : NEG_INF;
+        }
     };
     auto write_kadd = [&](int slot, int b) __attribute__((always_inline)) {
         for (int j = tid; j < TMAX; j += NT) {
@@ -365,8 +398,9 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             for (int s = 0; s < 4; ++s) qf[u][s] = *(const v8*)(base + (int64_t)iq[u] * ld + 16 * s + 8 * hh);
     };
     load_q(h_cur, b_cur);                                // older than the DMA below: waiting for it never waits for the DMA
+    if (LONG) write_window(0);
     issue_next(0);
-    write_kadd(0, b_cur);
+    if (!LONG) write_kadd(0, b_cur);
     if (tid < 64) {
         float a = 0.f, bb = 0.f;
         if (grep_w) {
@@ -430,9 +464,8 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     };
 
     for (int ph = 0; ph < np; ++ph) {
-        const int half = nh == 2 ? (ph & 1) : 0;
         const bool last_half = half == nh - 1;
-        const bool more_items = ph + (nh - half) < np;   // another item follows the one being computed
+        const bool more_items = ph + (nh - half) < np;   // another (item, query block) follows the one being computed
         // phase boundary: this wave's DMA for phase ph (issued one phase ago) has landed and every wave has finished
         // reading the other buffer.  When the previous phase ended an item, the 8 loads of the next item's Q are younger
         // than that DMA and stay in flight.
@@ -446,7 +479,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         AVX_PT(2)
         AVX_PT(3)
         if (half == 0) {
-            if (h_cur != h_tab) {                        // workgroup-uniform
+            if (!LONG && h_cur != h_tab) {               // workgroup-uniform
                 for (int r = tid; r < TAB_LD; r += NT) {
                     float v = 0.f;
                     if (bias_tab && r < 2 * Tn - 1) v = bias_tab[(int64_t)h_cur * (2 * Tn - 1) + r] * 1.4426950408889634f;
@@ -457,7 +490,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 h_tab = h_cur;
                 __syncthreads();
             }
-            if (more_items) {                            // the next item's key mask, read two barriers from now
+            if (!LONG && more_items) {                   // the next item's key mask, read two barriers from now
                 int bn = b_cur + 1;
                 bn = bn == Bc ? 0 : bn;
                 write_kadd(item_par ^ 1, bn);
@@ -494,13 +527,14 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         // previous item) complete HERE, before the DMA goes out: after it a compiler-placed vmcnt wait would wait for the DMA
         // as well.  Passing qf through the statement makes this the definition the tiles see, in every phase, so no wait
         // for those loads is placed inside the tiles.  From here to the next boundary a phase touches only LDS and registers.
+        if (LONG && ph + 1 < np) write_window(ph + 1);   // next phase's bias window + key mask (other slot; read after the next barrier)
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]));
         if (ph + 1 < np && dbg != 3) issue_next(ph + 1);
         AVX_PT(4)
         if (has_q) {
             const char* Kb = smem + (ph & 1) * A2_HALF;
-            const float* kad = kadd + item_par * TMAX;
+            const float* kad = LONG ? kadd + (ph & 1) * 256 - half * 256 : kadd + item_par * TMAX;   // indexed by the global key
             int kt_end = nkt - half * 8 < 8 ? nkt - half * 8 : 8;
             if (dbg == 1) kt_end = 0;
             if (dbg == 2) kt_end = 1;
@@ -512,8 +546,13 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             const float* tp[NQ];
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
-                const int tb = half * 256 + 4 * hh - iq[u] + (Tn - 1);
-                tp[u] = tab + (tb & 3) * TAB_LD + (tb & ~3);
+                if (LONG) {
+                    const int tb = 4 * hh + 511 - (iq[u] - qb_cur * 512);        // window coordinates, 0 .. 515
+                    tp[u] = tab + (ph & 1) * (4 * A2_WLD) + (tb & 3) * A2_WLD + (tb & ~3);
+                } else {
+                    const int tb = half * 256 + 4 * hh - iq[u] + (Tn - 1);
+                    tp[u] = tab + (tb & 3) * TAB_LD + (tb & ~3);
+                }
             }
             const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + A2_KBUF + v_lane);
 
@@ -639,11 +678,18 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         if (last_half) {
             // the item is complete: its Q fragment is dead, so the next item's goes straight into the same registers (these 8
             // loads are what the vmcnt(8) at the next boundary leaves in flight); then normalise and store
-            int hn = h_cur, bn = b_cur + 1;
-            if (bn == Bc) { bn = 0; ++hn; }
-            if (more_items) load_q(hn, bn);
-            store_item(h_cur, b_cur);
-            h_cur = hn; b_cur = bn; item_par ^= 1;
+            int hn = h_cur, bn = b_cur, qn = qb_cur + 1;
+            if (qn == nqb) { qn = 0; if (++bn == Bc) { bn = 0; ++hn; } }
+            if (LONG) {
+                store_item(h_cur, b_cur);                // its row indices are this block's: before set_qblock
+                set_qblock(qn);
+                if (more_items) load_q(hn, bn);
+            } else {
+                if (more_items) load_q(hn, bn);
+                store_item(h_cur, b_cur);
+            }
+            if (qn == 0) item_par ^= 1;
+            h_cur = hn; b_cur = bn; qb_cur = qn;
             // (stores are younger than the Q loads: the boundary's vmcnt(8) would have to be vmcnt(16) to skip them; it waits
             // for them instead, which also keeps the count independent of has_q)
 #pragma unroll
@@ -653,6 +699,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
             }
         }
+        half = last_half ? 0 : half + 1;
         AVX_PT(6)
 #undef AVX_PT
         if (ATT_STAMPS && dbg == 4 && blockIdx.x == 3 && tid == 0 && ph >= 2 && ph < 8)
@@ -670,12 +717,14 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         attr_set = true;
     }
     static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
-    const int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
+    int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
+    if (Tn > TMAX) variant = 2;          // variant 1 keeps a whole head in LDS (T <= 512)
     if (variant == 2) {
         static bool attr2_set = false;
         static int n_cu = 0;
         if (!attr2_set) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention2_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention2_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2L_LDS));
             int dev = 0;
             hipDeviceProp_t prop;
             AVX_HIP_CHECK(hipGetDevice(&dev));
@@ -688,8 +737,12 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several items per workgroup
         const int per_block = (n_items + n_wg - 1) / n_wg;
         const int grid = (n_items + per_block - 1) / per_block;
-        hipLaunchKernelGGL(attention2_kernel<T>, dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab,
-                           grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+        if (Tn > TMAX)
+            hipLaunchKernelGGL((attention2_kernel<T, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab,
+                               grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+        else
+            hipLaunchKernelGGL((attention2_kernel<T, false>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab,
+                               grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }
@@ -708,7 +761,7 @@ int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const
               hipStream_t s) {
     AVX_REQUIRE(qkv && out, "attention: null buffer");
     AVX_REQUIRE(B > 0 && H > 0, "attention: bad B=%d H=%d", B, H);
-    AVX_REQUIRE(T > 0 && T <= TMAX, "attention: T=%d tokens unsupported (1..%d; clips up to ~10.3 s)", T, TMAX);
+    AVX_REQUIRE(T > 0 && T <= 32768, "attention: T=%d tokens unsupported (1..32768)", T);
     AVX_REQUIRE(!grep_w || (grep_b && grep_a), "attention: grep_b/grep_a required with grep_w");
     if (dtype == AVEXHIP_F16) return launch<_Float16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, s);
     if (dtype == AVEXHIP_BF16) return launch<__bf16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, s);

@@ -5,7 +5,8 @@
 // Per (clip, group): out[t, o] = sum_{tap<128, c<48} X[t + tap - 64, c] * W[o, tap, c], i.e. a
 // [T x 6144] x [6144 x 48] product whose A-matrix is a sliding window over a (T+127) x 48 slab.
 //
-// One 512-thread workgroup per (clip, group): the group's slab (zero-padded, 96-byte rows — the
+// One 512-thread workgroup per (clip, 512-token segment, group) -- a 10 s BEATs clip is one segment of 496 tokens, longer clips
+// take several with a 64-row halo on each side -- : the group's slab (zero-padded, 96-byte rows — the
 // 16x16x32 fragment reads are bank-conflict free at that stride) is staged in LDS once; each wave
 // owns 64 tokens x 48 channels = 12 accumulators.  The MFMA "A" operand is the WEIGHT fragment
 // (rows = output channel, read from a two-stage LDS ring that LDS-DMA fills one tap pair ahead), the "B" operand the slab
@@ -44,13 +45,14 @@ static __device__ __forceinline__ void pc_dma16(const void* src, const char* lds
 template <typename T>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, const T* __restrict__ wp,
-                    const float* __restrict__ bias, int Tn, int E, int G, float* __restrict__ out, T* __restrict__ out_h) {
+                    const float* __restrict__ bias, int Tn, int E, int G, int nseg, float* __restrict__ out, T* __restrict__ out_h) {
     extern __shared__ __attribute__((aligned(16))) char slab[];
     typedef typename Half<T>::v8 v8;
     char* wring = slab + SLAB_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.x % G, b = blockIdx.x / G;
+    const int g = blockIdx.x % G, bs = blockIdx.x / G;
+    const int b = bs / nseg, t0 = (bs - b * nseg) * TMAX;             // this workgroup's tokens: [t0, min(t0 + 512, Tn))
     const T* xg = xh + (int64_t)b * Tn * E + g * CG;
     const char* wg = (const char*)(wp + (int64_t)g * CG * KTOT);      // this group's 64 x 9216 bytes
 
@@ -62,10 +64,10 @@ void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, cons
     };
     issue_w(0);
 
-    // ---- stage the zero-padded slab: slab row r <-> token r - 64 -------------------------------
+    // ---- stage the zero-padded slab: slab row r <-> token t0 + r - 64 ---------------------------
     for (int idx = tid; idx < SLAB_ROWS * 6; idx += 512) {
         const int r = idx / 6, c = idx - r * 6;
-        const int t = r - PAD;
+        const int t = t0 + r - PAD;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (t >= 0 && t < Tn) v = *(const uint4*)(xg + (int64_t)t * E + c * 8);
         *(uint4*)(slab + r * (CG * 2) + c * 16) = v;
@@ -75,7 +77,7 @@ void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, cons
 
     const int t16 = lane & 15, g4 = lane >> 4;
     const int tw0 = wave * 64;
-    const bool has_work = tw0 < Tn;     // wave-uniform; idle waves still copy weights and join the barriers
+    const bool has_work = t0 + tw0 < Tn;     // wave-uniform; idle waves still copy weights and join the barriers
 
     // per-lane constants for the three chunks of a tap pair
     int xoff[3];
@@ -119,7 +121,7 @@ void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, cons
     // ---- epilogue: + bias, exact GELU, + residual (backbone.py:68,174) --------------------------
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
-        const int t = tw0 + tt * 16 + t16;
+        const int tl = tw0 + tt * 16 + t16, t = t0 + tl;
         if (t >= Tn) continue;
         const int64_t rowoff = ((int64_t)b * Tn + t) * E + g * CG;
 #pragma unroll
@@ -131,7 +133,7 @@ void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, cons
             if (xf) {
                 r = *(const f32x4*)(xf + rowoff + n);
             } else {   // residual from the staged slab (operand precision)
-                const typename Half<T>::v4 rh = *(const typename Half<T>::v4*)(slab + (t + PAD) * (CG * 2) + n * 2);
+                const typename Half<T>::v4 rh = *(const typename Half<T>::v4*)(slab + (tl + PAD) * (CG * 2) + n * 2);
                 r = (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
             }
             r += v;
@@ -213,17 +215,18 @@ int posconv(const void* x_half, const float* x_f32, const void* w_packed, const 
     AVX_REQUIRE(x_half && w_packed && bias && (out || out_half), "posconv: null argument");
     AVX_REQUIRE(groups > 0 && E % groups == 0 && E / groups == CG && K == KT,
                 "posconv: only %d channels/group and %d taps are built (got E=%d groups=%d K=%d)", CG, KT, E, groups, K);
-    AVX_REQUIRE(B > 0 && T > 0 && T <= TMAX, "posconv: T=%d tokens unsupported (1..%d)", T, TMAX);
+    AVX_REQUIRE(B > 0 && T > 0, "posconv: empty input B=%d T=%d", B, T);
+    const int nseg = (T + TMAX - 1) / TMAX;
     if (dtype == AVEXHIP_BF16) {
         static bool set = false;
         if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS)); set = true; }
-        hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * groups), dim3(512), PC_LDS, s, (const __bf16*)x_half, x_f32,
-                           (const __bf16*)w_packed, bias, T, E, groups, out, (__bf16*)out_half);
+        hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * nseg * groups), dim3(512), PC_LDS, s, (const __bf16*)x_half, x_f32,
+                           (const __bf16*)w_packed, bias, T, E, groups, nseg, out, (__bf16*)out_half);
     } else if (dtype == AVEXHIP_F16) {
         static bool set = false;
         if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS)); set = true; }
-        hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * groups), dim3(512), PC_LDS, s, (const _Float16*)x_half, x_f32,
-                           (const _Float16*)w_packed, bias, T, E, groups, out, (_Float16*)out_half);
+        hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * nseg * groups), dim3(512), PC_LDS, s, (const _Float16*)x_half, x_f32,
+                           (const _Float16*)w_packed, bias, T, E, groups, nseg, out, (_Float16*)out_half);
     } else {
         avexhip_set_error("posconv: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;

@@ -100,12 +100,12 @@ def test_oracle_agrees_on_fresh_input(encoder, base_sd):
 
 
 def test_edge_sizes(encoder, base_sd):
-    """Smallest and largest inputs the path takes, and the ones it refuses loudly: 16 frames -> 8 tokens, 1024 frames -> 512
-    tokens (the LDS-resident attention/pos-conv limit), one frame more than that, fewer samples than one analysis window,
-    and an empty batch."""
+    """Smallest and unusual inputs the path takes, and the ones it refuses loudly: 16 frames -> 8 tokens, 1024 frames -> 512
+    tokens (the last size of the single-block attention path), one token row more (520 tokens: two query blocks, three key
+    blocks), fewer samples than one analysis window, and an empty batch."""
     from avex_amd._capi import AvexHipError
     tol = POOLED_TOL[encoder.dtype_name]
-    for samples, tokens in ((400 + 160 * 15, 8), (400 + 160 * 1023, 512)):
+    for samples, tokens in ((400 + 160 * 15, 8), (400 + 160 * 1023, 512), (400 + 160 * 1039, 520)):
         x = synth.noise_clips(1, samples, seed=31)
         f, _ = O.beats_forward(x, base_sd, synth.BEATS_BASE_CFG)
         assert f.shape[1] == tokens
@@ -113,11 +113,36 @@ def test_edge_sizes(encoder, base_sd):
         assert r["features"].shape == (1, tokens, 768)
         assert rel_l2(r["pooled"].cpu().numpy(), O.pooled(f)) < (3 * tol if tokens == 8 else tol)   # 8 tokens: no averaging
     with pytest.raises(AvexHipError):
-        encoder.forward(torch.zeros(1, 400 + 160 * 1039, device="cuda"), want_pooled=True)          # 520 tokens
-    with pytest.raises(AvexHipError):
         encoder.forward(torch.zeros(2, 300, device="cuda"), want_pooled=True)                       # shorter than one window
     with pytest.raises((AvexHipError, ValueError)):
         encoder.forward(torch.zeros(0, 160000, device="cuda"), want_pooled=True)                    # empty batch
+
+
+def test_long_clips_match_oracle(built_lib, base_sd):
+    """Clips longer than 10.3 s (the reference takes any length, beats.py:344-361 / backbone.py:151-221): 20 s = 992 tokens and
+    a 12.1 s clip beside a padding mask, BEATs-base, against the CPU oracle; chunking by token count must not show."""
+    from avex_amd import kernels as K
+    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype="f16", max_chunk_clips=2)
+    x = synth.noise_clips(3, 320000, seed=41)
+    f, taps = O.beats_forward(x[:1], base_sd, synth.BEATS_BASE_CFG)
+    r = enc.forward(torch.from_numpy(x).cuda(), hook_layers=[0, 12], want_features=True, want_pooled=True)
+    assert r["features"].shape == (3, 992, 768)
+    assert rel_l2(r["pooled"][:1].cpu().numpy(), O.pooled(f)) < 1e-3
+    assert rel_l2(r["features"][:1].cpu().numpy(), f) < 4e-3
+    assert rel_l2(r["hooks"][12][:1].cpu().numpy().mean(1), taps["backbone.encoder.layers.11.fc2"].mean(1)) < 1e-3
+    one = enc.forward(torch.from_numpy(x[2:3]).cuda(), want_pooled=True)["pooled"]
+    assert torch.equal(one[0], r["pooled"][2])                              # chunks of 1 clip (2 * 512 / 992) vs alone
+    # 12.1 s with the last third padded
+    T = 400 + 160 * 1209
+    x2 = synth.noise_clips(1, T, seed=42)
+    pm = np.zeros((1, T), bool); pm[0, 2 * T // 3:] = True
+    f2, _ = O.beats_forward(x2, base_sd, synth.BEATS_BASE_CFG, padding_mask=pm)
+    nt = f2.shape[1]
+    fpad = O.forward_padding_mask(nt, O.forward_padding_mask(1210, pm))
+    r2 = enc.forward(torch.from_numpy(x2).cuda(), want_features=True, frame_pad=torch.from_numpy(fpad))
+    assert r2["features"].shape == (1, nt, 768) and nt == 600
+    assert rel_l2(r2["features"].cpu().numpy(), f2) < 4e-3
+    enc.close()
 
 
 def test_full_size_properties(built_lib, base_sd):
@@ -161,3 +186,51 @@ def test_model_without_post_extract_proj(built_lib):
         with pytest.raises(AvexHipError):
             enc.forward(torch.from_numpy(x).cuda(), hook_layers=[0], want_features=True)
         enc.close()
+
+
+def test_config_c2_full_size_vs_reference_golden(built_lib, base_sd, golden_dir):
+    """BASELINE config C2 at its real size and in the bench's exact configuration (f16 operands, operand-type residual stream,
+    one 256-clip chunk, pooled-only -> the fused LayerNorm + mean kernel, M = 126 976 rows through the persistent GEMM): the four
+    clips of the reference golden b4 sit at rows 0, 1, 128 and 255 of the batch and must come out within north_star's 1e-3 of
+    the reference's fp32 CPU result; where a clip sits in the batch, and how large the batch is, must not matter."""
+    from avex_amd import kernels as K
+    g = np.load(f"{golden_dir}/base_api.npz")["b4.pooled"]
+    gold = synth.noise_clips(4, 160000, seed=0)
+    rows = (0, 1, 128, 255)
+    x = synth.noise_clips(256, 160000, seed=0, first_clip=1000)
+    for k, r in enumerate(rows):
+        x[r] = gold[k]
+    wav = torch.from_numpy(x).cuda()
+    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype="f16", max_chunk_clips=256, residual="half")
+    p = enc.forward(wav, want_features=False, want_pooled=True)["pooled"]
+    assert p.shape == (256, 768) and torch.isfinite(p).all()
+    got = p[list(rows)].cpu().numpy()
+    assert rel_l2(got, g) < 1e-3                                           # all four together
+    for k in range(4):
+        assert rel_l2(got[k], g[k]) < 1e-3                                 # and each clip alone
+    # the same clips at other rows of the same-size batch: bit-identical
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(5)).cuda()
+    p2 = enc.forward(wav[perm], want_features=False, want_pooled=True)["pooled"]
+    assert torch.equal(p2, p[perm])
+    # the same clips as a batch of 4 (small-problem GEMM kernel, unfused final LayerNorm + pooling of fp32 features)
+    small = enc.forward(torch.from_numpy(gold).cuda(), want_features=True, want_pooled=True)
+    assert rel_l2(got, small["pooled"].cpu().numpy()) < 5e-5
+    assert rel_l2(got, small["features"].mean(1).cpu().numpy()) < 5e-5
+    enc.close()
+
+
+def test_config_c5_full_size_efficientnet(built_lib):
+    """BASELINE config C5 at its real size (1024 clips x 10 s through the mel frontend and EfficientNet-B0): clips are independent,
+    so two clips run alone must reproduce their rows of the 1024-clip batch."""
+    from avex_amd import kernels as K
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    enc = EfficientNetB0Encoder(synth.effnet_b0_state_dict())
+    plan = K.MelspecPlan(n_fft=800, hop_length=160, n_mels=128, normalize=True)
+    wav = torch.from_numpy(synth.noise_clips(1024, 160000, seed=2)).cuda()
+    full = enc.forward(plan(wav), want_features=False, want_pooled=True)["pooled"]
+    assert full.shape == (1024, 1280) and torch.isfinite(full).all()
+    for r in (0, 517, 1023):
+        one = enc.forward(plan(wav[r:r + 1]), want_features=False, want_pooled=True)["pooled"]
+        # not bit-identical: the squeeze-excitation pool is accumulated with fp32 atomics (order varies with the grid), and a flipped
+        # f16 rounding of an activation carries the difference to ~4e-5
+        assert rel_l2(one.cpu().numpy(), full[r:r + 1].cpu().numpy()) < 2e-4

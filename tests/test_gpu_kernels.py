@@ -336,8 +336,35 @@ def test_attention_large_logits(built_lib, variant, monkeypatch):
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("T,grid", [(513, 0), (600, 7), (1000, 5), (1537, 3)])
+def test_attention_long_clips(built_lib, T, grid, monkeypatch):
+    """More than 512 tokens (the reference has no length limit, backbone.py:151-221; EAT has 513): queries in blocks of 512,
+    keys in blocks of 256, a bias-row window and a key mask per (query block, key block) phase.  Gate, key padding (a masked
+    first key tile, a clip whose last query block is one row), items that cross a head seam, vs the fp64 restatement."""
+    from avex_amd import kernels as K
+    if grid:
+        monkeypatch.setenv("AVEX_AMD_ATT_GRID", str(grid))
+    B, H = 3, 12
+    E = H * 64
+    qkv = round_half(synth.normal(f"qkvL{T}", (B * T, 3 * E), 1.0), "f16")
+    table = synth.normal("rel", (320, H), 0.5)
+    gw = synth.normal("gw", (8, 64), 0.1); gb = synth.normal("gb", (8,), 0.1); ga = 1.0 + synth.normal("ga", (H,), 0.2)
+    tab = _toeplitz(table, T, 320, 800)
+    out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), _dev(gw), _dev(gb), _dev(ga))
+    ref = _attention_ref(qkv, B, T, H, table, gw, gb, ga)
+    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+    pad = np.zeros((B, T), bool); pad[1, T // 3:] = True; pad[2, :40] = True; pad[0, T - 3:] = True
+    out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), _dev(gw), _dev(gb), _dev(ga), key_pad=_dev(pad.astype(np.uint8), torch.uint8))
+    ref = _attention_ref(qkv, B, T, H, table, gw, gb, ga, key_pad=pad)
+    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+    # no bias table at all (EAT / AVES): plain softmax(q k^T / 8) v
+    out = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None)
+    ref = _attention_ref(qkv, B, T, H, None, None, None, None)
+    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("T", [496, 48, 130])
+@pytest.mark.parametrize("T", [496, 48, 130, 513, 1100])
 def test_posconv(built_lib, dtype, T):
     from avex_amd import kernels as K
     B, E, G, Kt = 2, 768, 16, 128
