@@ -84,6 +84,8 @@ SYMBOLS = {
     "avexhip_mha_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
     "avexhip_fbank_forward_padded": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
+    "avexhip_fbank_forward_patches": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "avexhip_token_embed_ln": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "avexhip_cast_f32_to_half": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_cast_half_to_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _P]),

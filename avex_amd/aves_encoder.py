@@ -125,8 +125,6 @@ class AvesEncoder:
         hooks = set(int(i) for i in hook_layers)
         feats = self.extract_conv_features(wav)
         Tt = feats.shape[1]
-        if Tt > 512:
-            raise K.AvexHipError(f"AVES: {Tt} frames per clip unsupported (max 512, about 10.2 s)")
         M, E = B * Tt, self.E
         _, h = K.layernorm(feats.view(M, 512), *self.fp_ln, want_f32=False)
         x = K.gemm(h, self.fp_w, bias=self.fp_b, out_f32=False, out_half=True)["half"]

@@ -79,6 +79,11 @@ extern "C" int avexhip_posconv(const void* x_half, const float* x_f32, const voi
     return avx::posconv(x_half, x_f32, w_packed, bias, B, T, E, groups, K, out_f32, out_half, dtype, (hipStream_t)stream);
 }
 
+extern "C" int avexhip_token_embed_ln(const void* patches_half, const float* pos, const float* cls, const float* ln_w, const float* ln_b, float eps,
+                                      int B, int n_patches, int C, void* out_half, float* out_f32, int dtype, void* stream) {
+    return avx::token_embed_ln(patches_half, pos, cls, ln_w, ln_b, eps, B, n_patches, C, out_half, out_f32, dtype, (hipStream_t)stream);
+}
+
 extern "C" int avexhip_mean_pool(const float* in, int B, int T, int C, float* out, void* stream) {
     return avx::mean_pool(in, B, T, C, nullptr, out, (hipStream_t)stream);
 }

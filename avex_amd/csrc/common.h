@@ -237,6 +237,9 @@ int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s
 int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t s);
 int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s);
 int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s);
+// [B * Tp, C] patch rows (half) -> [B * (Tp + 1), C]: class token row + (patch + position) rows, LayerNorm'ed
+int token_embed_ln(const void* patches, const float* pos, const float* cls, const float* w, const float* b, float eps, int B, int Tp, int C,
+                   void* out_half, float* out_f32, int dtype, hipStream_t s);
 // rows with pad[m] != 0 set to zero in the fp32 and / or the operand-type copy (either may be NULL)
 int zero_rows(float* x32, int64_t ld32, void* x_half, int64_t ldh, int M, int C, const uint8_t* pad, hipStream_t s);
 // final LayerNorm + mean over tokens in one pass (half rows in, [B, C] fp32 out); C % 8 == 0, C <= 768

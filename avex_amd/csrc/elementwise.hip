@@ -333,6 +333,46 @@ __global__ __launch_bounds__(256) void lds_canary_kernel(int iters, unsigned* __
     }
 }
 
+// EAT / Data2Vec-multi token assembly: row 0 of a clip is the class token, row 1 + t is patch t plus its fixed position; every
+// row then goes through the encoder's first LayerNorm (`pre_norm`, the context encoder's norm with layer_norm_first = False).
+// One wave per output row, C <= 1024, C % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void token_embed_ln_kernel(const T* __restrict__ patches, const float* __restrict__ pos, const float* __restrict__ cls,
+                                                             const float* __restrict__ w, const float* __restrict__ b, float eps, int Tp, int C, int64_t rows,
+                                                             T* __restrict__ out_h, float* __restrict__ out_f) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t clip = row / (Tp + 1);
+    const int t = (int)(row - clip * (Tp + 1)) - 1;          // -1: class token
+    float v[16];
+    float s = 0.f;
+    const int n = C / 64;                                    // values per lane (strided by 64): C = 768 -> 12
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = 0.f;
+        if (i < n) {
+            const int c = lane + 64 * i;
+            v[i] = t < 0 ? cls[c] : (float)patches[(clip * Tp + t) * C + c] + pos[(int64_t)t * C + c];
+            s += v[i];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i < n) { const float d = v[i] - mean; q = __builtin_fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < n) {
+            const int c = lane + 64 * i;
+            const float y = (v[i] - mean) * rstd * w[c] + b[c];
+            if (out_h) out_h[row * C + c] = Half<T>::from(y);
+            if (out_f) out_f[row * C + c] = y;
+        }
+    }
+}
+
 // rows m with pad[m] != 0 become zero in the fp32 and/or operand-type copy of x (the encoder's `x[padding_mask] = 0`,
 // backbone.py:169-170, on the path where no GEMM epilogue does it: embed_dim == encoder_embed_dim, no post_extract_proj)
 __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ x32, unsigned short* __restrict__ xh, int64_t ld32, int64_t ldh,
@@ -456,6 +496,24 @@ int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const flo
         hipLaunchKernelGGL(layernorm_pool_kernel<__bf16>, dim3(B), dim3(1024), 0, s, (const __bf16*)in_half, ld_in, w, b, eps, T, C, out);
     else {
         avexhip_set_error("layernorm_pool: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int token_embed_ln(const void* patches, const float* pos, const float* cls, const float* w, const float* b, float eps, int B, int Tp, int C,
+                   void* out_half, float* out_f32, int dtype, hipStream_t s) {
+    AVX_REQUIRE(patches && pos && cls && w && b && (out_half || out_f32), "token_embed_ln: null argument");
+    AVX_REQUIRE(B > 0 && Tp > 0 && C % 64 == 0 && C <= 1024, "token_embed_ln: bad shape B=%d patches=%d C=%d", B, Tp, C);
+    const int64_t rows = (int64_t)B * (Tp + 1);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == AVEXHIP_F16)
+        hipLaunchKernelGGL(token_embed_ln_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)patches, pos, cls, w, b, eps, Tp, C, rows, (_Float16*)out_half, out_f32);
+    else if (dtype == AVEXHIP_BF16)
+        hipLaunchKernelGGL(token_embed_ln_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)patches, pos, cls, w, b, eps, Tp, C, rows, (__bf16*)out_half, out_f32);
+    else {
+        avexhip_set_error("token_embed_ln: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;
     }
     AVX_LAUNCH_CHECK();

@@ -345,6 +345,21 @@ extern "C" int avexhip_fbank_num_frames(const avexhip_fbank_plan* plan, int64_t 
     return (int)(1 + (T - plan->cfg.win_length) / plan->cfg.hop_length);
 }
 
+extern "C" int avexhip_fbank_forward_patches(const avexhip_fbank_plan* plan, const float* wav_dev, int B, int64_t T, int64_t wav_stride,
+                                             const float* clip_offset_dev, int out_frames, int patch, void* out_patch_dev, int dtype,
+                                             void* stream) {
+    AVX_REQUIRE(plan && wav_dev && out_patch_dev, "fbank_forward_patches: null argument");
+    AVX_REQUIRE(B > 0 && T > 0 && patch > 0, "fbank_forward_patches: empty input B=%d T=%lld patch=%d", B, (long long)T, patch);
+    AVX_REQUIRE(dtype == AVEXHIP_F16 || dtype == AVEXHIP_BF16, "fbank_forward_patches: unknown dtype %d", dtype);
+    if (wav_stride <= 0) wav_stride = T;
+    const int frames = avexhip_fbank_num_frames(plan, T);
+    if (out_frames <= 0) out_frames = frames;
+    AVX_REQUIRE(out_frames >= patch && plan->cfg.n_mels >= patch, "fbank_forward_patches: %d frames x %d bins hold no %d x %d patch", out_frames,
+                plan->cfg.n_mels, patch, patch);
+    return avx::fbank(plan->dev, wav_dev, B, T, wav_stride, frames, nullptr, out_patch_dev, patch, dtype, (hipStream_t)stream, clip_offset_dev,
+                      out_frames);
+}
+
 // internal accessor for the encoder handle
 const avx::FbankDev* avexhip_fbank_plan_dev(const avexhip_fbank_plan* plan) { return plan ? &plan->dev : nullptr; }
 

@@ -130,6 +130,27 @@ class FbankPlan:
                                                  out_frames, _ptr(out), _stream()), "fbank_forward_padded")
         return out
 
+    def patches(self, wav: torch.Tensor, out_frames: int = 0, patch: int = 16, remove_clip_mean: bool = False, dtype="f16") -> torch.Tensor:
+        """``[B, T]`` -> half ``[B * (out_frames/patch) * (n_mels/patch), patch*patch]``: the log-mel image cut into the rows a
+        patch-embedding GEMM reads (token = t * n_mels/patch + f), straight from the filterbank kernel."""
+        _need_cuda(wav)
+        if wav.dim() != 2 or wav.dtype != torch.float32:
+            raise ValueError("wav must be a [B, T] float32 tensor")
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, T = wav.shape
+        code = dtype_code(dtype)
+        frames = out_frames if out_frames > 0 else self.num_frames(T)
+        nt, nf = frames // patch, self.n_mels // patch
+        out = torch.empty((B * nt * nf, patch * patch), dtype=half_torch_dtype(code), device=wav.device)
+        off = None
+        if remove_clip_mean:
+            off = torch.empty((B,), dtype=torch.float32, device=wav.device)
+            check(lib().avexhip_clip_mean(_ptr(wav), B, T, wav.stride(0), _ptr(off), _stream()), "clip_mean")
+        check(lib().avexhip_fbank_forward_patches(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(off), out_frames, patch, _ptr(out), code,
+                                                  _stream()), "fbank_forward_patches")
+        return out
+
     def __del__(self) -> None:
         try:
             if getattr(self, "_h", None):
@@ -454,6 +475,20 @@ def posconv(x_half: torch.Tensor, x_f32: Optional[torch.Tensor], w_packed: torch
                                 _ptr(bias), B, T, E, groups, K, None if half_out else _ptr(out),
                                 _ptr(out) if half_out else None, code, _stream()), "posconv")
     return out
+
+
+def token_embed_ln(patches: torch.Tensor, pos: torch.Tensor, cls: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float,
+                   B: int, want_f32: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Class token + (patch + position) rows, LayerNorm'ed: half ``[B * n, C]`` -> (half, fp32 or None) ``[B * (n + 1), C]``."""
+    _need_cuda(patches, pos, cls, ln_w, ln_b)
+    code = _capi.F16 if patches.dtype == torch.float16 else _capi.BF16
+    M, Cc = patches.shape
+    n = M // B
+    outh = torch.empty((B * (n + 1), Cc), dtype=patches.dtype, device=patches.device)
+    outf = torch.empty((B * (n + 1), Cc), dtype=torch.float32, device=patches.device) if want_f32 else None
+    check(lib().avexhip_token_embed_ln(_ptr(patches.contiguous()), _ptr(pos.contiguous()), _ptr(cls.contiguous()), _ptr(ln_w), _ptr(ln_b), eps,
+                                       B, n, Cc, _ptr(outh), _ptr(outf), code, _stream()), "token_embed_ln")
+    return outh, outf
 
 
 def mean_pool(x: torch.Tensor) -> torch.Tensor:

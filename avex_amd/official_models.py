@@ -2,10 +2,8 @@
 ``model_spec`` values, default checkpoint URI and label-map URI
 (reference data files: avex/api/configs/official_models/*.yml).
 
-The ``beats``, ``efficientnet`` and ``aves`` classes are built in this package; the EAT ids are registered
-so that ``list_models()`` / ``get_model_spec()`` answer like the reference, and loading them raises
-``KeyError`` ("model class ... is not registered") exactly as the reference does for a class it
-could not import.
+The ``beats``, ``efficientnet``, ``aves`` and ``eat_hf`` classes are built in this package (the EAT encoder's parity is
+unpinned: its arithmetic is HF Hub remote code outside the reference tree, see oracle/eat_oracle.py).
 """
 from __future__ import annotations
 

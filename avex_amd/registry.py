@@ -148,6 +148,9 @@ def initialize_registry() -> None:
     _MODEL_CLASSES.setdefault("aves", AvesModel)
     from .efficientnet import Model as EfficientNetModel
     _MODEL_CLASSES.setdefault("efficientnet", EfficientNetModel)
+    from .eat_hf import EATHFModel
+    _MODEL_CLASSES.setdefault("eat_hf", EATHFModel)        # key = cls.name; the reference's module scan also lists the lower-cased
+    _MODEL_CLASSES.setdefault("eathf", EATHFModel)         # class name ("eat_hf, eathf")
 
 
 initialize_registry()

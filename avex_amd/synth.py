@@ -216,6 +216,59 @@ def aves_state_dict(cfg: Mapping[str, object] = AVES_BASE_CFG, seed: int = 0) ->
     return sd
 
 
+EAT_BASE_CFG: Dict[str, object] = dict(         # EAT-base (Data2Vec-multi image encoder on a [1024, 128] mel image); parity unpinned
+    embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, patch_size=16, target_length=1024, n_mels=128, max_length=768,
+    norm_eps=1e-6, layer_norm_first=False,
+)
+
+
+def sincos_2d_positions(embed_dim: int, grid_h: int, grid_w: int) -> np.ndarray:
+    """MAE-style fixed 2-D sine/cosine position table ``[grid_h * grid_w, embed_dim]`` (first half of the channels encodes the
+    column index w, second half the row index h; each half is [sin | cos] over ``omega_k = 10000^(-k / (D/4))``), row-major
+    over (h, w) like the patch order -- what EAT's ``fixed_positional_encoder.positions`` buffer holds."""
+    def one_d(d: int, pos: np.ndarray) -> np.ndarray:
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1).astype(np.float64), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    gh, gw = np.arange(grid_h, dtype=np.float32), np.arange(grid_w, dtype=np.float32)
+    grid = np.meshgrid(gw, gh)                               # [0] = w index, [1] = h index, each [grid_h, grid_w]
+    emb_h = one_d(embed_dim // 2, grid[0])
+    emb_w = one_d(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1).astype(np.float32)
+
+
+def eat_state_dict(cfg: Mapping[str, object] = EAT_BASE_CFG, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic EAT-base state dict (fp32 numpy) under the avex wrapper's ``backbone.`` prefix with the HF remote model's key
+    names (``model.local_encoder.proj``, ``model.extra_tokens``, ``model.fixed_positional_encoder.positions``, ``model.pre_norm``,
+    ``model.blocks.{i}.{attn.qkv, attn.proj, norm1, mlp.fc1, mlp.fc2, norm2}``; the fairseq -> HF renaming the reference does,
+    avex/models/eat_hf.py:55-73, fixes ``model.`` + ``pre_norm``; ``blocks.{i}.attn.proj`` is the hook name, :220-236)."""
+    E = int(cfg["embed_dim"]); L = int(cfg["depth"]); F = E * int(cfg["mlp_ratio"]); P = int(cfg["patch_size"])
+    gw = int(cfg["n_mels"]) // P
+    sd: Dict[str, np.ndarray] = {}
+    pre = "backbone.model."
+
+    def n(name, shape, std):
+        sd[pre + name] = normal("eat." + name, shape, std, seed)
+
+    def aff(name, dim, is_weight):
+        v = normal("eat." + name, (dim,), 0.1 if is_weight else 0.05, seed)
+        sd[pre + name] = (v + 1.0).astype(np.float32) if is_weight else v
+
+    n("local_encoder.proj.weight", (E, 1, P, P), 1.0 / P); n("local_encoder.proj.bias", (E,), 0.02)
+    n("extra_tokens", (1, 1, E), 0.02)
+    sd[pre + "fixed_positional_encoder.positions"] = sincos_2d_positions(E, int(cfg["max_length"]), gw)[None]
+    aff("pre_norm.weight", E, True); aff("pre_norm.bias", E, False)
+    for i in range(L):
+        p = f"blocks.{i}."
+        n(p + "attn.qkv.weight", (3 * E, E), math.sqrt(1.0 / E) * 0.8); n(p + "attn.qkv.bias", (3 * E,), 0.02)
+        n(p + "attn.proj.weight", (E, E), math.sqrt(1.0 / E) * 0.5); n(p + "attn.proj.bias", (E,), 0.02)
+        aff(p + "norm1.weight", E, True); aff(p + "norm1.bias", E, False)
+        n(p + "mlp.fc1.weight", (F, E), math.sqrt(2.0 / (E + F)) * 0.7); n(p + "mlp.fc1.bias", (F,), 0.02)
+        n(p + "mlp.fc2.weight", (E, F), math.sqrt(2.0 / (E + F)) * 0.7); n(p + "mlp.fc2.bias", (E,), 0.02)
+        aff(p + "norm2.weight", E, True); aff(p + "norm2.bias", E, False)
+    return sd
+
+
 # torchvision efficientnet_b0: (expand ratio, kernel, stride, in, out, layers) per stage
 EFFNET_B0_STAGES = [(1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3), (6, 5, 1, 80, 112, 3),
                     (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1)]

@@ -80,6 +80,14 @@ int avexhip_fbank_forward_padded(const avexhip_fbank_plan* plan, const float* wa
                                  int64_t wav_stride, const float* clip_offset_dev, int out_frames,
                                  float* out_dev, void* stream);
 
+/* The same frontend writing what a 16 x 16 patch-embedding GEMM reads: out_patch_dev [B, out_frames/patch, n_mels/patch, patch*patch]
+ * in the operand type (token = t * (n_mels/patch) + f, element = (frame % patch) * patch + (bin % patch)), i.e. Conv2d(1, D, patch,
+ * stride patch) over the [frames, n_mels] image becomes avexhip_gemm with K = patch*patch (BEATs beats.py:349-352; EAT's
+ * local_encoder, avex/models/eat_hf.py:274).  clip_offset_dev / out_frames as for avexhip_fbank_forward_padded (NULL / 0: none). */
+int avexhip_fbank_forward_patches(const avexhip_fbank_plan* plan, const float* wav_dev, int B, int64_t T, int64_t wav_stride,
+                                  const float* clip_offset_dev, int out_frames, int patch, void* out_patch_dev, int dtype,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Frontend: STFT power spectrogram / mel spectrogram of the reference's AudioProcessor
  * (avex/data/audio_utils.py:77-172): torch.stft(n_fft, hop, win_length, window, center (reflect pad)) -> |.|^2 ->
@@ -221,6 +229,12 @@ int avexhip_posconv_pack(const float* g_dev, const float* v_dev, int E, int grou
 int avexhip_posconv(const void* x_half_dev, const float* x_f32_dev, const void* w_packed_dev,
                     const float* bias_dev, int B, int T, int E, int groups, int K,
                     float* out_f32_dev, void* out_half_dev, int dtype, void* stream);
+
+/* EAT / Data2Vec-multi token assembly (the HF remote model behind avex/models/eat_hf.py:201,274; parity unpinned): per clip, row 0 =
+ * class token `extra_tokens`, row 1 + t = patch row t + fixed position t; then LayerNorm(C, eps) (`pre_norm`).
+ * patches_half [B * n_patches, C] (operand type), pos [n_patches, C], cls [C] fp32 -> out_half / out_f32 [B * (n_patches + 1), C]. */
+int avexhip_token_embed_ln(const void* patches_half, const float* pos, const float* cls, const float* ln_w, const float* ln_b, float eps,
+                           int B, int n_patches, int C, void* out_half, float* out_f32, int dtype, void* stream);
 
 /* mean over T: in [B, T, C] fp32 -> out [B, C] fp32 (features.mean(dim=1), README:80). */
 int avexhip_mean_pool(const float* in_dev, int B, int T, int C, float* out_dev, void* stream);
