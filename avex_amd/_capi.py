@@ -79,6 +79,7 @@ SYMBOLS = {
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
     "avexhip_wavconv0_stats_floats": (C.c_int64, [C.c_int, C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),
+    "avexhip_seq_interp_linear": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "avexhip_layer_mix": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_int64, _P, _P]),
     "avexhip_dense_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "avexhip_mha_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
@@ -96,10 +97,6 @@ SYMBOLS = {
     "avexhip_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "avexhip_mean_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "avexhip_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "avexhip_debug_lds_canary": (C.c_int, [C.c_int, C.c_int, _P, _P]),
-    "avexhip_debug_gemm_stamps": (C.c_int, [C.c_int, _P, C.c_int]),
-    "avexhip_debug_gemm_clocks": (C.c_int, [_P, C.c_int]),
-    "avexhip_debug_gemm_kclocks": (C.c_int, [_P, C.c_int]),
     "avexhip_beats_create": (_P, [C.POINTER(BeatsConfig), C.POINTER(Tensor), C.c_int]),
     "avexhip_beats_destroy": (None, [_P]),
     "avexhip_beats_num_tokens": (C.c_int, [_P, C.c_int64]),
@@ -111,6 +108,15 @@ SYMBOLS = {
     "avexhip_beats_set_profiling": (C.c_int, [_P, C.c_int]),
     "avexhip_beats_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
                                              C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]),
+}
+
+# exported by the diagnostic build only (-DAVEX_DIAG; AVEX_AMD_DIAG=1 python -m avex_amd.build, then AVEX_AMD_LIB=.../libavexhip_diag.so)
+DIAG_SYMBOLS = {
+    "avexhip_debug_lds_canary": (C.c_int, [C.c_int, C.c_int, _P, _P]),
+    "avexhip_debug_gemm_stamps": (C.c_int, [C.c_int, _P, C.c_int]),
+    "avexhip_debug_gemm_clocks": (C.c_int, [_P, C.c_int]),
+    "avexhip_debug_gemm_kclocks": (C.c_int, [_P, C.c_int]),
+    "avexhip_debug_att_stamps": (C.c_int, [_P, C.c_int]),       # -DATT_STAMPS=1 builds only
 }
 
 _lib: Optional[C.CDLL] = None
@@ -148,6 +154,11 @@ def lib() -> C.CDLL:
             raise AvexHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SYMBOLS.items():
+        fn = getattr(handle, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = handle
     return handle
 

@@ -15,9 +15,15 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_build")
+# AVEX_AMD_DIAG=1: the diagnostic build (-DAVEX_DIAG: clock stamps in the GEMM, debug knobs in the attention kernel, the LDS canary
+# and the avexhip_debug_* exports) goes to its own object directory and library; the product library contains none of it.
+DIAG = os.environ.get("AVEX_AMD_DIAG", "") == "1"
+# AVEX_AMD_LIB_SUFFIX=x: an A/B build (with AVEX_AMD_EXTRA_CFLAGS) into _build_x/ and lib/libavexhip_x.so, selected at run time with
+# AVEX_AMD_LIB=.../libavexhip_x.so; the product library is the one without a suffix.
+_SUFFIX = os.environ.get("AVEX_AMD_LIB_SUFFIX", "") or ("diag" if DIAG else "")
+OBJ = os.path.join(HERE, "_build_" + _SUFFIX if _SUFFIX else "_build")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libavexhip.so")
+LIB = os.path.join(LIBDIR, f"libavexhip_{_SUFFIX}.so" if _SUFFIX else "libavexhip.so")
 SOURCES = ["api.cpp", "gemm.hip", "elementwise.hip", "fbank.hip", "attention.hip", "posconv.hip", "wavconv.hip", "melspec.hip", "effnet.hip", "probe.hip"]
 ARCH = "gfx950"
 # Per-file flags.  hipcc's SLP vectoriser turns complex (float2) arithmetic into packed-fp32 instructions whose second source
@@ -50,7 +56,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdr = _deps_mtime()
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-Wno-unused-result",
              "-fno-gpu-rdc", "-ffp-contract=off"]
-    flags += os.environ.get("AVEX_AMD_EXTRA_CFLAGS", "").split()      # diagnostic builds, e.g. -DATT_STAMPS=1
+    if DIAG:
+        flags.append("-DAVEX_DIAG")
+    flags += os.environ.get("AVEX_AMD_EXTRA_CFLAGS", "").split()      # e.g. -DATT_STAMPS=1
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

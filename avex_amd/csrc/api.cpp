@@ -6,6 +6,8 @@
 #include <stdlib.h>
 
 #include <map>
+#include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -56,6 +58,40 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
     return avx::gemm(g, dtype, (hipStream_t)stream);
 }
+
+namespace avx {
+namespace {
+std::mutex g_dev_mu;
+std::map<std::pair<int, const void*>, int> g_lds_set;     // (device, kernel) -> bytes already opted in
+std::map<int, int> g_cu_count;
+}  // namespace
+
+int ensure_max_dynamic_lds(const void* func, int bytes) {
+    int dev = 0;
+    AVX_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    auto key = std::make_pair(dev, func);
+    auto it = g_lds_set.find(key);
+    if (it != g_lds_set.end() && it->second >= bytes) return AVEXHIP_OK;
+    AVX_HIP_CHECK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_lds_set[key] = bytes;
+    return AVEXHIP_OK;
+}
+
+int device_cu_count(int* n_cu) {
+    int dev = 0;
+    AVX_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    auto it = g_cu_count.find(dev);
+    if (it == g_cu_count.end()) {
+        hipDeviceProp_t prop;
+        AVX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        it = g_cu_count.emplace(dev, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256).first;
+    }
+    *n_cu = it->second;
+    return AVEXHIP_OK;
+}
+}  // namespace avx
 
 extern "C" int avexhip_layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b,
                                  float eps, int M, int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh,

@@ -23,6 +23,14 @@
 
 namespace {
 
+// The AVEX_AMD_ATT_DEBUG experiment knobs (skip tiles, skip the DMA, non-temporal stores) exist only in the diagnostic build
+// (-DAVEX_DIAG); in the product library `dbg` is the constant 0 and the branches on it are compiled out.
+#ifdef AVEX_DIAG
+#define AVX_ATT_DBG(arg) const int dbg = (arg);
+#else
+#define AVX_ATT_DBG(arg) constexpr int dbg = 0; (void)(arg);
+#endif
+
 constexpr int TMAX = 512;
 constexpr int VT_LD = 516;                       // halves per V^T row (1032 B: conflict-free b64 reads)
 constexpr int KS_BYTES = TMAX * 128;             // 65536
@@ -40,7 +48,8 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
                                                         const float* __restrict__ grep_b,
                                                         const float* __restrict__ grep_a,
                                                         const uint8_t* __restrict__ key_pad,
-                                                        T* __restrict__ out, int dbg) {
+                                                        T* __restrict__ out, int dbg_arg) {
+    AVX_ATT_DBG(dbg_arg)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -282,6 +291,15 @@ constexpr int A2L_KADD_OFF = A2_TAB_OFF + 2 * A2_WIN_BYTES;
 constexpr int A2L_GW_OFF = A2L_KADD_OFF + 2 * 256 * 4;
 constexpr int ATT2L_LDS = A2L_GW_OFF + GW_BYTES;
 constexpr float A2_THR = 8.f;
+#if defined(ATT_STAMPS) && ATT_STAMPS
+__device__ unsigned long long g_att_stamps[64 * 8 * 32 * 8];   // [block < 64][wave][phase < 32][7 x s_memtime, s_memrealtime]
+#endif
+#ifndef ATT_STAGGER
+#define ATT_STAGGER 0    // waves 4-7 enter each phase's key tiles this many 64-cycle sleeps after waves 0-3 (SIMD partners out of lockstep)
+#endif
+#ifndef ATT_PRIO
+#define ATT_PRIO 1       // 1: waves 4-7 run at s_setprio 1
+#endif
 #ifndef ATT_STAMPS
 #define ATT_STAMPS 0     // diagnostic build: -DATT_STAMPS=1 prints one tile's cycle stamps (AVEX_AMD_ATT_DEBUG=4)
 #endif                             // deferred-max threshold, log2 units (p <= 256)
@@ -302,7 +320,8 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                                                         const float* __restrict__ grep_b,
                                                         const float* __restrict__ grep_a,
                                                         const uint8_t* __restrict__ key_pad,
-                                                        T* __restrict__ out, int dbg) {
+                                                        T* __restrict__ out, int dbg_arg) {
+    AVX_ATT_DBG(dbg_arg)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -397,6 +416,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[u][s] = *(const v8*)(base + (int64_t)iq[u] * ld + 16 * s + 8 * hh);
     };
+    if (ATT_PRIO && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every VALU arbitration otherwise (one static raise, no per-segment flips)
     load_q(h_cur, b_cur);                                // older than the DMA below: waiting for it never waits for the DMA
     if (LONG) write_window(0);
     issue_next(0);
@@ -431,8 +451,12 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 
     // Output of item (h, b): the lane pair (l, l + 32) holds a query row's d = 8g + 4hh + 0..3; two v_permlane32_swap per
     // pair of g give each lane 8 consecutive d, so a row is written in 16-byte pieces (four stores per 32-query tile).
+    int n_st = 0;                                        // store instructions this wave issued for the last finished item (wave-uniform)
     auto store_item = [&](int h, int b) __attribute__((always_inline)) {
-        if (!has_q) return;
+        n_st = 0;
+        if (!has_q || (dbg & 32)) return;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) n_st += __builtin_amdgcn_readfirstlane(qi[u] - r32) < Tn ? 4 : 0;
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
@@ -471,6 +495,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         // than that DMA and stay in flight.
 #define AVX_PT(i) if (ATT_STAMPS) { __builtin_amdgcn_sched_barrier(0); pt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         unsigned long long pt[8];
+        if (ATT_STAMPS) pt[7] = __builtin_amdgcn_s_memrealtime();
         AVX_PT(0)
         if (half == 0 && ph > 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -478,8 +503,10 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         __builtin_amdgcn_s_barrier();
         AVX_PT(2)
         AVX_PT(3)
+        bool vm_young = LONG;                            // a global load younger than the previous item's output stores is pending
         if (half == 0) {
             if (!LONG && h_cur != h_tab) {               // workgroup-uniform
+                vm_young = true;
                 for (int r = tid; r < TAB_LD; r += NT) {
                     float v = 0.f;
                     if (bias_tab && r < 2 * Tn - 1) v = bias_tab[(int64_t)h_cur * (2 * Tn - 1) + r] * 1.4426950408889634f;
@@ -494,11 +521,12 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 int bn = b_cur + 1;
                 bn = bn == Bc ? 0 : bn;
                 write_kadd(item_par ^ 1, bn);
+                vm_young = vm_young || key_pad != nullptr;
             }
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
                 gate[u] = 1.f;
-                if (grep_w) {
+                if (grep_w && !(dbg & 16)) {
                     f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
@@ -528,8 +556,28 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         // as well.  Passing qf through the statement makes this the definition the tiles see, in every phase, so no wait
         // for those loads is placed inside the tiles.  From here to the next boundary a phase touches only LDS and registers.
         if (LONG && ph + 1 < np) write_window(ph + 1);   // next phase's bias window + key mask (other slot; read after the next barrier)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]));
+        // At an item's first phase the youngest outstanding operations are the previous item's output stores (n_st of them, issued
+        // after the Q loads): the counted wait lets them drain under the tiles instead of stalling every wave for their round trip
+        // to HBM (3.4k of an item's 37k cycles).  Anything younger (mask / bias-row loads above) forces the full wait.
+        if (half == 0 && ph > 0 && !vm_young && n_st == 8)
+            asm volatile("s_waitcnt vmcnt(8)"
+                         : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]));
+        else if (half == 0 && ph > 0 && !vm_young && n_st == 4)
+            asm volatile("s_waitcnt vmcnt(4)"
+                         : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]));
+        else
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]));
+        if (half == 0) {
+            // this (item, query block)'s fragment arrives unscaled (the gate above wants it so); from here on it carries the score scale
+            const T qs = (T)cs;
+#pragma unroll
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) qf[u][s4][e8] = qf[u][s4][e8] * qs;
+        }
         if (ph + 1 < np && dbg != 3) issue_next(ph + 1);
         AVX_PT(4)
         if (has_q) {
@@ -559,6 +607,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             v8 kf[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s]);
+            if (ATT_STAGGER > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(ATT_STAGGER);
             auto tile = [&](auto KT) __attribute__((always_inline)) {
                 constexpr int ktl = decltype(KT)::value;
                 const int kt = half * 8 + ktl;
@@ -572,98 +621,108 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 AVX_TR(vt[1][0][0], 1024 * (ktl * 4 + 2) + 0);   AVX_TR(vt[1][0][1], 1024 * (ktl * 4 + 3) + 0);
                 AVX_TR(vt[1][1][0], 1024 * (ktl * 4 + 2) + 512); AVX_TR(vt[1][1][1], 1024 * (ktl * 4 + 3) + 512);
 #undef AVX_TR
-                // both query tiles in one straight-line block: S chains, scores, exponentials.  The running reference is
-                // checked AFTER the exponentials, on the half-row sums that are needed anyway: a sum below 2^12 proves every p of
-                // this lane is below 2^12 (f16-safe), so the common path has no maximum at all.
-                float e[NQ][16];
+                // Both query tiles in one straight-line block.  The MFMA accumulators START at the additive part of the score,
+                // gate * bias - m_run (+ the key mask), in log2 units, and the query fragment is pre-multiplied by log2(e) / 8 (once per
+                // item, below): the S chain then delivers  score - m_run  ready for the exponential -- no VALU between the matrix
+                // pipe and v_exp_f32, and the bias FMAs sit in front of the chain where they overlap the partner wave's MFMAs.
+                // The running reference is checked AFTER the exponentials, on the half-row sums that are needed anyway: a sum below
+                // 2^12 proves every p of this lane is below 2^12 (f16-safe), so the common path has no maximum at all.
                 v8 pf[NQ][2];
                 f32x2 ls[NQ];
-                bool moves = false;
                 f32x16 Sq[NQ];
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Sq[u][r] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) Sq[u] = mfma32(kf[s], qf[u][s], Sq[u]);
-                }
-                // the K fragment is dead once both chains are issued: the next tile's goes into the same registers now
-                if (ktl + 1 < 8) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
-                }
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const f32x16 S = Sq[u];
-                    // e = score - m_run in log2 units: S * (log2e / 8) + (gate * (bias * log2e) - m_run)
-                    const f32x2 g2 = {gate[u], gate[u]}, c2 = {cs, cs}, nm2 = {-m_run[u], -m_run[u]};
+                auto init_acc = [&](int u) __attribute__((always_inline)) {
+                    const f32x2 g2 = {gate[u], gate[u]}, nm2 = {-m_run[u], -m_run[u]};
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const f32x4 t4 = *(const f32x4*)(tp[u] + ktl * 32 + 8 * g4);
-                        const f32x2 ea = __builtin_elementwise_fma((f32x2){S[4 * g4], S[4 * g4 + 1]}, c2, __builtin_elementwise_fma(g2, (f32x2){t4[0], t4[1]}, nm2));
-                        const f32x2 eb = __builtin_elementwise_fma((f32x2){S[4 * g4 + 2], S[4 * g4 + 3]}, c2, __builtin_elementwise_fma(g2, (f32x2){t4[2], t4[3]}, nm2));
-                        e[u][4 * g4] = ea[0]; e[u][4 * g4 + 1] = ea[1]; e[u][4 * g4 + 2] = eb[0]; e[u][4 * g4 + 3] = eb[1];
+                        const f32x4 t4 = (dbg & 512) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(tp[u] + ktl * 32 + 8 * g4);
+                        const f32x2 ea = __builtin_elementwise_fma(g2, (f32x2){t4[0], t4[1]}, nm2);
+                        const f32x2 eb = __builtin_elementwise_fma(g2, (f32x2){t4[2], t4[3]}, nm2);
+                        Sq[u][4 * g4] = ea[0]; Sq[u][4 * g4 + 1] = ea[1]; Sq[u][4 * g4 + 2] = eb[0]; Sq[u][4 * g4 + 3] = eb[1];
                     }
                     if (masked_tile) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) e[u][r] += kad[jb + (r & 3) + 8 * (r >> 2)];
+                        for (int r = 0; r < 16; ++r) Sq[u][r] += kad[jb + (r & 3) + 8 * (r >> 2)];
                     }
+                };
+                // exponentials of tile u -> P fragment + half-row sums; true if the running reference has to move
+                auto softmax_u = [&](int u) __attribute__((always_inline)) -> bool {
                     ls[u] = (f32x2){0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        const f32x2 pp = {__builtin_amdgcn_exp2f(e[u][r]), __builtin_amdgcn_exp2f(e[u][r + 1])};
+                        const f32x2 pp = (dbg & 128) ? (f32x2){Sq[u][r], Sq[u][r + 1]} : (f32x2){__builtin_amdgcn_exp2f(Sq[u][r]), __builtin_amdgcn_exp2f(Sq[u][r + 1])};
                         ls[u] += pp;
                         pf[u][r >> 3][r & 7] = (T)pp[0];
                         pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
                     }
                     // !(sum < 2^12) also catches the overflowed (inf) and the invalid (NaN) sum
-                    moves = moves || !ref_set[u] || !(hsum2(ls[u]) < 4096.f);
-                }
-                if (__any(moves)) {
-                    // a row's first unmasked tile sets its reference to the row maximum; later it moves when a tile has grown past it.
-                    // The exponentials of this tile are redone against the new reference.
+                    return !ref_set[u] || !(hsum2(ls[u]) < 4096.f);
+                };
+                // a row's first unmasked tile sets its reference to the row maximum; later it moves when a tile has grown past it.
+                // The exponentials of this tile are redone against the new reference.
+                auto redo_u = [&](int u) __attribute__((always_inline)) {
+                    float mx = Sq[u][0];
 #pragma unroll
-                    for (int u = 0; u < NQ; ++u) {
-                        float mx = e[u][0];
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, Sq[u][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const bool need = ref_set[u] ? mx > A2_THR : mx != NEG_INF;
+                    const float d = need ? mx : 0.f;
+                    const float alpha = (need && ref_set[u]) ? __builtin_amdgcn_exp2f(-d) : 1.f;
+                    ref_set[u] = ref_set[u] || need;
+                    m_run[u] += d;
+                    l_run[u] *= alpha;
+                    ls[u] = (f32x2){0.f, 0.f};
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, e[u][r]);
-                        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                        const bool need = ref_set[u] ? mx > A2_THR : mx != NEG_INF;
-                        const float d = need ? mx : 0.f;
-                        const float alpha = (need && ref_set[u]) ? __builtin_amdgcn_exp2f(-d) : 1.f;
-                        ref_set[u] = ref_set[u] || need;
-                        m_run[u] += d;
-                        l_run[u] *= alpha;
-                        ls[u] = (f32x2){0.f, 0.f};
+                    for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
-#pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const f32x2 pp = {__builtin_amdgcn_exp2f(e[u][r] - d), __builtin_amdgcn_exp2f(e[u][r + 1] - d)};
-                            ls[u] += pp;
-                            pf[u][r >> 3][r & 7] = (T)pp[0];
-                            pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
-                        }
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 pp = {__builtin_amdgcn_exp2f(Sq[u][r] - d), __builtin_amdgcn_exp2f(Sq[u][r + 1] - d)};
+                        ls[u] += pp;
+                        pf[u][r >> 3][r & 7] = (T)pp[0];
+                        pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
                     }
+                };
+                v8 vf[2][2];
+                auto wait_v = [&]() __attribute__((always_inline)) {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                                   "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]));
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int dh = 0; dh < 2; ++dh) {
+                            const v4 lo = __builtin_bit_cast(v4, vt[s2][dh][0]), hi = __builtin_bit_cast(v4, vt[s2][dh][1]);
+                            vf[s2][dh] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                };
+                auto next_k = [&]() __attribute__((always_inline)) {
+                    // the K fragment is dead once both chains are issued: the next tile's goes into the same registers now
+                    if (ktl + 1 < 8) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
+                    }
+                };
+                init_acc(0); init_acc(1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {            // the two tiles' chains interleaved: consecutive MFMAs never share an accumulator
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) if (!(dbg & 64)) Sq[u] = mfma32(kf[s], qf[u][s], Sq[u]);
                 }
+                next_k();
+                bool moves = softmax_u(0);
+                moves = softmax_u(1) || moves;
+                if (__any(moves)) { redo_u(0); redo_u(1); }
+                l_run[0] += hsum2(ls[0]); l_run[1] += hsum2(ls[1]);
+                wait_v();
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) l_run[u] += hsum2(ls[u]);
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
-                               "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]));
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-                    for (int dh = 0; dh < 2; ++dh) {
-                        const v4 lo = __builtin_bit_cast(v4, vt[s2][dh][0]), hi = __builtin_bit_cast(v4, vt[s2][dh][1]);
-                        const v8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
                         for (int u = 0; u < NQ; ++u) {
-                            if (dh == 0) o0[u] = mfma32(vf, pf[u][s2], o0[u]);
-                            else o1[u] = mfma32(vf, pf[u][s2], o1[u]);
+                            if (dbg & 256) continue;
+                            if (dh == 0) o0[u] = mfma32(vf[s2][0], pf[u][s2], o0[u]);
+                            else o1[u] = mfma32(vf[s2][1], pf[u][s2], o1[u]);
                         }
-                    }
-                }
             };
             if (0 < kt_end) tile(a_ic<0>{});
             if (1 < kt_end) tile(a_ic<1>{});
@@ -702,36 +761,27 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         half = last_half ? 0 : half + 1;
         AVX_PT(6)
 #undef AVX_PT
-        if (ATT_STAMPS && dbg == 4 && blockIdx.x == 3 && tid == 0 && ph >= 2 && ph < 8)
-            printf("phase %d half %d: vmwait %llu barrier %llu dma-issue %llu setup %llu tiles %llu finish %llu\n", ph, half, pt[1] - pt[0], pt[2] - pt[1],
-                   pt[3] - pt[2], pt[4] - pt[3], pt[5] - pt[4], pt[6] - pt[5]);
+#if ATT_STAMPS
+        if (blockIdx.x < 64 && lane == 0 && ph < 32) {
+            unsigned long long* d = g_att_stamps + (((size_t)blockIdx.x * 8 + wave) * 32 + ph) * 8;
+            for (int i = 0; i < 8; ++i) d[i] = pt[i];
+        }
+#endif
     }
 }
 
 template <typename T>
 int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const float* grep_w, const float* grep_b,
            const float* grep_a, const uint8_t* key_pad, void* out, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-        attr_set = true;
-    }
+    AVX_ENSURE_LDS(attention_kernel<T>, ATT_LDS);
     static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
     int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
     if (Tn > TMAX) variant = 2;          // variant 1 keeps a whole head in LDS (T <= 512)
     if (variant == 2) {
-        static bool attr2_set = false;
-        static int n_cu = 0;
-        if (!attr2_set) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention2_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention2_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2L_LDS));
-            int dev = 0;
-            hipDeviceProp_t prop;
-            AVX_HIP_CHECK(hipGetDevice(&dev));
-            AVX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            attr2_set = true;
-        }
+        AVX_ENSURE_LDS((attention2_kernel<T, false>), ATT2_LDS);
+        AVX_ENSURE_LDS((attention2_kernel<T, true>), ATT2L_LDS);
+        int n_cu = 256;
+        { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
         const int n_items = B * H;
         int n_wg = n_cu;
         if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several items per workgroup
@@ -753,6 +803,14 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
 }
 
 }  // namespace
+
+#if defined(AVEX_DIAG) && ATT_STAMPS
+extern "C" int avexhip_debug_att_stamps(unsigned long long* host_out, int n) {
+    if (!host_out || n <= 0) return -1;
+    if (n > 64 * 8 * 32 * 8) n = 64 * 8 * 32 * 8;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_att_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
 
 namespace avx {
 

@@ -193,6 +193,14 @@ void avexhip_set_error(const char* fmt, ...);
 // Internal launchers shared between translation units (all return AVEXHIP_* codes).
 namespace avx {
 
+// Per-device launcher state (thread-safe): the dynamic-LDS opt-in of a kernel is a property of the function ON ONE DEVICE, and the
+// CU count differs between devices; a process that drives several GPUs, or several threads, must not share one `static bool`.
+//   AVX_ENSURE_LDS(kernel, bytes)  hipFuncSetAttribute(..MaxDynamicSharedMemorySize..) once per (current device, kernel)
+//   avx::device_cu_count(&n)       multiProcessorCount of the current device, cached per device
+int ensure_max_dynamic_lds(const void* func, int bytes);
+int device_cu_count(int* n_cu);
+#define AVX_ENSURE_LDS(kernel, bytes) do { const int rc_ = avx::ensure_max_dynamic_lds((const void*)(kernel), (int)(bytes)); if (rc_ != AVEXHIP_OK) return rc_; } while (0)
+
 struct GemmArgs {
     const void* A; int64_t lda;
     const void* W; int64_t ldw;

@@ -298,6 +298,7 @@ __global__ void patchify_kernel(const float* __restrict__ fb, int frames, int n_
     out[i] = Half<T>::from(fb[(b * frames + fr) * n_mels + mel]);
 }
 
+#ifdef AVEX_DIAG
 // Debug aid: fills a static LDS array with a pattern and re-checks it for a while; any foreign write
 // into this workgroup's LDS shows up in report[] = {mismatch count, first bad word index, value seen, block}.
 __global__ __launch_bounds__(256) void lds_canary_kernel(int iters, unsigned* __restrict__ report) {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(256) void lds_canary_kernel(int iters, unsigned* __
         __syncthreads();
     }
 }
+#endif  // AVEX_DIAG
 
 // EAT / Data2Vec-multi token assembly: row 0 of a clip is the class token, row 1 + t is patch t plus its fixed position; every
 // row then goes through the encoder's first LayerNorm (`pre_norm`, the context encoder's norm with layer_norm_first = False).
@@ -548,7 +550,9 @@ int patchify(const float* fbank, int B, int frames, int n_mels, int patch, void*
 
 }  // namespace avx
 
+#ifdef AVEX_DIAG
 extern "C" int avexhip_debug_lds_canary(int blocks, int iters, unsigned* report_dev, void* stream) {
     hipLaunchKernelGGL(lds_canary_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, report_dev);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+#endif

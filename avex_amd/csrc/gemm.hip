@@ -192,10 +192,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 // half-tiles issued in B(t) = 6 DMA instructions are younger, hence vmcnt(6) in B(t), before the
 // barrier that every wave must pass before any wave reads tile t+1 (RAW).
 // ---------------------------------------------------------------------------------------------
+// Clock stamps exist only in the diagnostic build (AVEX_AMD_DIAG=1 python -m avex_amd.build -> lib/libavexhip_diag.so, -DAVEX_DIAG):
+// in the product library AVX_STAMPS_ON is the constant false and every stamp statement below is compiled out.
+#ifdef AVEX_DIAG
 __device__ unsigned long long g_gemm_stamps[4 * 8192];
 __device__ int g_gemm_stamps_on = 0;
 __device__ unsigned long long g_gemm_clk[2 * 8192];
-__device__ unsigned long long g_gemm_kclk[256 * 64];   // s_memtime at the top of every K-tile of each workgroup's third tile, variant 5   // s_memtime (shader clock) at loop start / end, variant 5
+__device__ unsigned long long g_gemm_kclk[256 * 64];
+#define AVX_STAMPS_ON (g_gemm_stamps_on != 0)
+#define AVX_STAMP(...) do { __VA_ARGS__; } while (0)
+#else
+#define AVX_STAMPS_ON false
+#define AVX_STAMP(...) do { } while (0)
+#endif
+//   // s_memtime at the top of every K-tile of each workgroup's third tile, variant 5   // s_memtime (shader clock) at loop start / end, variant 5
 
 constexpr int T2 = 256;
 // Tile walk of the 256-tile kernels: consecutive logical tile ids (each XCD owns a contiguous range of them, and its 32 CUs
@@ -449,8 +459,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
     const int nk = p.K / BK;
-    const bool stamp = g_gemm_stamps_on != 0 && tid == 0 && blockIdx.x < 8192;
-    if (stamp) g_gemm_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+    const bool stamp = AVX_STAMPS_ON && tid == 0 && blockIdx.x < 8192;
+    AVX_STAMP(if (stamp) g_gemm_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime(););
 
     // ---- per-lane DMA source pointers: [half][q] for W and X ------------------------------------
     // W half h = rows 128q + 64h + 8*wid + (lane>>3); X half h = rows 128q + 64*(wid>>2) + 32h + 8*(wid&3) + (lane>>3)
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         ((float2*)(smem + LNS_OFF))[tid] = make_float2(rstd, -mu * rstd);       // LN(y) = y * rstd + (-mu * rstd), times gamma, plus beta
     }
     AVX_BAR();
-    if (stamp) g_gemm_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    AVX_STAMP(if (stamp) g_gemm_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(););
     if (wm == 1) { AVX_BAR(); }   // stagger: waves 4-7 run one barrier behind
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
         AVX_BAR();
     }
     if (wm == 0) { AVX_BAR(); }   // re-align the two groups
-    if (stamp) g_gemm_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    AVX_STAMP(if (stamp) g_gemm_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(););
 
     // ---- epilogue -------------------------------------------------------------------------------
     // Each wave transposes its 128(n) x 64(m) accumulators through a private LDS slab (the stage
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
             }
         }
     }
-    if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_gemm_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); }
+    AVX_STAMP(if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_gemm_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); });
 }
 
 
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     set_tile(tile);
     dma_bias(n0, 0);
     tile_prologue();
-    const bool stamp_on = g_gemm_stamps_on != 0 && tid == 0;
+    const bool stamp_on = AVX_STAMPS_ON && tid == 0;
     AVX_VMCNT(6);
     AVX_BAR();
     if (wm == 1) { AVX_BAR(); }      // stagger: waves 4-7 run one barrier behind, for the whole tile walk
@@ -797,10 +807,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         const int em0 = m0, en0 = n0;
         const int next_tile = ((it + 1) * 8 + xcd) * per_xcd + slot;
         const bool has_next = next_tile < ntiles;
-        if (stamp) { g_gemm_stamps[4 * tile + 0] = g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); }
+        AVX_STAMP(if (stamp) { g_gemm_stamps[4 * tile + 0] = g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); });
         for (int kt = 0; kt < nk; ++kt) {
             const int st = (g0 + kt) & 1;
-            if (stamp && it == 2 && kt < 63 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + kt] = __builtin_amdgcn_s_memtime();
+            AVX_STAMP(if (stamp && it == 2 && kt < 63 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + kt] = __builtin_amdgcn_s_memtime(););
             AVX_READ_X(st);
             AVX_READ_W(0, st);
             if (kt + 1 < nk) { if (!(early_w1 && kt == 0 && it > 0)) dma_w(1, kt + 1, st ^ 1); }   // (issued before the epilogue, see below)
@@ -832,7 +842,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_HALF(1);
             AVX_BAR();
         }
-        if (stamp && it == 2 && nk < 64 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + nk] = __builtin_amdgcn_s_memtime();
+        AVX_STAMP(if (stamp && it == 2 && nk < 64 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + nk] = __builtin_amdgcn_s_memtime(););
         // Re-align the two wave groups for the epilogue (as the tile-per-workgroup kernel does): left staggered, the lagging group cannot
         // pass its last loop barrier before the leading group reaches the next tile's first one, i.e. the two epilogues run one after the other.
         if (wm == 0) { AVX_BAR(); }
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         // epilogue's stores, the first K-tile's counted wait does not have to wait for those stores.
         if (early_w1 && has_next) dma_w(1, 1, ((g0 + nk) & 1) ^ 1);
         g0 += nk;
-        if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); }
+        AVX_STAMP(if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); });
 
         const int er = lane >> 3, ec = lane & 7, lc = lane & 15, lg = lane >> 4;
 
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 }
             }
         }
-        if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime();
+        AVX_STAMP(if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime(););
         if (!has_next) break;
         prev_full = em0 + T2 <= p.M;
         if (wm == 1) { AVX_BAR(); }      // stagger again for the next tile's loop
@@ -970,18 +980,10 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         if (!fast_half && !fast_resid) variant = 2;
     }
     if (variant == 5) {
-        static bool attr_set5 = false;
-        static int n_cu = 0;
-        if (!attr_set5) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256p_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5));
-            int dev = 0;
-            hipDeviceProp_t prop;
-            AVX_HIP_CHECK(hipGetDevice(&dev));
-            AVX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            attr_set5 = true;
-        }
+        AVX_ENSURE_LDS((gemm256p_kernel<T, 1>), LDS5);
+        AVX_ENSURE_LDS((gemm256p_kernel<T, 2>), LDS5);
+        int n_cu = 256;
+        { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
         avx::GemmArgs a5 = a;
         a5.stagger_ticks = 0; a5.stagger_groups = 1;
@@ -996,11 +998,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         return AVEXHIP_OK;
     }
     if (variant == 2) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
-            attr_set = true;
-        }
+        AVX_ENSURE_LDS(gemm256_kernel<T>, LDS2);
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
         static const int order = getenv("AVEX_AMD_GEMM_TILE_ORDER") ? atoi(getenv("AVEX_AMD_GEMM_TILE_ORDER")) : 0;
         avx::GemmArgs a2 = a;
@@ -1013,14 +1011,8 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     static const char* pad_env = getenv("AVEX_AMD_DEBUG_LDS_PAD");
     const size_t lds = 2 * 2 * TILE_BYTES + (pad_env ? atoi(pad_env) : 0);
-    {
-        static bool attr_set = false;
-        if (!attr_set) {
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            AVX_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
-        }
-    }
+    AVX_ENSURE_LDS((gemm_nt_kernel<T, false>), 96 * 1024);
+    AVX_ENSURE_LDS((gemm_nt_kernel<T, true>), 96 * 1024);
     if (variant == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(tiles), dim3(256), lds, s, a);
     } else {
@@ -1053,6 +1045,7 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
 
 }  // namespace avx
 
+#ifdef AVEX_DIAG
 // debug: enable/read the per-block stamps of gemm256_kernel (start, prologue done, loop done, epilogue stores retired)
 extern "C" int avexhip_debug_gemm_stamps(int enable, unsigned long long* host_out, int n_blocks) {
     int on = enable;
@@ -1079,3 +1072,4 @@ extern "C" int avexhip_debug_gemm_kclocks(unsigned long long* host_out, int n_bl
     if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_kclk), sizeof(unsigned long long) * 64 * n_blocks) != hipSuccess) return -2;
     return 0;
 }
+#endif  // AVEX_DIAG

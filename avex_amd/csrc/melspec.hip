@@ -256,8 +256,7 @@ extern "C" int avexhip_melspec_forward(const avexhip_melspec_plan* p, const floa
     const int take_log = p->cfg.normalize ? 1 : 0;
 #define AVX_MEL_LAUNCH(NTW)                                                                                              \
     do {                                                                                                                 \
-        static bool set = false;                                                                                         \
-        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)melspec_kernel<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        AVX_ENSURE_LDS(melspec_kernel<NTW>, 160 * 1024);                                                                 \
         hipLaunchKernelGGL(melspec_kernel<NTW>, grid, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log); \
     } while (0)
     switch (ntw) {

@@ -218,13 +218,11 @@ int posconv(const void* x_half, const float* x_f32, const void* w_packed, const 
     AVX_REQUIRE(B > 0 && T > 0, "posconv: empty input B=%d T=%d", B, T);
     const int nseg = (T + TMAX - 1) / TMAX;
     if (dtype == AVEXHIP_BF16) {
-        static bool set = false;
-        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS)); set = true; }
+        AVX_ENSURE_LDS(posconv_kernel<__bf16>, PC_LDS);
         hipLaunchKernelGGL(posconv_kernel<__bf16>, dim3(B * nseg * groups), dim3(512), PC_LDS, s, (const __bf16*)x_half, x_f32,
                            (const __bf16*)w_packed, bias, T, E, groups, nseg, out, (__bf16*)out_half);
     } else if (dtype == AVEXHIP_F16) {
-        static bool set = false;
-        if (!set) { AVX_HIP_CHECK(hipFuncSetAttribute((const void*)posconv_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS)); set = true; }
+        AVX_ENSURE_LDS(posconv_kernel<_Float16>, PC_LDS);
         hipLaunchKernelGGL(posconv_kernel<_Float16>, dim3(B * nseg * groups), dim3(512), PC_LDS, s, (const _Float16*)x_half, x_f32,
                            (const _Float16*)w_packed, bias, T, E, groups, nseg, out, (_Float16*)out_half);
     } else {

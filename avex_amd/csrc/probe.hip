@@ -300,6 +300,30 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* __restrict__
 
 }  // namespace
 
+// torch.nn.functional.interpolate(x.transpose(1, 2), size=Tout, mode="linear", align_corners=False).transpose(1, 2) on [B, Tin, C]
+// rows (base_probes.py:398-411: taps of different sequence lengths are brought to the shortest one): source position
+// (t + 0.5) * Tin / Tout - 0.5 clamped at 0, the two neighbours weighted (1 - w) and w in that order.
+__global__ __launch_bounds__(256) void seq_interp_linear_kernel(const float* __restrict__ in, int Tin, int C, int Tout, float scale, float* __restrict__ out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    float src = scale * ((float)t + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    const float w1 = src - (float)i0, w0 = 1.f - w1;
+    const float* r0 = in + ((int64_t)b * Tin + i0) * C;
+    const float* r1 = in + ((int64_t)b * Tin + i1) * C;
+    float* o = out + ((int64_t)b * Tout + t) * C;
+    for (int c = threadIdx.x; c < C; c += 256) o[c] = w0 * r0[c] + w1 * r1[c];
+}
+
+extern "C" int avexhip_seq_interp_linear(const float* in_dev, int B, int Tin, int C, int Tout, float* out_dev, void* stream) {
+    AVX_REQUIRE(in_dev && out_dev, "seq_interp_linear: null argument");
+    AVX_REQUIRE(B > 0 && Tin > 0 && Tout > 0 && C > 0 && B <= 65535, "seq_interp_linear: bad shape B=%d Tin=%d Tout=%d C=%d", B, Tin, Tout, C);
+    seq_interp_linear_kernel<<<dim3(Tout, B), dim3(256), 0, (hipStream_t)stream>>>(in_dev, Tin, C, Tout, (float)Tin / (float)Tout, out_dev);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
 extern "C" int avexhip_layer_mix(const float* const* taps, int L, const float* layer_weights, int64_t n, float* out, void* stream) {
     AVX_REQUIRE(taps && out && L >= 1 && L <= MIX_MAX && n >= 0, "layer_mix: need 1..%d taps, got %d", MIX_MAX, L);
     if (n == 0) return AVEXHIP_OK;
@@ -344,11 +368,7 @@ extern "C" int avexhip_mha_f32(const float* qkv, int B, int T, int E, int H, con
         return AVEXHIP_OK;
     }
     const size_t lds = sizeof(float) * ((size_t)MQ * MHD_MAX + (size_t)MQ * T);
-    static bool attr = false;
-    if (!attr) {
-        AVX_HIP_CHECK(hipFuncSetAttribute((const void*)mha_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (MQ * MHD_MAX + MQ * 2048))));
-        attr = true;
-    }
+    AVX_ENSURE_LDS(mha_f32_kernel, sizeof(float) * (MQ * MHD_MAX + MQ * 2048));
     mha_f32_kernel<<<dim3((T + MQ - 1) / MQ, H, B), dim3(256), lds, (hipStream_t)stream>>>(qkv, T, E, H, hd, key_pad, out);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;

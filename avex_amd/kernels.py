@@ -285,6 +285,16 @@ def wavconv0(wav: torch.Tensor, w: torch.Tensor, gn_w: torch.Tensor, gn_b: torch
 PROBE_ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "tanh": 3}
 
 
+def seq_interp_linear(x: torch.Tensor, t_out: int) -> torch.Tensor:
+    """``[B, Tin, C]`` fp32 -> ``[B, t_out, C]``: ``F.interpolate(mode="linear", align_corners=False)`` along the sequence."""
+    _need_cuda(x)
+    x = x.float().contiguous()
+    B, Tin, Cc = x.shape
+    out = torch.empty((B, int(t_out), Cc), dtype=torch.float32, device=x.device)
+    check(lib().avexhip_seq_interp_linear(_ptr(x), B, Tin, Cc, int(t_out), _ptr(out), _stream()), "seq_interp_linear")
+    return out
+
+
 def layer_mix(taps: Sequence[torch.Tensor], layer_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``sum_l softmax(layer_weights)_l * taps[l]`` (weights of 1.0 without ``layer_weights``), the reference's
     ``_BaseProbe._sum`` (base_probes.py:197-206), in one pass over the taps."""

@@ -44,21 +44,60 @@ class _DeviceProbe(nn.Module):
         self.target_length = target_length
         self.freeze_backbone = True
         shapes = self._probe_input_shapes(input_dim)
-        feats = {self._feature_dim(s) for s in shapes}
-        if len(feats) != 1:
-            raise NotImplementedError(f"taps of different widths {sorted(feats)} need embedding projectors, which are not built")
-        if len(shapes) > 1:                                         # base_probes.py:150-152: only for several embeddings
-            self.register_buffer("layer_weights", torch.zeros(len(shapes)))
-        self.inferred_dim = feats.pop()
+        self.embedding_projectors: Optional[nn.ModuleList] = None
+        if len(shapes) > 1 or self._list_input:                     # a LIST of embeddings: projectors + layer weights
+            self.inferred_dim = self._analyze_and_create_projectors(shapes)
+            if len(shapes) > 1:                                     # base_probes.py:150-152: only for several embeddings
+                self.register_buffer("layer_weights", torch.zeros(len(shapes)))
+        else:
+            self.inferred_dim = self._feature_dim(shapes[0])
         self.build_head(self.inferred_dim)
         self.to(device)
         super().train(False)
 
     # -- construction ------------------------------------------------------------------------------------------------------
+    def _analyze_and_create_projectors(self, shapes: List[tuple]) -> int:
+        """Which taps need an ``nn.Linear`` to the common width (base_probes.py:254-289 for 2-D probes, :333-367 for 3-D ones): the
+        target is the width (and, for 3-D, the sequence length) more than half of the taps share, else the largest; taps that differ
+        get a projector (3-D: also when only their sequence length differs, as the reference does).  Entries are ``None`` where no
+        projection is needed, so ``state_dict`` keys are ``embedding_projectors.{i}.weight/bias`` like the reference's."""
+        from collections import Counter
+        if self.rank == 2:
+            dims = [self._feature_dim(s) for s in shapes]
+            common, count = Counter(dims).most_common(1)[0]
+            target = common if count > len(dims) / 2 else max(dims)
+            need = [d != target for d in dims]
+            in_dims = dims
+        else:
+            info = []
+            for s in shapes:                                        # (seq_len, feat) per tap, shapes are without the batch dim
+                if len(s) == 2:
+                    info.append((s[0], s[1]))
+                elif len(s) == 3:
+                    info.append((s[2], s[0] * s[1]))
+                elif len(s) == 1:
+                    info.append((s[0], 1))
+                else:
+                    raise ValueError(f"Unsupported embedding dim {len(s) + 1} for 3D probe")
+            seq_c, seq_n = Counter(q for q, _ in info).most_common(1)[0]
+            feat_c, feat_n = Counter(f for _, f in info).most_common(1)[0]
+            target_seq = seq_c if seq_n > len(info) / 2 else max(q for q, _ in info)
+            target = feat_c if feat_n > len(info) / 2 else max(f for _, f in info)
+            need = [not (f == target and q == target_seq) for q, f in info]
+            in_dims = [f for _, f in info]
+        self.embedding_projectors = nn.ModuleList([nn.Linear(d, target) if n else None for d, n in zip(in_dims, need)])
+        for m in self.embedding_projectors:
+            if m is not None:
+                for p_ in m.parameters():
+                    p_.requires_grad_(False)
+        return target
+
     def _probe_input_shapes(self, input_dim) -> List[tuple]:
         """Per-embedding shapes without the batch dim (base_probes.py:93-163)."""
+        self._list_input = False
         if self.feature_mode and input_dim is not None:
             if isinstance(input_dim, list):
+                self._list_input = len(input_dim) > 1
                 return [tuple(s) for s in input_dim]
             if isinstance(input_dim, tuple):
                 return [input_dim]
@@ -75,6 +114,7 @@ class _DeviceProbe(nn.Module):
                              "target_length_seconds")
         with torch.no_grad():
             emb = self.base_model.extract_embeddings(torch.randn(1, n, device=self.device), aggregation=self.aggregation)
+        self._list_input = isinstance(emb, list)
         return [tuple(e.shape[1:]) for e in (emb if isinstance(emb, list) else [emb])]
 
     def _feature_dim(self, shape: tuple) -> int:
@@ -118,16 +158,27 @@ class _DeviceProbe(nn.Module):
     def _mix(self, taps: List[torch.Tensor]) -> torch.Tensor:
         return K.layer_mix([t.float() for t in taps], getattr(self, "layer_weights", None))
 
+    def _project(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        """``embedding_projectors[i](x)`` on the device (fp32 MFMA); ``x`` is ``[B, in]`` or ``[B, T, in]``."""
+        proj = self.embedding_projectors[i] if self.embedding_projectors is not None and i < len(self.embedding_projectors) else None
+        if proj is None:
+            return x
+        lead = x.shape[:-1]
+        y = K.dense_f32(x.reshape(-1, x.shape[-1]).float().contiguous(), proj.weight.detach(), proj.bias.detach())
+        return y.reshape(*lead, y.shape[-1])
+
     def _combine(self, emb: TensorOrList) -> torch.Tensor:
         if self.rank == 2:                                          # base_probes.py:299-322
             if isinstance(emb, list):
-                return self._mix([e.reshape(e.shape[0], -1) for e in emb])
+                return self._mix([self._project(i, e.reshape(e.shape[0], -1)) for i, e in enumerate(emb)])
             return emb.reshape(emb.shape[0], -1).float()
         fmt = self._seq_feat                                        # base_probes.py:389-414
         if isinstance(emb, list):
-            taps = [fmt(e) for e in emb]
-            if len({t.shape[1] for t in taps}) > 1:
-                raise NotImplementedError("taps of different sequence lengths (linear interpolation) are not built")
+            taps = [self._project(i, fmt(e)) for i, e in enumerate(emb)]
+            lens = [t.shape[1] for t in taps]
+            if len(set(lens)) > 1:                                  # to the SHORTEST length, linear, align_corners=False (:398-411)
+                tgt = min(lens)
+                taps = [t if t.shape[1] == tgt else K.seq_interp_linear(t, tgt) for t in taps]
             return self._mix(taps)
         return fmt(emb).float()
 

@@ -151,7 +151,10 @@ int avexhip_wavconv0(const float* wav_dev, int B, int64_t T, int64_t wav_stride,
  *                      mlp_probe.py:51-73,91; attention_probe.py:59-86,128-134);
  *   avexhip_mha_f32    the attention core of nn.MultiheadAttention(batch_first=True) in eval (attention_probe.py:128): qkv
  *                      [B*T, 3E] = in_proj output (q | k | v thirds, head h at columns h*E/H..), key_pad optional [B, T] uint8
- *                      (1 = ignore key), out [B*T, E] (to be fed to out_proj).  E/H a multiple of 4, <= 128; T <= 2048. */
+ *                      (1 = ignore key), out [B*T, E] (to be fed to out_proj).  E/H a multiple of 4, <= 128; T <= 2048.
+ *   avexhip_seq_interp_linear  base_probes.py:398-411: taps of different sequence lengths are resampled to the shortest with
+ *                      F.interpolate(mode="linear", align_corners=False) along the sequence: in [B, Tin, C] -> out [B, Tout, C]. */
+int avexhip_seq_interp_linear(const float* in_dev, int B, int Tin, int C, int Tout, float* out_dev, void* stream);
 int avexhip_layer_mix(const float* const* taps, int L, const float* layer_weights_dev, int64_t n, float* out_dev, void* stream);
 int avexhip_dense_f32(const float* x_dev, int64_t ldx, const float* w_dev, int64_t ldw, const float* bias_dev, const float* resid_dev,
                       int64_t ldr, int M, int N, int K, int act, float* out_dev, int64_t ldo, void* stream);
@@ -239,6 +242,7 @@ int avexhip_token_embed_ln(const void* patches_half, const float* pos, const flo
 /* mean over T: in [B, T, C] fp32 -> out [B, C] fp32 (features.mean(dim=1), README:80). */
 int avexhip_mean_pool(const float* in_dev, int B, int T, int C, float* out_dev, void* stream);
 
+#ifdef AVEX_DIAG   /* diagnostic build only (AVEX_AMD_DIAG=1 python -m avex_amd.build -> libavexhip_diag.so); the product library exports none of these */
 /* Debug aid: `blocks` workgroups hold a 26 880-byte LDS pattern for `iters` re-check rounds;
  * report_dev[4] (zeroed by the caller) = {mismatches, first bad word, value seen, block}. */
 int avexhip_debug_lds_canary(int blocks, int iters, unsigned* report_dev, void* stream);
@@ -251,6 +255,7 @@ int avexhip_debug_gemm_clocks(unsigned long long* host_out, int n_tiles);
 /* Debug aid: s_memtime at the top of every K-tile (and after the last one) of each workgroup's third tile in the persistent GEMM
  * (variant 5, stamps enabled): host_out[64 * block + kt], blocks < 256, kt < 64. */
 int avexhip_debug_gemm_kclocks(unsigned long long* host_out, int n_blocks);
+#endif /* AVEX_DIAG */
 
 /* T5 bidirectional bucket of a relative position (backbone.py:438-473).  Pure host function. */
 int avexhip_rel_bucket(int rel, int num_buckets, int max_distance);

@@ -1,0 +1,83 @@
+// Cost in shader cycles of the attention kernel's two segment types on one SIMD (gfx950): a matrix segment (16 x
+// v_mfma_f32_32x32x16_f16) and a vector segment (32 v_exp_f32, 16 v_cvt_pk_f16_f32, 16 v_pk_add_f32, 16 v_pk_fma_f32), alone and
+// side by side (wave w and w + 4 of a 512-thread workgroup share a SIMD).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/seg_cost.hip -o scripts/micro/bin/seg_cost
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// mode bit 0: waves 0-3 run the matrix segment; bit 1: waves 4-7 run the vector segment; bit 2: waves 4-7 run the matrix segment too;
+// bit 3: waves 0-3 run the vector segment too (same-type pairs)
+template <bool AGPR>
+__global__ __launch_bounds__(512) void seg_kernel(int mode, int iters, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool grp1 = wave >= 4;
+    const bool do_m = grp1 ? (mode & 4) : (mode & 1);
+    const bool do_v = grp1 ? (mode & 2) : (mode & 8);
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    h8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.01f * (lane + e)); b[e] = (_Float16)(0.02f * (lane - e)); }
+    float x[32];
+    for (int i = 0; i < 32; ++i) x[i] = -0.01f * (float)(lane + i);
+    f32x2 sum = {0.f, 0.f};
+    unsigned pk[16];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (do_m) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));     // accumulators in AGPRs
+                    else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);                        // ... where the compiler puts them (VGPRs)
+                }
+        }
+        if (do_v) {
+            const f32x2 g = {1.0001f, 1.0001f}, m = {-0.001f, -0.001f};
+#pragma unroll
+            for (int i = 0; i < 32; i += 2) {
+                f32x2 p = {__builtin_amdgcn_exp2f(x[i]), __builtin_amdgcn_exp2f(x[i + 1])};
+                sum += p;
+                h2 h = {(_Float16)p[0], (_Float16)p[1]};
+                pk[i >> 1] = __builtin_bit_cast(unsigned, h);
+                const f32x2 nx = __builtin_elementwise_fma(g, (f32x2){x[i], x[i + 1]}, m);
+                x[i] = nx[0]; x[i + 1] = nx[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pk[i]));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = sum[0] + sum[1];
+    for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][5];
+    for (int i = 0; i < 32; ++i) r += x[i];
+    if (r == 1234.5f) sink[0] = r;
+    if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
+int main() {
+    unsigned long long* cyc; float* sink;
+    CK(hipMalloc(&cyc, 64)); CK(hipMalloc(&sink, 64));
+    const int iters = 2000;
+    struct { int mode; const char* name; } cases[] = {
+        {1, "matrix segment alone (waves 0-3)"}, {2, "vector segment alone (waves 4-7)"}, {3, "matrix (0-3) beside vector (4-7)"},
+        {5, "matrix beside matrix"}, {10, "vector beside vector"}, {15, "each wave: matrix then vector (both groups)"},
+        {17, "AGPR acc: matrix alone"}, {19, "AGPR acc: matrix (0-3) beside vector (4-7)"}, {31, "AGPR acc: each wave matrix then vector"}};
+    for (auto& c : cases) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (c.mode & 16) hipLaunchKernelGGL(seg_kernel<true>, dim3(256), dim3(512), 0, 0, c.mode & 15, iters, cyc, sink);
+            else hipLaunchKernelGGL(seg_kernel<false>, dim3(256), dim3(512), 0, 0, c.mode, iters, cyc, sink);
+            CK(hipDeviceSynchronize());
+        }
+        unsigned long long h[8];
+        CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+        printf("%-46s: cycles per iteration  wave0 %.0f  wave4 %.0f\n", c.name, (double)h[0] / iters, (double)h[4] / iters);
+    }
+    return 0;
+}

@@ -72,6 +72,35 @@ def main():
     np.savez_compressed(os.path.join(HERE, "probes.npz"), **out)
     print({k: v.shape for k, v in out.items()})
 
+    # ---- taps of unequal width / length: embedding projectors (base_probes.py:254-289,333-367) and the interpolation to the
+    # shortest sequence (:398-411) -> probes_proj.npz
+    out = {}
+    g = torch.Generator().manual_seed(4321)
+    dims = [768, 768, 512]
+    embs = [torch.randn(B, d, generator=g) for d in dims]
+    for i, e in enumerate(embs):
+        out[f"lin.emb{i}"] = e.numpy()
+    lin = LinearProbe(None, [], C, device="cpu", feature_mode=True, input_dim=[(d,) for d in dims])
+    seed_params(lin, 5)
+    lin.eval()
+    out["lin.logits"] = lin({f"l{i}": e for i, e in enumerate(embs)}).detach().numpy()
+    for k, v in lin.state_dict().items():
+        out[f"lin.sd.{k}"] = v.numpy()
+    shapes = [(24, 128), (24, 128), (31, 96), (40, 128)]
+    seqs = [torch.randn(3, t, d, generator=g) for t, d in shapes]
+    for i, e in enumerate(seqs):
+        out[f"att.seq{i}"] = e.numpy()
+    att = AttentionProbe(None, [], C, device="cpu", feature_mode=True, input_dim=shapes, aggregation="none", num_heads=4, attention_dim=128,
+                         num_layers=1, dropout_rate=0.0, use_positional_encoding=False)
+    seed_params(att, 6)
+    att.eval()
+    out["att.logits"] = att({f"l{i}": e for i, e in enumerate(seqs)}).detach().numpy()
+    out["att.combined"] = att._combine_or_reshape_embeddings(seqs).detach().numpy()
+    for k, v in att.state_dict().items():
+        out[f"att.sd.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "probes_proj.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
 
 if __name__ == "__main__":
     main()

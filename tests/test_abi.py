@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "avexhip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef AVEX_DIAG.*?#endif", "", text, flags=re.S)      # diagnostic-build-only exports
     return sorted(set(re.findall(r"\b(avexhip_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -20,6 +21,15 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
         assert hasattr(built_lib, name), f"libavexhip.so does not export {name}"
     # the ctypes binding table covers the header exactly
     assert sorted(_capi.SYMBOLS) == declared
+
+
+def test_product_library_has_no_debug_exports(built_lib):
+    """Clock stamps, canaries and debug entry points live behind -DAVEX_DIAG (a separate library); the product one has none."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert not [n for n in names if "debug" in n.lower()], [n for n in names if "debug" in n.lower()]
+    assert not hasattr(built_lib, "avexhip_debug_gemm_stamps")
 
 
 def test_host_only_entry_points(built_lib):

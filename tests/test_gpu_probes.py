@@ -146,3 +146,30 @@ def test_attention_probe_padding_mask(built_lib, golden_dir):
     assert rel_l2(out.cpu().numpy(), g["att.logits"]) > 1e-3                       # the mask changed something
     dropped = att(seqs, padding_mask=torch.zeros(3, 160000, dtype=torch.bool).cuda())   # sample-level mask: ignored, as in the reference
     assert rel_l2(dropped.cpu().numpy(), g["att.logits"]) < 1e-5
+
+
+def test_projectors_and_interpolation_match_reference(built_lib, golden_dir):
+    """Embedding projectors (base_probes.py:254-289,333-367) and the linear resampling of longer taps to the shortest sequence
+    (:398-411) on the device against the reference's own probe classes (probes_proj.npz)."""
+    from avex_amd import probes as P
+    from avex_amd import kernels as K
+    g = np.load(f"{golden_dir}/probes_proj.npz")
+    lin = P.LinearProbe(None, [], 37, device="cuda", feature_mode=True, input_dim=[(768,), (768,), (512,)])
+    lin.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("lin.sd.")})
+    out = lin({f"l{i}": torch.from_numpy(g[f"lin.emb{i}"]).cuda() for i in range(3)})
+    assert rel_l2(out.cpu().numpy(), g["lin.logits"]) < 5e-6
+    att = P.AttentionProbe(None, [], 37, device="cuda", feature_mode=True, input_dim=[(24, 128), (24, 128), (31, 96), (40, 128)],
+                           aggregation="none", num_heads=4, attention_dim=128, num_layers=1, dropout_rate=0.0)
+    att.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("att.sd.")})
+    seqs = [torch.from_numpy(g[f"att.seq{i}"]).cuda() for i in range(4)]
+    comb = att._combine(seqs)
+    assert comb.shape == (3, 24, 128) and rel_l2(comb.cpu().numpy(), g["att.combined"]) < 5e-6
+    out = att({f"l{i}": s for i, s in enumerate(seqs)})
+    assert rel_l2(out.cpu().numpy(), g["att.logits"]) < 2e-5
+    # the resampling kernel alone against torch's own interpolate, up- and down-sampling, odd ratios
+    for tin, tout in ((40, 24), (31, 24), (24, 40), (7, 7), (100, 1), (3, 17)):
+        x = torch.from_numpy(synth.normal(f"itp{tin}", (2, tin, 96), 1.0))
+        ref = torch.nn.functional.interpolate(x.transpose(1, 2), size=tout, mode="linear", align_corners=False).transpose(1, 2)
+        got = K.seq_interp_linear(x.cuda(), tout).cpu()
+        # same formula, same float arithmetic; torch.s vectorised CPU kernel may contract w0 * x0 + w1 * x1 into an FMA
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5 and rel_l2(got.numpy(), ref.numpy()) < 2e-6, (tin, tout)

@@ -40,8 +40,23 @@ def test_refusals():
     with pytest.raises(ValueError):
         P.LinearProbe(None, [], 5, device="cpu", feature_mode=True)
     with pytest.raises(NotImplementedError):
-        P.LinearProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=[(32,), (64,)])
-    with pytest.raises(NotImplementedError):
         P.LinearProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=32, freeze_backbone=False)
     with pytest.raises(ValueError):
         P.MLPProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=32, activation="swish")
+
+
+def test_embedding_projectors_match_reference(golden_dir):
+    """Taps of unequal width / length: which taps get an nn.Linear, to what width, under which state_dict keys -- as the reference's
+    own probe classes decided for the same shapes (tests/golden/probes_proj.npz, made by make_probe_goldens.py)."""
+    g = np.load(f"{golden_dir}/probes_proj.npz")
+    lin = P.LinearProbe(None, [], 37, device="cpu", feature_mode=True, input_dim=[(768,), (768,), (512,)])
+    want = {k[7:]: g[k].shape for k in g.files if k.startswith("lin.sd.")}
+    assert {k: tuple(v.shape) for k, v in lin.state_dict().items()} == want
+    assert lin.embedding_projectors[0] is None and lin.embedding_projectors[2].in_features == 512 and lin.inferred_dim == 768
+    att = P.AttentionProbe(None, [], 37, device="cpu", feature_mode=True, input_dim=[(24, 128), (24, 128), (31, 96), (40, 128)],
+                           aggregation="none", num_heads=4, attention_dim=128, num_layers=1, dropout_rate=0.0)
+    want = {k[7:]: g[k].shape for k in g.files if k.startswith("att.sd.")}
+    assert {k: tuple(v.shape) for k, v in att.state_dict().items()} == want
+    # no majority sequence length -> the target is the longest (40), so the two 24-long taps get 128 -> 128 projectors too
+    assert [m is None for m in att.embedding_projectors] == [False, False, False, True]
+    att.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("att.sd.")})
