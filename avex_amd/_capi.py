@@ -76,6 +76,11 @@ SYMBOLS = {
     "avexhip_effnet_stem": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "avexhip_effnet_dwconv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_effnet_se": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "avexhip_resample_plan_create": (_P, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "avexhip_resample_plan_destroy": (None, [_P]),
+    "avexhip_resample_out_length": (C.c_int64, [_P, C.c_int64]),
+    "avexhip_resample_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
+    "avexhip_pcm_to_mono_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
     "avexhip_wavconv0_stats_floats": (C.c_int64, [C.c_int, C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),

@@ -19,6 +19,10 @@ namespace {
 
 struct MelDev {
     int n_fft, hop, n_freq, half, nc, n_out, center, skew, use_mel, kfold, fold;
+    // FFT path (n_fft = 2^a 3^b 5^c <= 2048): mixed-radix Stockham passes in LDS
+    int n_pass, radix[12], fb;       // radices in pass order; frames per workgroup (32, or 16 above 1024 points)
+    const float2* tw;        // [n_fft] exp(-2 pi i k / n_fft)
+    const float* win;        // [n_fft] analysis window, centre-padded to n_fft like torch.stft
     const float* dft;        // [kfold][nc], kfold = n_fft/2 + 1 rounded up to even: the folded contraction (see the kernel)
     const int* mel_start;    // [n_out] CSR over frequency bins (mel) -- unused for plain spectrograms
     const int* mel_len;
@@ -31,6 +35,10 @@ __device__ __forceinline__ int ord_key(float v) {            // monotonic float 
     return b >= 0 ? b : b ^ 0x7fffffff;
 }
 __device__ __forceinline__ float ord_val(int k) { return __builtin_bit_cast(float, k >= 0 ? k : k ^ 0x7fffffff); }
+
+template <int FB>
+__device__ __forceinline__ void melspec_epilogue(const MelDev& md, const float* pw, int pw_ld, int b, int f0, int frames, float* __restrict__ out,
+                                                 int* __restrict__ minmax, int take_log, int tid, int nthreads);
 
 template <int NTW>   // 32-column tiles per wave (HALF = 64 * NTW)
 __global__ __launch_bounds__(256) void melspec_kernel(MelDev md, const float* __restrict__ wav, int64_t T, int64_t stride, int frames,
@@ -103,11 +111,18 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelDev md, const float* __
         }
         __syncthreads();
     }
-    // mel (CSR) or plain bins, log, store [clip][bin][frame]; per-clip min / max
-    const int f = tid & 31, grp = tid >> 5;
+    melspec_epilogue<32>(md, pw, pw_ld, b, f0, frames, out, minmax, take_log, tid, 256);
+}
+
+// mel (CSR) or plain bins, log, store [clip][bin][frame], per-clip min / max -- shared by the dense and the FFT kernel.
+// pw: [FB][pw_ld] power spectra of the block's FB frames in LDS; thread (f = tid % FB, grp = tid / FB) walks bins grp, grp + G, ...
+template <int FB>
+__device__ __forceinline__ void melspec_epilogue(const MelDev& md, const float* pw, int pw_ld, int b, int f0, int frames, float* __restrict__ out,
+                                                 int* __restrict__ minmax, int take_log, int tid, int nthreads) {
+    const int f = tid % FB, grp = tid / FB, G = nthreads / FB;
     float mn = __builtin_inff(), mx = -__builtin_inff();
     const bool fvalid = f0 + f < frames;
-    for (int m = grp; m < md.n_out; m += 8) {
+    for (int m = grp; m < md.n_out; m += G) {
         float e;
         if (md.use_mel) {
             const int st = md.mel_start[m], len = md.mel_len[m], off = md.mel_off[m];
@@ -118,6 +133,155 @@ __global__ __launch_bounds__(256) void melspec_kernel(MelDev md, const float* __
         }
         const float y = take_log ? logf(e + 1e-6f) : e;
         if (fvalid) {
+            out[((int64_t)b * md.n_out + m) * frames + f0 + f] = y;
+            mn = fminf(mn, y); mx = fmaxf(mx, y);
+        }
+    }
+    if (minmax) {
+        mn = -wave_max(-mn); mx = wave_max(mx);
+        if ((tid & 63) == 0 && mx >= mn) { atomicMin(minmax + 2 * b, ord_key(mn)); atomicMax(minmax + 2 * b + 1, ord_key(mx)); }
+    }
+}
+
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 c_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 c_mni(float2 a) { return make_float2(a.y, -a.x); }              // a * (-i)
+__device__ __forceinline__ float2 c_scale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// r-point forward DFTs (exp(-2 pi i / r)), in place
+__device__ __forceinline__ void dft2(float2* v) { const float2 a = v[0], b = v[1]; v[0] = c_add(a, b); v[1] = c_sub(a, b); }
+__device__ __forceinline__ void dft3(float2* v) {
+    const float2 t = c_add(v[1], v[2]);
+    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    const float2 n = c_mni(c_scale(c_sub(v[1], v[2]), 0.86602540378443864676f));           // -i (sqrt3 / 2)(v1 - v2)
+    v[0] = c_add(v[0], t); v[1] = c_add(m, n); v[2] = c_sub(m, n);
+}
+__device__ __forceinline__ void dft4(float2* v) {
+    const float2 a = c_add(v[0], v[2]), b = c_sub(v[0], v[2]), c = c_add(v[1], v[3]), d = c_mni(c_sub(v[1], v[3]));
+    v[0] = c_add(a, c); v[1] = c_add(b, d); v[2] = c_sub(a, c); v[3] = c_sub(b, d);
+}
+__device__ __forceinline__ void dft5(float2* v) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const float2 t1 = c_add(v[1], v[4]), t2 = c_add(v[2], v[3]), t3 = c_sub(v[1], v[4]), t4 = c_sub(v[2], v[3]);
+    const float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    const float2 m2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    const float2 n1 = c_mni(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+    const float2 n2 = c_mni(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+    v[0] = c_add(v[0], c_add(t1, t2));
+    v[1] = c_add(m1, n1); v[4] = c_sub(m1, n1);
+    v[2] = c_add(m2, n2); v[3] = c_sub(m2, n2);
+}
+
+// One Stockham pass of radix R over the wave's N-point sequence: butterfly j reads in[j + t N/R], twists input t by
+// exp(-2 pi i t k / (Ns R)) with k = j mod Ns, transforms, and writes out[(j - k) R + k + t Ns]; after the last pass the
+// sequence is in natural order.
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int N, int Ns, int lane) {
+    const int M = N / R, step = N / (Ns * R);
+    const float inv_ns = 1.0f / (float)Ns;
+    for (int j = lane; j < M; j += 64) {
+        const int k = j - (int)(((float)j + 0.5f) * inv_ns) * Ns;      // j mod Ns (exact: j < 2^11, the quotient is never within 2^-12 of an integer)
+        float2 v[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            v[t] = in[j + t * M];
+            if (t > 0 && Ns > 1) v[t] = c_mul(v[t], tw[t * k * step]);      // t k step < N
+        }
+        if (R == 2) dft2(v); else if (R == 3) dft3(v); else if (R == 4) dft4(v); else dft5(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; ++t) out[j0 + t * Ns] = v[t];
+    }
+}
+
+// STFT power spectra by FFT: every wave transforms frame PAIRS packed as one complex sequence (x_a + i x_b), 4 pairs per wave,
+// FB = 8 * waves frames per workgroup.  A wave finishes its two frames on its own -- power spectra into the idle half of its
+// ping-pong buffer, mel (CSR) / log into a [bin][frame] staging tile -- so the only workgroup-wide step is the final coalesced store
+// of that tile (128-byte rows of [clip][bin][frame]) with the per-clip min / max.  LDS: twiddles 8 N + 16 N per wave + the staging
+// tile (n_out x (FB + 1) floats): 74 KB for the EfficientNet setting (800 points, 128 mels), two workgroups per CU.
+template <int FB>
+__global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float* __restrict__ wav, int64_t T, int64_t stride, int frames,
+                                                          float* __restrict__ out, int* __restrict__ minmax, int take_log) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = FB / 8, SLD = FB + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = md.n_fft, nf = N / 2 + 1;
+    const int b = blockIdx.y, f0 = blockIdx.x * FB;
+    float2* tw = (float2*)smem;                                   // [N]
+    float2* buf = tw + N + (size_t)wave * 2 * N;                  // this wave's ping-pong buffers
+    float* stage = (float*)(tw + N + (size_t)NW * 2 * N);         // [n_out][FB + 1]
+    for (int i = tid; i < N; i += FB * 8) tw[i] = md.tw[i];
+    __syncthreads();
+    const float* src = wav + (int64_t)b * stride;
+    for (int pr = 0; pr < 4; ++pr) {
+        const int fl = wave * 8 + 2 * pr, fa = f0 + fl;           // frames fa, fa + 1 (block-local fl, fl + 1)
+        float2* A = buf;
+        float2* Bf = buf + N;
+        // window, reflect padding (torch.stft center=True), pack
+        const int64_t base = (int64_t)fa * md.hop - (md.center ? N / 2 : 0);
+        for (int n = lane; n < N; n += 64) {
+            float2 z;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int64_t j = base + (int64_t)h * md.hop + n;
+                if (j < 0) j = -j;
+                if (j >= T) j = 2 * (T - 1) - j;
+                if (j < 0) j = 0;
+                const float x = (fa + h < frames && j < T) ? src[j] * md.win[n] : 0.f;
+                if (h == 0) z.x = x; else z.y = x;
+            }
+            A[n] = z;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private buffers: a wave's LDS operations execute in order
+        int Ns = 1;
+        for (int p = 0; p < md.n_pass; ++p) {
+            const int R = md.radix[p];
+            if (R == 5) stockham_pass<5>(A, Bf, tw, N, Ns, lane);
+            else if (R == 4) stockham_pass<4>(A, Bf, tw, N, Ns, lane);
+            else if (R == 3) stockham_pass<3>(A, Bf, tw, N, Ns, lane);
+            else stockham_pass<2>(A, Bf, tw, N, Ns, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float2* t_ = A; A = Bf; Bf = t_;
+            Ns *= R;
+        }
+        // split the two real spectra (conjugate symmetry); their power goes to the idle buffer (2 N floats >= 2 (N/2 + 2))
+        float* pa = (float*)Bf;
+        float* pb = pa + nf + 1;
+        for (int k = lane; k < nf; k += 64) {
+            const float2 zk = A[k], zn = A[k == 0 ? 0 : N - k];
+            const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
+            const float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);
+            pa[k] = ar * ar + ai * ai;
+            pb[k] = br * br + bi * bi;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // mel (CSR) or plain bins, log -> staging tile
+        for (int m = lane; m < md.n_out; m += 64) {
+            float ea, eb;
+            if (md.use_mel) {
+                const int st = md.mel_start[m], len = md.mel_len[m], off = md.mel_off[m];
+                ea = 0.f; eb = 0.f;
+                for (int q = 0; q < len; ++q) {
+                    const float w = md.mel_w[off + q];
+                    ea = __builtin_fmaf(pa[st + q], w, ea);
+                    eb = __builtin_fmaf(pb[st + q], w, eb);
+                }
+            } else {
+                ea = pa[m]; eb = pb[m];
+            }
+            stage[m * SLD + fl] = take_log ? logf(ea + 1e-6f) : ea;
+            stage[m * SLD + fl + 1] = take_log ? logf(eb + 1e-6f) : eb;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // coalesced store [clip][bin][frame] (FB consecutive frames per row) + per-clip min / max
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    const int f = tid % FB, fr_ok = f0 + f < frames;
+    for (int m = tid / FB; m < md.n_out; m += (FB * 8) / FB) {
+        const float y = stage[m * SLD + f];
+        if (fr_ok) {
             out[((int64_t)b * md.n_out + m) * frames + f0 + f] = y;
             mn = fminf(mn, y); mx = fmaxf(mx, y);
         }
@@ -149,19 +313,33 @@ struct avexhip_melspec_plan {
     MelDev dev;
     void* blob = nullptr;
     size_t lds = 0;
+    bool fft = false;        // mixed-radix FFT path (n_fft = 2^a 3^b 5^c <= 2048) instead of the dense fp32-MFMA product
 };
 
 extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melspec_config* cfg, const float* window, const float* mel_fb) {
     if (!cfg || !window) { avexhip_set_error("melspec_plan_create: null argument"); return nullptr; }
     const int N = cfg->n_fft, win = cfg->win_length, hop = cfg->hop_length, nf = N / 2 + 1;
-    if (N < 64 || N > 1024 || (N & 1) || win <= 0 || win > N || hop <= 0 || cfg->n_mels < 0 || cfg->n_mels > 512) {
-        avexhip_set_error("melspec_plan_create: unsupported n_fft=%d win=%d hop=%d n_mels=%d (even n_fft in 64..1024, win <= n_fft)", N, win, hop, cfg->n_mels);
+    if (N < 64 || N > 2048 || (N & 1) || win <= 0 || win > N || hop <= 0 || cfg->n_mels < 0 || cfg->n_mels > 512) {
+        avexhip_set_error("melspec_plan_create: unsupported n_fft=%d win=%d hop=%d n_mels=%d (even n_fft in 64..2048, win <= n_fft)", N, win, hop, cfg->n_mels);
         return nullptr;
     }
     if (cfg->n_mels > 0 && !mel_fb) { avexhip_set_error("melspec_plan_create: mel_fb missing"); return nullptr; }
+    // n_fft = 2^a 3^b 5^c: mixed-radix FFT in LDS (the reference's defaults: 2048 (AudioConfig), 800 (EfficientNet), 512, 1024, 400);
+    // anything else (a factor 7, 11, ...) falls back to the dense fp32-MFMA product, which is built for n_fft <= 1024 only
+    std::vector<int> radices;
+    {
+        int m = N;
+        for (int pr : {5, 3}) while (m % pr == 0) { radices.push_back(pr); m /= pr; }
+        while (m % 4 == 0) { radices.push_back(4); m /= 4; }
+        while (m % 2 == 0) { radices.push_back(2); m /= 2; }
+        if (m != 1 || radices.size() > 12) radices.clear();
+    }
+    const char* force_dense = getenv("AVEX_AMD_MELSPEC_DENSE");
+    const bool use_fft = !radices.empty() && !(force_dense && atoi(force_dense) != 0 && N <= 1024);
     const int half = ((nf + 63) / 64) * 64, nc = 2 * half, ntw = half / 64;
-    if (ntw != 3 && ntw != 4 && ntw != 5 && ntw != 7 && ntw != 9) {
-        avexhip_set_error("melspec_plan_create: n_fft=%d (column tiling %d) is not instantiated (n_fft 256..384, 400..512, 514..640, 770..896, 1026.. are)", N, ntw);
+    if (!use_fft && (N > 1024 || (ntw != 3 && ntw != 4 && ntw != 5 && ntw != 7 && ntw != 9))) {
+        avexhip_set_error("melspec_plan_create: n_fft=%d has a prime factor above 5 and its dense column tiling %d is not instantiated "
+                          "(dense path: n_fft 256..384, 400..512, 514..640, 770..896, 1026..1024)", N, ntw);
         return nullptr;
     }
     std::vector<float> hwin(win), hmel;
@@ -186,8 +364,15 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
     for (int n = 1; n < N / 2; ++n)
         if (fabsf(wat(n) - wat(N - n)) > 1e-6f * fmaxf(1.f, fabsf(wat(n)))) sym = false;
     const int kfold = sym ? (((N / 2 + 1) + 1) & ~1) : N;
-    std::vector<float> dft((size_t)kfold * nc, 0.f);
-    for (int n = 0; n < (sym ? N / 2 + 1 : N); ++n) {
+    std::vector<float> dft(use_fft ? 0 : (size_t)kfold * nc, 0.f);
+    std::vector<float2> twid(use_fft ? N : 0);
+    std::vector<float> wfull(use_fft ? N : 0);
+    for (int k = 0; k < (int)twid.size(); ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)N;
+        twid[k] = make_float2((float)cos(a), (float)sin(a));
+        wfull[k] = wat(k);
+    }
+    for (int n = 0; !use_fft && n < (sym ? N / 2 + 1 : N); ++n) {
         const float w = wat(n);
         for (int k = 0; k < nf; ++k) {
             const long long kn = ((long long)k * n) % N;             // exact argument reduction
@@ -197,9 +382,11 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
         }
     }
     const size_t o_dft = 0, o_st = sizeof(float) * dft.size(), o_ln = o_st + sizeof(int) * n_out, o_of = o_ln + sizeof(int) * n_out,
-                 o_w = o_of + sizeof(int) * n_out, total = o_w + sizeof(float) * (packed.size() + 1);
+                 o_w = o_of + sizeof(int) * n_out, o_tw = (o_w + sizeof(float) * (packed.size() + 1) + 15) & ~(size_t)15,
+                 o_win = o_tw + sizeof(float2) * twid.size(), total = o_win + sizeof(float) * (wfull.size() + 1);
     std::vector<char> host(total, 0);
-    memcpy(host.data() + o_dft, dft.data(), sizeof(float) * dft.size());
+    if (!dft.empty()) memcpy(host.data() + o_dft, dft.data(), sizeof(float) * dft.size());
+    if (!twid.empty()) { memcpy(host.data() + o_tw, twid.data(), sizeof(float2) * twid.size()); memcpy(host.data() + o_win, wfull.data(), sizeof(float) * wfull.size()); }
     memcpy(host.data() + o_st, st.data(), sizeof(int) * n_out);
     memcpy(host.data() + o_ln, ln.data(), sizeof(int) * n_out);
     memcpy(host.data() + o_of, of.data(), sizeof(int) * n_out);
@@ -218,9 +405,15 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
     md.skew = (hop % 2 == 0) ? 1 : 0; md.use_mel = cfg->n_mels > 0 ? 1 : 0; md.kfold = kfold; md.fold = sym ? 1 : 0;
     md.dft = (const float*)(base + o_dft); md.mel_start = (const int*)(base + o_st); md.mel_len = (const int*)(base + o_ln);
     md.mel_off = (const int*)(base + o_of); md.mel_w = (const float*)(base + o_w);
+    p->fft = use_fft;
+    md.n_pass = (int)radices.size();
+    for (int i = 0; i < 12; ++i) md.radix[i] = i < md.n_pass ? radices[i] : 1;
+    md.fb = (sizeof(float2) * ((size_t)N + 4 * 2 * (size_t)N) + sizeof(float) * (size_t)n_out * 33 <= 160 * 1024) ? 32 : 16;
+    md.tw = (const float2*)(base + o_tw); md.win = (const float*)(base + o_win);
     const int nseg = hop * 31 + N;
     const int xs_words = nseg + (md.skew ? nseg / hop + 1 : 0);
-    p->lds = sizeof(float) * (((xs_words + 3) & ~3) + 32 * (size_t)(half + 1));
+    if (use_fft) p->lds = sizeof(float2) * ((size_t)N + (size_t)(md.fb / 8) * 2 * N) + sizeof(float) * (size_t)n_out * (md.fb + 1);
+    else p->lds = sizeof(float) * (((xs_words + 3) & ~3) + 32 * (size_t)(half + 1));
     if (p->lds > 160 * 1024) { avexhip_set_error("melspec_plan_create: hop=%d n_fft=%d need %zu bytes of LDS", hop, N, p->lds); (void)hipFree(d); delete p; return nullptr; }
     return p;
 }
@@ -251,9 +444,27 @@ extern "C" int avexhip_melspec_forward(const avexhip_melspec_plan* p, const floa
     hipStream_t s = (hipStream_t)stream;
     int* mm = p->cfg.normalize ? minmax_dev : nullptr;
     if (mm) hipLaunchKernelGGL(melspec_minmax_init, dim3((B + 255) / 256), dim3(256), 0, s, mm, B);
+    const int take_log = p->cfg.normalize ? 1 : 0;
+    if (p->fft) {
+        const int FB = p->dev.fb;
+        const dim3 gridf((frames + FB - 1) / FB, B);
+        if (FB == 32) {
+            AVX_ENSURE_LDS(stft_fft_kernel<32>, 160 * 1024);
+            hipLaunchKernelGGL(stft_fft_kernel<32>, gridf, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
+        } else {
+            AVX_ENSURE_LDS(stft_fft_kernel<16>, 160 * 1024);
+            hipLaunchKernelGGL(stft_fft_kernel<16>, gridf, dim3(128), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
+        }
+        AVX_LAUNCH_CHECK();
+        if (mm) {
+            const int64_t per_clip = (int64_t)p->dev.n_out * frames;
+            hipLaunchKernelGGL(melspec_norm_kernel, dim3(64, B), dim3(256), 0, s, out_dev, per_clip, mm);
+            AVX_LAUNCH_CHECK();
+        }
+        return AVEXHIP_OK;
+    }
     const dim3 grid((frames + 31) / 32, B);
     const int ntw = p->dev.half / 64;
-    const int take_log = p->cfg.normalize ? 1 : 0;
 #define AVX_MEL_LAUNCH(NTW)                                                                                              \
     do {                                                                                                                 \
         AVX_ENSURE_LDS(melspec_kernel<NTW>, 160 * 1024);                                                                 \

@@ -22,7 +22,7 @@ from ._capi import AvexHipError
 from .base_model import ModelBase
 from .configs import AudioConfig
 from .effnet_encoder import EfficientNetB0Encoder
-from .synth import EFFNET_B0_STAGES
+from .synth import EFFNET_B0_STAGES, EFFNET_STAGES
 
 logger = logging.getLogger(__name__)
 
@@ -57,12 +57,12 @@ class _MBConv(nn.Module):
 class EfficientNetParameters(nn.Module):
     """Parameter tree with torchvision ``EfficientNet``'s names (features / classifier)."""
 
-    def __init__(self, num_outputs: int = 1000) -> None:
+    def __init__(self, num_outputs: int = 1000, stages=EFFNET_B0_STAGES) -> None:
         super().__init__()
-        feats: List[nn.Module] = [_cna(3, EFFNET_B0_STAGES[0][3], 3, 2)]
-        for (er, k, s, cin, cout, n) in EFFNET_B0_STAGES:
+        feats: List[nn.Module] = [_cna(3, stages[0][3], 3, 2)]
+        for (er, k, s, cin, cout, n) in stages:
             feats.append(nn.Sequential(*[_MBConv(er, k, s if j == 0 else 1, cin if j == 0 else cout, cout) for j in range(n)]))
-        feats.append(_cna(EFFNET_B0_STAGES[-1][4], 1280, 1, 1))
+        feats.append(_cna(stages[-1][4], 1280, 1, 1))
         self.features = nn.Sequential(*feats)
         self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(1280, num_outputs))
 
@@ -76,10 +76,10 @@ class Model(ModelBase):
                  audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None, return_features_only: bool = False,
                  efficientnet_variant: str = "b0", operand_dtype: str = "f16") -> None:
         super().__init__(device=device, audio_config=audio_config)
-        if efficientnet_variant != "b0":
-            if efficientnet_variant == "b1":
-                raise NotImplementedError("EfficientNet variant 'b1' is not built in avex_amd (only 'b0')")
+        if efficientnet_variant not in EFFNET_STAGES:                     # efficientnet.py:61-68: b0 and b1
             raise ValueError(f"Unsupported EfficientNet variant: {efficientnet_variant}")
+        self.efficientnet_variant = efficientnet_variant
+        self._stages = EFFNET_STAGES[efficientnet_variant]
         if pretrained:
             raise FileNotFoundError("pretrained=True needs torchvision's IMAGENET1K_V1 weights (efficientnet.py:56), which are not "
                                     "reachable offline; load a local state dict with load_state_dict() / checkpoint_path=")
@@ -90,7 +90,7 @@ class Model(ModelBase):
         self.gradient_checkpointing = False
         self.audio_config = audio_config
         self.operand_dtype = operand_dtype
-        self.model = EfficientNetParameters(1000 if return_features_only else int(num_classes))
+        self.model = EfficientNetParameters(1000 if return_features_only else int(num_classes), self._stages)
         self._encoder: Optional[EfficientNetB0Encoder] = None
         self._weights_dirty = True
         try:
@@ -116,7 +116,7 @@ class Model(ModelBase):
                 raise AvexHipError(f"EfficientNet parameters live on {p.device}; the avex_amd path runs on a GPU only (no CPU fallback)")
             with torch.cuda.device(p.device):
                 state = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items() if k.startswith("model.features.")}
-                self._encoder = EfficientNetB0Encoder(state, operand_dtype=self.operand_dtype)
+                self._encoder = EfficientNetB0Encoder(state, operand_dtype=self.operand_dtype, stages=self._stages)
             self._weights_dirty = False
         return self._encoder
 

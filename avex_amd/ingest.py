@@ -1,0 +1,130 @@
+"""Audio ingest for the embedding path: file -> mono float32 at the model's sample rate, decoded and resampled on the GPU
+(SURVEY.md section 8, row f4).
+
+What the reference does on the host before a clip reaches a model: read the file (``soundfile`` / ``torchaudio.load``), average the
+channels (``noise_wav.mean(dim=0)``, avex/data/augmentations.py:269-271; ``audio_stereo_to_mono(..., "average")``,
+avex/data/birdset_train_splits.py:184-186) and resample when the rate differs (``torchaudio.transforms.Resample(sr, self.sr)``,
+augmentations.py:274-276; ``librosa.resample(..., res_type="kaiser_best")``, birdset_train_splits.py:190-196).  Here the host only
+parses the container: the raw PCM bytes go to the device as they are and ``avexhip_pcm_to_mono_f32`` / ``avexhip_resample_forward``
+do the rest (a 44.1 kHz stereo minute is 10 MB over PCIe instead of 3.8 MB of finished floats, but no host core touches a sample).
+
+Containers: RIFF/WAVE with integer PCM (8 / 16 / 24 / 32 bit) or IEEE float (32 / 64 bit), incl. WAVE_FORMAT_EXTENSIBLE; anything else
+(FLAC, MP3, OGG need a codec library that neither machine has) raises ``ValueError`` -- decode those with the reference's reader and
+hand the array to :func:`to_device_mono`.  The resampler is torchaudio's algorithm (Hann-windowed sinc); librosa's ``kaiser_best``
+filter is a different low-pass design and is NOT reproduced sample for sample (PARITY UNPINNED for both: neither library is
+installed; checker = oracle/ingest_oracle.py).
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import AvexHipError, check, lib
+
+__all__ = ["parse_wav", "Resampler", "to_device_mono", "load_audio"]
+
+
+def parse_wav(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int, int]:
+    """``(raw uint8 samples, sample_rate, channels, sample_format)`` of a RIFF/WAVE file; ``sample_format`` as avexhip_pcm_to_mono_f32
+    takes it (8 / 16 / 24 / 32 integer PCM, 0 float32, 64 float64).  No sample is converted on the host."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file (only PCM / float WAV is decoded here)")
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
+        body = data[pos + 8: pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr, _br, _ba, bits = struct.unpack_from("<HHIIHH", body, 0)
+            if tag == 0xFFFE and len(body) >= 26:                       # WAVE_FORMAT_EXTENSIBLE: the real tag is in the sub-format GUID
+                tag = struct.unpack_from("<H", body, 24)[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            payload = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None:
+        raise ValueError("WAVE file without a fmt or data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 1 and bits in (8, 16, 24, 32):
+        code = bits
+    elif tag == 3 and bits in (32, 64):
+        code = 0 if bits == 32 else 64
+    else:
+        raise ValueError(f"unsupported WAVE encoding (format tag {tag}, {bits} bits)")
+    frame_bytes = ch * bits // 8
+    n = len(payload) // frame_bytes
+    return np.frombuffer(payload, dtype=np.uint8, count=n * frame_bytes), sr, ch, code
+
+
+class Resampler:
+    """``torchaudio.transforms.Resample(orig_freq, new_freq)`` on the device (defaults as torchaudio's: ``sinc_interp_hann``,
+    ``lowpass_filter_width=6``, ``rolloff=0.99``; ``beta`` > 0 selects the Kaiser window, ``sinc_interp_kaiser``)."""
+
+    def __init__(self, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99, beta: float = 0.0) -> None:
+        _capi.require_gpu()
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        self._h = None
+        if self.orig_freq != self.new_freq:
+            self._h = lib().avexhip_resample_plan_create(self.orig_freq, self.new_freq, int(lowpass_filter_width), float(rolloff), float(beta))
+            if not self._h:
+                raise AvexHipError(f"resample_plan_create failed: {_capi.last_error()}")
+
+    def out_length(self, T: int) -> int:
+        return T if self._h is None else int(lib().avexhip_resample_out_length(self._h, T))
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise ValueError("Resampler takes float32 CUDA tensors ([T] or [B, T])")
+        if self._h is None:
+            return x
+        squeeze = x.dim() == 1
+        x2 = (x.unsqueeze(0) if squeeze else x).contiguous()
+        B, T = x2.shape
+        out = torch.empty((B, self.out_length(T)), dtype=torch.float32, device=x.device)
+        check(lib().avexhip_resample_forward(self._h, x2.data_ptr(), B, T, T, out.data_ptr(), out.shape[1], torch.cuda.current_stream().cuda_stream),
+              "resample_forward")
+        return out[0] if squeeze else out
+
+    def __del__(self) -> None:
+        try:
+            if getattr(self, "_h", None):
+                lib().avexhip_resample_plan_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def to_device_mono(raw: Union[np.ndarray, torch.Tensor], channels: int, sample_format: int, device: Optional[torch.device] = None) -> torch.Tensor:
+    """Interleaved samples as the file holds them (uint8 view, or a float32 / int16 / ... array of shape ``[frames, channels]``) -> mono
+    float32 ``[frames]`` on the device, channels averaged."""
+    _capi.require_gpu()
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    t = torch.from_numpy(np.ascontiguousarray(raw)) if isinstance(raw, np.ndarray) else raw
+    buf = t.contiguous().view(torch.uint8).reshape(-1)
+    width = {8: 1, 16: 2, 24: 3, 32: 4, 0: 4, 64: 8}[sample_format]
+    frames = buf.numel() // (width * channels)
+    if frames <= 0:
+        raise ValueError("no audio frames")
+    d = buf.to(dev, non_blocking=True)
+    out = torch.empty((frames,), dtype=torch.float32, device=dev)
+    check(lib().avexhip_pcm_to_mono_f32(d.data_ptr(), sample_format, channels, frames, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "pcm_to_mono_f32")
+    return out
+
+
+_RESAMPLERS: Dict[Tuple[int, int], Resampler] = {}
+
+
+def load_audio(path_or_bytes: Union[str, bytes], target_sr: Optional[int] = 16000, device: Optional[torch.device] = None) -> Tuple[torch.Tensor, int]:
+    """WAV file -> ``(mono float32 [T] on the device, sample_rate)``; resampled to ``target_sr`` when it differs (``None``: keep)."""
+    raw, sr, ch, code = parse_wav(path_or_bytes)
+    x = to_device_mono(raw, ch, code, device)
+    if target_sr is not None and sr != target_sr:
+        key = (sr, int(target_sr))
+        if key not in _RESAMPLERS:
+            _RESAMPLERS[key] = Resampler(sr, int(target_sr))
+        x, sr = _RESAMPLERS[key](x), int(target_sr)
+    return x, sr

@@ -274,6 +274,11 @@ EFFNET_B0_STAGES = [(1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40
                     (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1)]
 
 
+# torchvision efficientnet_b1 = width multiplier 1.0, depth multiplier 1.1: the same channel widths, ceil(1.1 n) layers per stage
+EFFNET_B1_STAGES = [(er, k, st, cin, cout, -(-(11 * n) // 10)) for (er, k, st, cin, cout, n) in EFFNET_B0_STAGES]
+EFFNET_STAGES = {"b0": EFFNET_B0_STAGES, "b1": EFFNET_B1_STAGES}
+
+
 def effnet_b0_state_dict(seed: int = 0, stages=EFFNET_B0_STAGES, head: int = 1280) -> Dict[str, np.ndarray]:
     """Synthetic EfficientNet-B0 ``features`` state dict (fp32 numpy) with torchvision's key names under the wrapper's ``model.``
     prefix (efficientnet.py:57): Conv2dNormActivation = ``.0`` conv (no bias) + ``.1`` BatchNorm2d; MBConv ``block`` =

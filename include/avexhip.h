@@ -92,12 +92,13 @@ int avexhip_fbank_forward_patches(const avexhip_fbank_plan* plan, const float* w
  * Frontend: STFT power spectrogram / mel spectrogram of the reference's AudioProcessor
  * (avex/data/audio_utils.py:77-172): torch.stft(n_fft, hop, win_length, window, center (reflect pad)) -> |.|^2 ->
  * optional MelScale matrix -> optional _normalize: log(x + 1e-6), then per-clip (x - min) / (max - min + 1e-8).
- * The transform is a dense fp32-MFMA product with a precomputed, window-folded DFT matrix, so n_fft need not be a
- * power of two (EfficientNet: 800).  Output [B, n_bins, frames] fp32, n_bins = n_mels or n_fft/2 + 1.
+ * The transform is a mixed-radix (2, 3, 4, 5) Stockham FFT in LDS for n_fft = 2^a 3^b 5^c up to 2048 (the reference's 2048 / 800 /
+ * 512 / 400), two frames packed per complex transform; other even n_fft <= 1024 run as a dense fp32-MFMA product with a
+ * precomputed, window-folded DFT matrix.  Output [B, n_bins, frames] fp32, n_bins = n_mels or n_fft/2 + 1.
  * ------------------------------------------------------------------------------------------ */
 typedef struct avexhip_melspec_plan avexhip_melspec_plan;
 typedef struct {
-    int32_t n_fft;        /* even, 64..1024 */
+    int32_t n_fft;        /* even, 64..2048 (prime factors above 5: <= 1024) */
     int32_t hop_length;
     int32_t win_length;   /* <= n_fft; the window is centre-padded to n_fft like torch.stft */
     int32_t n_mels;       /* 0: power spectrogram */
@@ -128,6 +129,20 @@ int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, int Cp, int k
                           const float* bias_dev, void* out_dev, float* pool_dev, int dtype, void* stream);
 int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, int Cs, const float* w1_dev, const float* b1_dev,
                       const float* w2_dev, const float* b2_dev, float* scale_dev, void* x_dev, int dtype, void* stream);
+
+/* Audio ingest: samples as a PCM file holds them -> mono float32 -> another sample rate, on the device.
+ *   avexhip_pcm_to_mono_f32  interleaved [frames][channels] samples (sample_format 16 / 24 / 32 / 8 = integer PCM widths, 0 = float32,
+ *                            64 = float64) -> [frames] fp32, channels averaged (augmentations.py:269-271, birdset_train_splits.py:184-186)
+ *   avexhip_resample_*       torchaudio.transforms.Resample(orig, new) (augmentations.py:274-276): band-limited sinc interpolation,
+ *                            Hann window (kaiser_beta <= 0) or Kaiser window, lowpass_filter_width 6 and rolloff 0.99 by default;
+ *                            x [B, T] -> out [B, ceil(new * T / orig)] (avexhip_resample_out_length).  Parity unpinned (torchaudio absent). */
+typedef struct avexhip_resample_plan avexhip_resample_plan;
+avexhip_resample_plan* avexhip_resample_plan_create(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff, double kaiser_beta);
+void avexhip_resample_plan_destroy(avexhip_resample_plan* plan);
+int64_t avexhip_resample_out_length(const avexhip_resample_plan* plan, int64_t T);
+int avexhip_resample_forward(const avexhip_resample_plan* plan, const float* x_dev, int B, int64_t T, int64_t x_stride, float* out_dev,
+                             int64_t out_stride, void* stream);
+int avexhip_pcm_to_mono_f32(const void* raw_dev, int sample_format, int channels, int64_t frames, float* out_dev, void* stream);
 
 /* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
  * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):

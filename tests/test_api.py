@@ -307,8 +307,10 @@ def test_efficientnet_class_contract_cpu():
     assert m.register_hooks_for_layers(["last_layer"]) == ["model.features.8.0"] or len(m.register_hooks_for_layers(["last_layer"])) == 1
     m.deregister_all_hooks()
     assert Model(device="cpu", num_classes=7).model.classifier[1].out_features == 7
-    with pytest.raises(NotImplementedError):
-        Model(device="cpu", efficientnet_variant="b1")
+    b1 = Model(device="cpu", efficientnet_variant="b1", return_features_only=True)     # efficientnet.py:64-66: same widths, deeper stages
+    assert [len(st) for st in list(b1.model.features)[1:8]] == [2, 3, 3, 4, 4, 5, 2]
+    assert {k for k in b1.state_dict() if k.startswith("model.features.")} == set(synth.effnet_b0_state_dict(stages=synth.EFFNET_B1_STAGES))
+    assert len(b1.register_hooks_for_layers(["all"])) == 23                             # stem + 21 `block.3.0` projections (stage 1 has no expansion, its projection is block.2.0) + head
     with pytest.raises(ValueError):
         Model(device="cpu", efficientnet_variant="b9")
     with pytest.raises(FileNotFoundError):

@@ -529,7 +529,44 @@ def test_melspec_other_configs_and_processor_mirror(built_lib):
     assert np.abs(out.numpy() - O.audio_processor(x, n_fft=800, hop=160)).max() < 2e-4
     from avex_amd._capi import AvexHipError
     with pytest.raises(AvexHipError):
-        K.MelspecPlan(n_fft=2048, hop_length=512)                     # beyond the built sizes: refuses loudly
+        K.MelspecPlan(n_fft=4096, hop_length=1024)                    # beyond the built sizes: refuses loudly
+    with pytest.raises(AvexHipError):
+        K.MelspecPlan(n_fft=1078, hop_length=256)                     # 2 * 7^2 * 11: no FFT radix, too long for the dense product
+
+
+@pytest.mark.parametrize("n_fft,hop,win,window,center", [(2048, 512, 2048, "hann", True), (2048, 512, 1200, "hamming", True), (1024, 256, 1024, "hann", False),
+                                                          (400, 160, 400, "hann", True), (96, 24, 96, "hann", True), (1500, 300, 1500, "hann", True),
+                                                          (800, 160, 800, "hann", True)])
+def test_stft_fft_path_matches_torch_stft(built_lib, n_fft, hop, win, window, center):
+    """The mixed-radix FFT frontend (n_fft = 2^a 3^b 5^c up to 2048, incl. the AudioConfig default 2048 / hop 512, configs.py:178) against
+    torch.stft itself: plain power spectrogram, then the whole AudioProcessor chain against the oracle."""
+    from avex_amd import kernels as K
+    x = synth.noise_clips(2, 24000, seed=63) * np.float32(2.0)
+    xd = _dev(x)
+    spec = K.MelspecPlan(n_fft=n_fft, hop_length=hop, win_length=win, window=window, mel=False, center=center, normalize=False)(xd).cpu().numpy()
+    wt = torch.hann_window(win) if window == "hann" else torch.hamming_window(win)
+    ts = torch.stft(torch.from_numpy(x), n_fft=n_fft, hop_length=hop, win_length=win, window=wt, center=center, return_complex=True).abs().pow(2).numpy()
+    assert spec.shape == ts.shape
+    assert np.abs(spec - ts).max() <= 3e-5 * ts.max()
+    y = K.MelspecPlan(n_fft=n_fft, hop_length=hop, win_length=win, window=window, n_mels=64, center=center, normalize=True)(xd).cpu().numpy()
+    ref = O.audio_processor(x, n_fft=n_fft, hop=hop, win_length=win, window=window, n_mels=64, center=center)
+    assert y.shape == ref.shape and np.abs(y - ref).max() < 2e-4
+
+
+def test_stft_fft_and_dense_paths_agree(built_lib, monkeypatch):
+    """n_fft 800 both ways: the FFT (default) and the dense fp32-MFMA product (AVEX_AMD_MELSPEC_DENSE=1, the fallback for lengths
+    with prime factors above 5), and a length only the dense path takes (770 = 2 * 5 * 7 * 11)."""
+    from avex_amd import kernels as K
+    x = synth.noise_clips(2, 32000, seed=64)
+    xd = _dev(x)
+    a = K.MelspecPlan(n_fft=800, hop_length=160, mel=False, normalize=False)(xd).cpu().numpy()
+    monkeypatch.setenv("AVEX_AMD_MELSPEC_DENSE", "1")
+    b = K.MelspecPlan(n_fft=800, hop_length=160, mel=False, normalize=False)(xd).cpu().numpy()
+    monkeypatch.delenv("AVEX_AMD_MELSPEC_DENSE")
+    assert np.abs(a - b).max() <= 3e-5 * b.max()
+    c = K.MelspecPlan(n_fft=770, hop_length=160, mel=False, normalize=False)(xd).cpu().numpy()
+    ts = torch.stft(torch.from_numpy(x), n_fft=770, hop_length=160, win_length=770, window=torch.hann_window(770), center=True, return_complex=True).abs().pow(2).numpy()
+    assert np.abs(c - ts).max() <= 3e-5 * ts.max()
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -565,6 +602,23 @@ def test_effnet_blocks_match_oracle(built_lib):
         e = 1.0 / (1.0 + np.exp(-(EO.silu(m @ w1.T + b1) @ w2.T + b2)))
         assert np.allclose(sc[:, :C], e, rtol=2e-4, atol=2e-5) and np.all(sc[:, C:] == 0)
         assert rel_l2(xs.float().cpu().numpy()[..., :C], o[..., :C] * e[:, None, None, :]) < 6e-4
+
+
+def test_effnet_b1_matches_oracle(built_lib):
+    """EfficientNet-B1 (efficientnet.py:64-66: torchvision efficientnet_b1 = B0's widths with ceil(1.1 n) blocks per stage) through
+    the same kernels, against the NumPy restatement."""
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    from oracle import effnet_oracle as EO
+    sd = synth.effnet_b0_state_dict(stages=synth.EFFNET_B1_STAGES)
+    enc = EfficientNetB0Encoder(sd, stages=synth.EFFNET_B1_STAGES)
+    mel = np.abs(synth.normal("emel1", (2, 64, 101), 0.5)).astype(np.float32)
+    ref, taps = EO.effnet_features(mel, sd, synth.EFFNET_B1_STAGES)
+    names = enc.tap_names()
+    assert names == list(taps.keys()) and len(names) == 23
+    r = enc.forward(_dev(mel), hook_layers=[names[0], names[-1]], want_features=True, want_pooled=True)
+    assert r["features"].shape == ref.shape == (2, 1280, 2, 4)
+    assert rel_l2(r["features"].cpu().numpy(), ref) < 2.5e-2
+    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 2.5e-2
 
 
 def test_effnet_b0_matches_oracle(built_lib):

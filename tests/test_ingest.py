@@ -1,0 +1,97 @@
+"""Ingest: WAV container parsing on the host (no GPU), PCM -> mono and the sinc resampler on the device vs the oracle."""
+import io
+import struct
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from avex_amd import ingest, synth
+from oracle import ingest_oracle as IO
+
+
+def _wav_bytes(x: np.ndarray, sr: int, width: int) -> bytes:
+    """int PCM WAV via the standard library (width in bytes); x is [frames, channels] float in [-1, 1)."""
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as w:
+        w.setnchannels(x.shape[1]); w.setsampwidth(width); w.setframerate(sr)
+        if width == 1:
+            w.writeframes((np.clip(x * 128 + 128, 0, 255)).astype(np.uint8).tobytes())
+        elif width == 2:
+            w.writeframes((x * 32767).astype("<i2").tobytes())
+        elif width == 3:
+            v = (x * 8388607).astype(np.int32)
+            w.writeframes(np.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], -1).astype(np.uint8).tobytes())
+        else:
+            w.writeframes((x * 2147483647).astype("<i4").tobytes())
+    return buf.getvalue()
+
+
+def _float_wav_bytes(x: np.ndarray, sr: int, bits: int) -> bytes:
+    data = x.astype("<f4" if bits == 32 else "<f8").tobytes()
+    ch = x.shape[1]
+    fmt = struct.pack("<HHIIHH", 3, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits)
+    return b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data)) + data
+
+
+def test_parse_wav_and_oracle_decoding():
+    x = (synth.normal("wavx", (1000, 2), 0.2)).astype(np.float32).clip(-0.99, 0.99)
+    for width, fmt, tol in ((1, 8, 1e-2), (2, 16, 8e-5), (3, 24, 4e-7), (4, 32, 1e-7)):
+        raw, sr, ch, code = ingest.parse_wav(_wav_bytes(x, 44100, width))
+        assert (sr, ch, code) == (44100, 2, fmt) and raw.dtype == np.uint8 and raw.size == 1000 * 2 * width
+        assert np.abs(IO.pcm_to_mono(raw, ch, code) - x.mean(1)).max() < tol
+    raw, sr, ch, code = ingest.parse_wav(_float_wav_bytes(x, 22050, 32))
+    assert (sr, ch, code) == (22050, 2, 0) and np.allclose(IO.pcm_to_mono(raw, ch, code), x.mean(1), atol=1e-7)
+    raw, sr, ch, code = ingest.parse_wav(_float_wav_bytes(x[:, :1], 8000, 64))
+    assert (sr, ch, code) == (8000, 1, 64) and np.allclose(IO.pcm_to_mono(raw, ch, code), x[:, 0], atol=1e-7)
+    with pytest.raises(ValueError):
+        ingest.parse_wav(b"fLaC" + b"\\0" * 64)
+
+
+def test_oracle_resampler_properties():
+    """The restated sinc resampler: output length ceil(new T / orig), a tone below both Nyquists keeps frequency and amplitude, DC stays DC
+    (away from the edges), identity for equal rates."""
+    sr, new = 44100, 16000
+    t = np.arange(44100) / sr
+    y = IO.resample(np.sin(2 * np.pi * 1000 * t).astype(np.float32), sr, new)
+    assert y.shape == (16000,)
+    tn = np.arange(16000) / new
+    assert np.abs(y[200:-200] - np.sin(2 * np.pi * 1000 * tn)[200:-200]).max() < 2e-3
+    dc = IO.resample(np.ones(8000, np.float32), 48000, 16000)
+    assert dc.shape == (2667,) and np.abs(dc[50:-50] - 1.0).max() < 2e-3
+    x = synth.normal("rsx", (3, 500), 1.0)
+    assert np.array_equal(IO.resample(x, 16000, 16000), x)
+    assert IO.resample(x, 8000, 16000).shape == (3, 1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orig,new", [(44100, 16000), (48000, 16000), (22050, 16000), (8000, 16000), (32000, 16000), (16000, 22050)])
+def test_device_resampler_matches_oracle(built_lib, orig, new):
+    x = synth.normal(f"rs{orig}", (3, 30011), 0.3)
+    ref = IO.resample(x, orig, new)
+    rs = ingest.Resampler(orig, new)
+    y = rs(torch.from_numpy(x).cuda())
+    assert y.shape == ref.shape == (3, rs.out_length(30011))
+    assert np.abs(y.cpu().numpy() - ref).max() < 2e-6
+    y1 = rs(torch.from_numpy(x[1]).cuda())
+    assert torch.equal(y1, y[1])
+    yk = ingest.Resampler(orig, new, lowpass_filter_width=16, rolloff=0.945, beta=14.77)(torch.from_numpy(x).cuda())      # torchaudio's "kaiser_best"-like settings
+    assert np.abs(yk.cpu().numpy() - IO.resample(x, orig, new, 16, 0.945, 14.77)).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_load_audio_end_to_end(built_lib, tmp_path):
+    """A 44.1 kHz stereo 24-bit file -> mono 16 kHz on the device, then through the BEATs frontend like any clip."""
+    x = (synth.normal("wavfile", (44100, 2), 0.2)).astype(np.float32).clip(-0.99, 0.99)
+    path = tmp_path / "clip.wav"
+    path.write_bytes(_wav_bytes(x, 44100, 3))
+    wav, sr = ingest.load_audio(str(path), 16000)
+    raw, _, ch, code = ingest.parse_wav(str(path))
+    ref = IO.resample(IO.pcm_to_mono(raw, ch, code), 44100, 16000)
+    assert sr == 16000 and wav.shape == (16000,) and np.abs(wav.cpu().numpy() - ref).max() < 2e-6
+    same, sr2 = ingest.load_audio(_wav_bytes(x[:, :1], 16000, 2), 16000)
+    assert sr2 == 16000 and np.abs(same.cpu().numpy() - (x[:, 0] * 32767).astype(np.int16) / 32768.0).max() < 1e-7
+    from avex_amd import kernels as K
+    fb = K.FbankPlan()(wav.unsqueeze(0))
+    assert fb.shape == (1, 98, 128) and torch.isfinite(fb).all()
