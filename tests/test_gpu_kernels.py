@@ -488,6 +488,33 @@ def test_aves_encoder_matches_oracle(built_lib, samples):
         assert rel_l2(r["hooks"][i].cpu().numpy().mean(1), taps[name].mean(1)) < 3e-3
 
 
+def test_aves_full_depth_and_long_clip(built_lib):
+    """All 12 transformer layers (the configuration the reference builds, aves_model.py:19-47) on 2 s clips, and a 12 s clip (599 frames:
+    past the single-block attention limit) with 2 layers, vs the NumPy restatement."""
+    from avex_amd.aves_encoder import AvesEncoder
+    from oracle import aves_oracle as AO
+    cfg = synth.AVES_BASE_CFG
+    sd = synth.aves_state_dict(cfg)
+    enc = AvesEncoder(cfg, sd)
+    x = synth.noise_clips(2, 32000, seed=44)
+    ref, taps = AO.aves_forward(x, sd, cfg)
+    r = enc.forward(_dev(x), hook_layers=[0, 5, 11], want_features=True, want_pooled=True)
+    assert r["features"].shape == ref.shape == (2, 99, 768)
+    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean(1)) < 2e-3
+    assert rel_l2(r["features"].cpu().numpy(), ref) < 8e-3
+    for i in (0, 5, 11):
+        name = f"model.encoder.transformer.layers.{i}.feed_forward.output_dense"
+        assert rel_l2(r["hooks"][i].cpu().numpy().mean(1), taps[name].mean(1)) < 3e-3
+    cfg2 = dict(cfg, encoder_num_layers=2)
+    sd2 = synth.aves_state_dict(cfg2)
+    enc2 = AvesEncoder(cfg2, sd2)
+    xl = synth.noise_clips(1, 192000, seed=45)
+    refl, _ = AO.aves_forward(xl, sd2, cfg2)
+    rl = enc2.forward(_dev(xl), want_features=True, want_pooled=True)
+    assert rl["features"].shape == refl.shape == (1, 599, 768)
+    assert rel_l2(rl["pooled"].cpu().numpy(), refl.mean(1)) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # Spectrogram / mel frontend of the reference's AudioProcessor (SURVEY.md section 8 a16)
 # ------------------------------------------------------------------------------------------------------------------------
@@ -617,8 +644,8 @@ def test_effnet_b1_matches_oracle(built_lib):
     assert names == list(taps.keys()) and len(names) == 23
     r = enc.forward(_dev(mel), hook_layers=[names[0], names[-1]], want_features=True, want_pooled=True)
     assert r["features"].shape == ref.shape == (2, 1280, 2, 4)
-    assert rel_l2(r["features"].cpu().numpy(), ref) < 2.5e-2
-    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 2.5e-2
+    assert rel_l2(r["features"].cpu().numpy(), ref) < 1.5e-3
+    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 1e-3
 
 
 def test_effnet_b0_matches_oracle(built_lib):
@@ -633,8 +660,13 @@ def test_effnet_b0_matches_oracle(built_lib):
     assert names == list(taps.keys()) and len(names) == 17
     r = enc.forward(_dev(mel), hook_layers=[names[0], names[3], names[-1]], want_features=True, want_pooled=True)
     assert r["features"].shape == ref.shape == (2, 1280, 2, 4)
-    assert rel_l2(r["features"].cpu().numpy(), ref) < 2e-2                      # 50 layers of f16 operands / activations
-    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 2e-2
+    # measured (scripts/effnet_tap_errors.py, f16): every tap 4e-4 .. 6e-4, features 3.5e-4, pooled 2.2e-4 -- the rounding of one layer's
+    # operands; eval-mode BatchNorm renormalises every layer, so nothing accumulates over the ~50 layers (bf16: 4e-3 / 2.8e-3 / 1.8e-3)
+    assert rel_l2(r["features"].cpu().numpy(), ref) < 1.2e-3
+    assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 8e-4
     assert rel_l2(r["hooks"][names[0]].cpu().numpy(), taps[names[0]]) < 2e-5     # stem tap: fp32
-    assert rel_l2(r["hooks"][names[3]].cpu().numpy(), taps[names[3]]) < 1e-2
-    assert rel_l2(r["hooks"][names[-1]].cpu().numpy(), taps[names[-1]]) < 2e-2
+    assert rel_l2(r["hooks"][names[3]].cpu().numpy(), taps[names[3]]) < 1.5e-3
+    assert rel_l2(r["hooks"][names[-1]].cpu().numpy(), taps[names[-1]]) < 1.5e-3
+    allr = enc.forward(_dev(mel), hook_layers=names, want_features=False)
+    for n in names[1:]:
+        assert rel_l2(allr["hooks"][n].cpu().numpy(), taps[n]) < 1.5e-3, n
