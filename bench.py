@@ -242,20 +242,25 @@ def main():
         stages = {n: {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 and fl > 0 else None} for n, ms, fl in prof}
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
         traffic = None     # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and B == 256 and args.dtype == "f16":
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_traffic.json")))      # the latest round's PMC summary
+        traffic_src = None
+        if tfiles and B == 256 and args.dtype == "f16":
             try:
-                traffic = round(json.load(open(tpath))[kernel_name]["hbm_bytes_per_launch"])
+                traffic = round(json.load(open(tfiles[-1]))[kernel_name]["hbm_bytes_per_launch"])
+                traffic_src = "profiles/" + os.path.basename(tfiles[-1])
             except Exception:  # noqa: BLE001
                 traffic = None
         roof = {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_tflop_per_launch": round(gemm_fl / n_gemm_launch / 1e12, 4),
                 "launches_per_step": n_gemm_launch, "avg_launch_ms": round(gemm_ms / n_gemm_launch, 4),
                 "gemm_share_of_step": round(gemm_ms / total_ms, 3),
                 "note": "peak is the 2.4 GHz dense MFMA figure; this kernel (and the step as a whole) runs at the board's 1400 W power cap, "
                         "shader clock 1.5-1.9 GHz on random operands (profiles/r01c_gemm_power.txt, profiles/r01e_step_power.txt); a register-only MFMA loop "
-                        "on random halves sustains 1.8 PFLOP/s under that cap, 1.4 with this kernel's LDS traffic (profiles/r01h_mfma_power.txt)"}
+                        "on random halves sustains 1.8 PFLOP/s under that cap, 1.4 with this kernel's LDS traffic (profiles/r01h_mfma_power.txt); "
+                        "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE doubled, "
+                        "the gfx950 correction), algorithmic bytes per launch 0.88 GB"}
 
     if rank == 0:
         clips = world * B * args.steps
