@@ -314,7 +314,7 @@ static __device__ __forceinline__ void a2_dma16(const void* src, const char* lds
 }
 
 template <typename T, bool LONG>
-__global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block,
+__global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block, int nqb_main,
                                                         const float* __restrict__ bias_tab,
                                                         const float* __restrict__ grep_w,
                                                         const float* __restrict__ grep_b,
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     const int64_t ld = 3 * (int64_t)E;
     const float NEG_INF = -__builtin_inff();
     const int nh = LONG ? (Tn + 255) >> 8 : (Tn > 256 ? 2 : 1);      // key blocks of 256 per query block
-    const int nqb = LONG ? (Tn + 511) >> 9 : 1;                      // query blocks of 512 per item
+    const int nqb = LONG ? nqb_main : 1;                             // query blocks of 512 per item (a short last block may be left to the tail kernel)
     const int np = (it1 - it0) * nqb * nh;
     const int nkt = (Tn + 31) >> 5;
     const int hh = lane >> 5, r32 = lane & 31;
@@ -770,6 +770,76 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     }
 }
 
+// The last few query rows of a long clip (T = 512 n + r, r <= 32: EAT's 513 tokens, a 10.4 s BEATs clip): a whole query block of
+// the streamed kernel for them would cost as much as 512 rows.  One wave per (clip, head, row) instead: scores over all keys with
+// the lanes on the keys (K rows from L2), softmax through LDS, then the lanes on the 64 output dimensions.  Same arithmetic as the
+// main kernel (base-2 softmax, gate * bias, key mask), fp32 throughout except the operands and the stored output.
+template <typename T>
+__global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict__ qkv, int Tn, int H, int T0, int R, const float* __restrict__ bias_tab,
+                                                            const float* __restrict__ grep_w, const float* __restrict__ grep_b, const float* __restrict__ grep_a,
+                                                            const uint8_t* __restrict__ key_pad, T* __restrict__ out) {
+    extern __shared__ float sc[];                            // [Tn] scores, then probabilities; + 64 floats of q
+    float* qs = sc + Tn;
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x % R, h = (blockIdx.x / R) % H, b = blockIdx.x / (R * H);
+    const int i = T0 + r;
+    const int E = H * 64;
+    const int64_t ld = 3 * (int64_t)E;
+    const T* base = qkv + (int64_t)b * Tn * ld + h * 64;
+    const float NEG_INF = -__builtin_inff();
+    const float qv = (float)base[(int64_t)i * ld + lane];
+    qs[lane] = qv;
+    float gate = 1.f;
+    if (grep_w) {
+        const float wa = (grep_w[0 * 64 + lane] + grep_w[1 * 64 + lane]) + (grep_w[2 * 64 + lane] + grep_w[3 * 64 + lane]);
+        const float wb = (grep_w[4 * 64 + lane] + grep_w[5 * 64 + lane]) + (grep_w[6 * 64 + lane] + grep_w[7 * 64 + lane]);
+        const float sa = wave_sum(qv * wa) + ((grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]));
+        const float sb = wave_sum(qv * wb) + ((grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]));
+        const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
+        gate = ga * (gb * grep_a[h] - 1.f) + 2.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float cs = 0.125f * 1.4426950408889634f;
+    float mx = NEG_INF;
+    for (int j = lane; j < Tn; j += 64) {
+        typedef typename Half<T>::v8 v8;
+        const T* krow = base + (int64_t)j * ld + E;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v8 kv = *(const v8*)(krow + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)kv[e], qs[8 * c + e], d);
+        }
+        float sv = d * cs;
+        if (bias_tab) sv = __builtin_fmaf(gate, bias_tab[(int64_t)h * (2 * Tn - 1) + (j - i) + (Tn - 1)] * 1.4426950408889634f, sv);
+        if (key_pad && key_pad[(int64_t)b * Tn + j]) sv = NEG_INF;
+        sc[j] = sv;
+        mx = fmaxf(mx, sv);
+    }
+    mx = wave_max(mx);
+    if (mx == NEG_INF) mx = 0.f;                             // every key masked: all probabilities 0 (the division below gives NaN like the reference)
+    float l = 0.f;
+    for (int j = lane; j < Tn; j += 64) {
+        const float pj = __builtin_amdgcn_exp2f(sc[j] - mx);
+        sc[j] = (float)(T)pj;                                 // the numerator uses P rounded to the operand type, the row sum does not -- as in the main kernel
+        l += pj;
+    }
+    l = wave_sum(l);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const T* vcol = base + 2 * E + lane;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    int j = 0;
+    for (; j + 4 <= Tn; j += 4) {
+        o0 = __builtin_fmaf(sc[j], (float)vcol[(int64_t)j * ld], o0);
+        o1 = __builtin_fmaf(sc[j + 1], (float)vcol[(int64_t)(j + 1) * ld], o1);
+        o2 = __builtin_fmaf(sc[j + 2], (float)vcol[(int64_t)(j + 2) * ld], o2);
+        o3 = __builtin_fmaf(sc[j + 3], (float)vcol[(int64_t)(j + 3) * ld], o3);
+    }
+    for (; j < Tn; ++j) o0 = __builtin_fmaf(sc[j], (float)vcol[(int64_t)j * ld], o0);
+    out[((int64_t)b * Tn + i) * E + h * 64 + lane] = Half<T>::from(((o0 + o1) + (o2 + o3)) / l);
+}
+
 template <typename T>
 int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const float* grep_w, const float* grep_b,
            const float* grep_a, const uint8_t* key_pad, void* out, hipStream_t s) {
@@ -787,12 +857,25 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several items per workgroup
         const int per_block = (n_items + n_wg - 1) / n_wg;
         const int grid = (n_items + per_block - 1) / per_block;
-        if (Tn > TMAX)
-            hipLaunchKernelGGL((attention2_kernel<T, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab,
+        if (Tn > TMAX) {
+            // a last query block of at most 32 rows goes to the tail kernel (one wave per row) instead of a whole 512-row block
+            const int rem = Tn % 512;
+            const bool use_tail = rem > 0 && rem <= 32 && !getenv("AVEX_AMD_ATT_NO_TAIL");
+            const int nqb_main = use_tail ? Tn / 512 : (Tn + 511) / 512;
+            hipLaunchKernelGGL((attention2_kernel<T, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
                                grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
-        else
-            hipLaunchKernelGGL((attention2_kernel<T, false>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab,
+            AVX_LAUNCH_CHECK();
+            if (use_tail) {
+                AVX_REQUIRE((int64_t)B * H * rem < (1ll << 31), "attention: too many tail rows");
+                const size_t lds = sizeof(float) * ((size_t)Tn + 64);
+                AVX_ENSURE_LDS(attention_tail_kernel<T>, 160 * 1024);
+                hipLaunchKernelGGL(attention_tail_kernel<T>, dim3(B * H * rem), dim3(64), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b,
+                                   grep_a, key_pad, (T*)out);
+            }
+        } else {
+            hipLaunchKernelGGL((attention2_kernel<T, false>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, 1, bias_tab,
                                grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+        }
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }

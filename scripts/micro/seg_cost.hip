@@ -61,9 +61,46 @@ __global__ __launch_bounds__(512) void seg_kernel(int mode, int iters, unsigned 
     if (r == 1234.5f) sink[0] = r;
     if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
+// 16 waves (4 per SIMD), every wave: matrix segment then vector segment, free running
+__global__ __launch_bounds__(1024) void seg16_kernel(int iters, int nm, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[2];
+    for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    h8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.01f * (lane + e)); b[e] = (_Float16)(0.02f * (lane - e)); }
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = -0.01f * (float)(lane + i);
+    f32x2 sum = {0.f, 0.f};
+    unsigned pk[8];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);      // 8 MFMAs: one query tile
+        const f32x2 g = {1.0001f, 1.0001f}, m = {-0.001f, -0.001f};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {                                                                              // 16 exps etc.: one query tile
+            f32x2 p = {__builtin_amdgcn_exp2f(x[i]), __builtin_amdgcn_exp2f(x[i + 1])};
+            sum += p;
+            h2 h = {(_Float16)p[0], (_Float16)p[1]};
+            pk[i >> 1] = __builtin_bit_cast(unsigned, h);
+            const f32x2 nx = __builtin_elementwise_fma(g, (f32x2){x[i], x[i + 1]}, m);
+            x[i] = nx[0]; x[i + 1] = nx[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(pk[i]));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = sum[0] + sum[1] + acc[0][0] + acc[1][5];
+    for (int i = 0; i < 16; ++i) r += x[i];
+    if (r == 1234.5f) sink[0] = r;
+    if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
 int main() {
     unsigned long long* cyc; float* sink;
-    CK(hipMalloc(&cyc, 64)); CK(hipMalloc(&sink, 64));
+    CK(hipMalloc(&cyc, 256)); CK(hipMalloc(&sink, 64));
     const int iters = 2000;
     struct { int mode; const char* name; } cases[] = {
         {1, "matrix segment alone (waves 0-3)"}, {2, "vector segment alone (waves 4-7)"}, {3, "matrix (0-3) beside vector (4-7)"},
@@ -79,5 +116,11 @@ int main() {
         CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
         printf("%-46s: cycles per iteration  wave0 %.0f  wave4 %.0f\n", c.name, (double)h[0] / iters, (double)h[4] / iters);
     }
+    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(seg16_kernel, dim3(256), dim3(1024), 0, 0, iters, 0, cyc, sink); CK(hipDeviceSynchronize()); }
+    unsigned long long h16[16];
+    CK(hipMemcpy(h16, cyc, 128, hipMemcpyDeviceToHost));
+    printf("16 waves (4 per SIMD), each: 8 MFMAs then half the vector segment (one query tile): cycles per iteration wave0 %.0f wave4 %.0f wave8 %.0f wave12 %.0f\n",
+           (double)h16[0] / iters, (double)h16[4] / iters, (double)h16[8] / iters, (double)h16[12] / iters);
+    printf("   (the same work per SIMD as 'each wave: matrix then vector (both groups)' above: 32 MFMAs + 160 vector instructions per iteration)\n");
     return 0;
 }

@@ -336,7 +336,7 @@ def test_attention_large_logits(built_lib, variant, monkeypatch):
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("T,grid", [(513, 0), (600, 7), (1000, 5), (1537, 3)])
+@pytest.mark.parametrize("T,grid", [(513, 0), (600, 7), (1000, 5), (1537, 3), (520, 0), (544, 4), (545, 0)])
 def test_attention_long_clips(built_lib, T, grid, monkeypatch):
     """More than 512 tokens (the reference has no length limit, backbone.py:151-221; EAT has 513): queries in blocks of 512,
     keys in blocks of 256, a bias-row window and a key mask per (query block, key block) phase.  Gate, key padding (a masked
@@ -361,6 +361,14 @@ def test_attention_long_clips(built_lib, T, grid, monkeypatch):
     out = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None)
     ref = _attention_ref(qkv, B, T, H, None, None, None, None)
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+    if 0 < T % 512 <= 32:
+        # a last query block of at most 32 rows runs in the one-wave-per-row tail kernel: same rows through the streamed kernel instead
+        monkeypatch.setenv("AVEX_AMD_ATT_NO_TAIL", "1")
+        out2 = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None)
+        monkeypatch.delenv("AVEX_AMD_ATT_NO_TAIL")
+        o1, o2 = out.float().cpu().numpy().reshape(B, T, E), out2.float().cpu().numpy().reshape(B, T, E)
+        assert np.array_equal(o1[:, :T - T % 512], o2[:, :T - T % 512])                 # the main blocks are untouched by the split
+        assert rel_l2(o1[:, T - T % 512:], o2[:, T - T % 512:]) < 1.5e-3
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
