@@ -13,7 +13,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 // mode bit 0: waves 0-3 run the matrix segment; bit 1: waves 4-7 run the vector segment; bit 2: waves 4-7 run the matrix segment too;
 // bit 3: waves 0-3 run the vector segment too (same-type pairs)
-template <bool AGPR>
+template <bool AGPR, int MF = 0>
 __global__ __launch_bounds__(512) void seg_kernel(int mode, int iters, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool grp1 = wave >= 4;
@@ -30,7 +30,18 @@ __global__ __launch_bounds__(512) void seg_kernel(int mode, int iters, unsigned 
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
-        if (do_m) {
+        if (do_m && MF == 1) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            static_assert(sizeof(f4v) == 16, "");
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f4v* q = (f4v*)&acc[i];
+                    q[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q[0], 0, 0, 0);
+                    q[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q[1], 0, 0, 0);
+                }
+        } else if (do_m) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -112,6 +123,13 @@ int main() {
             else hipLaunchKernelGGL(seg_kernel<false>, dim3(256), dim3(512), 0, 0, c.mode, iters, cyc, sink);
             CK(hipDeviceSynchronize());
         }
+        unsigned long long h[8];
+        CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+        printf("%-46s: cycles per iteration  wave0 %.0f  wave4 %.0f\n", c.name, (double)h[0] / iters, (double)h[4] / iters);
+    }
+    struct { int mode; const char* name; } c2[] = {{1, "16x16x32: matrix segment alone (32 MFMAs)"}, {3, "16x16x32: matrix (0-3) beside vector (4-7)"}, {15, "16x16x32: each wave matrix then vector"}};
+    for (auto& c : c2) {
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((seg_kernel<false, 1>), dim3(256), dim3(512), 0, 0, c.mode, iters, cyc, sink); CK(hipDeviceSynchronize()); }
         unsigned long long h[8];
         CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
         printf("%-46s: cycles per iteration  wave0 %.0f  wave4 %.0f\n", c.name, (double)h[0] / iters, (double)h[4] / iters);
