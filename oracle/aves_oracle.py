@@ -15,7 +15,8 @@ wav2vec2 architecture from its documentation as the reference configures it:
                      x = LN(x + out_proj(SDPA(q, k, v)));  x = final_LN(x + output_dense(GELU(intermediate_dense(x))))
   output             the last layer's output, [B, 499, 768] for 10 s at 16 kHz
 
-and is the checker for the GPU path on the same synthetic weights.  Shared building blocks (layer_norm, gelu_erf, linear,
+and is the checker for the GPU path on the same synthetic weights.  Second opinion: tests/test_independent_pins.py compares this
+file with transformers' Wav2Vec2Model (torchaudio's import_huggingface_model key map) on the same weights: < 2e-5 rel-L2 at 12 layers.  Shared building blocks (layer_norm, gelu_erf, linear,
 pos_conv, attention without bias) are the pinned ones of beats_oracle.py.
 """
 from __future__ import annotations

@@ -72,6 +72,46 @@ __global__ __launch_bounds__(512) void seg_kernel(int mode, int iters, unsigned 
     if (r == 1234.5f) sink[0] = r;
     if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
+// every wave: the matrix and the vector segment of one iteration interleaved instruction by instruction (1 MFMA, then NV vector
+// instructions, 16 times) -- what a software-pipelined tile body would issue
+template <int NV>
+__global__ __launch_bounds__(512) void seg_il_kernel(int iters, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    h8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.01f * (lane + e)); b[e] = (_Float16)(0.02f * (lane - e)); }
+    float x[32];
+    for (int i = 0; i < 32; ++i) x[i] = -0.01f * (float)(lane + i);
+    f32x2 sum = {0.f, 0.f};
+    unsigned pk[16];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const f32x2 g = {1.0001f, 1.0001f}, m = {-0.001f, -0.001f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k & 3], 0, 0, 0);
+#pragma unroll
+            for (int i = k * (NV / 5) * 2; i < (k + 1) * (NV / 5) * 2 && i < 32; i += 2) {
+                f32x2 p = {__builtin_amdgcn_exp2f(x[i]), __builtin_amdgcn_exp2f(x[i + 1])};
+                sum += p;
+                h2 h = {(_Float16)p[0], (_Float16)p[1]};
+                pk[i >> 1] = __builtin_bit_cast(unsigned, h);
+                const f32x2 nx = __builtin_elementwise_fma(g, (f32x2){x[i], x[i + 1]}, m);
+                x[i] = nx[0]; x[i + 1] = nx[1];
+                asm volatile("" : "+v"(pk[i >> 1]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = sum[0] + sum[1];
+    for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][5];
+    for (int i = 0; i < 32; ++i) r += x[i];
+    if (r == 1234.5f) sink[0] = r;
+    if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
 // 16 waves (4 per SIMD), every wave: matrix segment then vector segment, free running
 __global__ __launch_bounds__(1024) void seg16_kernel(int iters, int nm, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -133,6 +173,15 @@ int main() {
         unsigned long long h[8];
         CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
         printf("%-46s: cycles per iteration  wave0 %.0f  wave4 %.0f\n", c.name, (double)h[0] / iters, (double)h[4] / iters);
+    }
+    for (int nw = 1; nw <= 2; ++nw) {
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(seg_il_kernel<5>, dim3(256), dim3(256 * nw), 0, 0, iters, cyc, sink); CK(hipDeviceSynchronize()); }
+        unsigned long long h[8];
+        CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+        printf("interleaved 1 MFMA : 5 vector, %d wave(s) per SIMD: cycles per iteration wave0 %.0f wave%d %.0f\n", nw, (double)h[0] / iters, nw == 2 ? 4 : 3, (double)h[nw == 2 ? 4 : 3] / iters);
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(seg_il_kernel<10>, dim3(256), dim3(256 * nw), 0, 0, iters, cyc, sink); CK(hipDeviceSynchronize()); }
+        CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+        printf("interleaved 1 MFMA : 10 vector (8 MFMAs bare), %d wave(s) per SIMD: cycles per iteration wave0 %.0f wave%d %.0f\n", nw, (double)h[0] / iters, nw == 2 ? 4 : 3, (double)h[nw == 2 ? 4 : 3] / iters);
     }
     for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(seg16_kernel, dim3(256), dim3(1024), 0, 0, iters, 0, cyc, sink); CK(hipDeviceSynchronize()); }
     unsigned long long h16[16];
