@@ -300,6 +300,9 @@ __device__ unsigned long long g_att_stamps[64 * 8 * 32 * 8];   // [block < 64][w
 #ifndef ATT_PRIO
 #define ATT_PRIO 1       // 1: waves 4-7 run at s_setprio 1
 #endif
+#ifndef ATT_IL
+#define ATT_IL 1         // 1: the key tile's MFMAs and vector work interleaved instruction by instruction in every wave (below); 0: in segments
+#endif
 #ifndef ATT_STAMPS
 #define ATT_STAMPS 0     // diagnostic build: -DATT_STAMPS=1 prints one tile's cycle stamps (AVEX_AMD_ATT_DEBUG=4)
 #endif                             // deferred-max threshold, log2 units (p <= 256)
@@ -608,6 +611,165 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 #pragma unroll
             for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s]);
             if (ATT_STAGGER > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(ATT_STAGGER);
+#if ATT_IL
+            // A wave issues in order, and an MFMA that finds the matrix pipe busy holds the SIMD's vector issue port until it is
+            // accepted (scripts/micro/seg_cost.hip: a vector wave beside a wave of back-to-back MFMAs runs at an eighth of its rate).
+            // So the overlap of matrix and vector work is made INSIDE each wave: every stage below is one MFMA chain of one query
+            // tile with the other tile's vector work placed between its instructions, and the scheduler is fenced so that it stays
+            // there.  Stage 1: S chain of tile 0.  Stage 2: S chain of tile 1 | exponentials of tile 0.  Stage 3: P V of tile 0 |
+            // exponentials of tile 1.  Stage 4: P V of tile 1 | the next key tile's accumulator start (gate * bias - m) of both.
+            f32x16 Sq[NQ];
+            auto masked_at = [&](int ktl) __attribute__((always_inline)) { return key_pad != nullptr || (half * 8 + ktl) * 32 + 32 > Tn; };
+            auto mask_acc = [&](int u, int ktl) __attribute__((always_inline)) {
+                const int jb = (half * 8 + ktl) * 32 + 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Sq[u][r] += kad[jb + (r & 3) + 8 * (r >> 2)];
+            };
+            auto acc_start = [&](int u, int g4, const f32x4 t4) __attribute__((always_inline)) {
+                const f32x2 g2 = {gate[u], gate[u]}, nm2 = {-m_run[u], -m_run[u]};
+                const f32x2 ea = __builtin_elementwise_fma(g2, (f32x2){t4[0], t4[1]}, nm2);
+                const f32x2 eb = __builtin_elementwise_fma(g2, (f32x2){t4[2], t4[3]}, nm2);
+                Sq[u][4 * g4] = ea[0]; Sq[u][4 * g4 + 1] = ea[1]; Sq[u][4 * g4 + 2] = eb[0]; Sq[u][4 * g4 + 3] = eb[1];
+            };
+#pragma unroll
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) acc_start(u, g4, *(const f32x4*)(tp[u] + 8 * g4));
+            if (masked_at(0)) { mask_acc(0, 0); mask_acc(1, 0); }
+#define AVX_FENCE() __builtin_amdgcn_sched_barrier(0)
+            auto tile = [&](auto KT) __attribute__((always_inline)) {
+                constexpr int ktl = decltype(KT)::value;
+                unsigned long long ts[8];
+#define AVX_TS(i) if (ATT_STAMPS && ktl == 3 && ph == 6) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+                AVX_TS(0)
+                a_i32x2 vt[2][2][2];
+#define AVX_TR(dst, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(OFF))
+                AVX_TR(vt[0][0][0], 1024 * (ktl * 4 + 0) + 0);   AVX_TR(vt[0][0][1], 1024 * (ktl * 4 + 1) + 0);
+                AVX_TR(vt[0][1][0], 1024 * (ktl * 4 + 0) + 512); AVX_TR(vt[0][1][1], 1024 * (ktl * 4 + 1) + 512);
+                AVX_TR(vt[1][0][0], 1024 * (ktl * 4 + 2) + 0);   AVX_TR(vt[1][0][1], 1024 * (ktl * 4 + 3) + 0);
+                AVX_TR(vt[1][1][0], 1024 * (ktl * 4 + 2) + 512); AVX_TR(vt[1][1][1], 1024 * (ktl * 4 + 3) + 512);
+#undef AVX_TR
+                v8 pf[NQ][2];
+                f32x2 ls[NQ];
+                auto exp8 = [&](int u, int r0) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; r += 2) {
+                        const f32x2 pp = {__builtin_amdgcn_exp2f(Sq[u][r]), __builtin_amdgcn_exp2f(Sq[u][r + 1])};
+                        ls[u] += pp;
+                        pf[u][r >> 3][r & 7] = (T)pp[0];
+                        pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
+                    }
+                };
+                // (see the segment form below for the deferred reference: a half-row sum below 2^12 proves the tile's p are f16-safe)
+                auto redo_u = [&](int u) __attribute__((always_inline)) {
+                    float mx = Sq[u][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, Sq[u][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const bool need = ref_set[u] ? mx > A2_THR : mx != NEG_INF;
+                    const float d = need ? mx : 0.f;
+                    const float alpha = (need && ref_set[u]) ? __builtin_amdgcn_exp2f(-d) : 1.f;
+                    ref_set[u] = ref_set[u] || need;
+                    m_run[u] += d;
+                    l_run[u] *= alpha;
+                    ls[u] = (f32x2){0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 pp = {__builtin_amdgcn_exp2f(Sq[u][r] - d), __builtin_amdgcn_exp2f(Sq[u][r + 1] - d)};
+                        ls[u] += pp;
+                        pf[u][r >> 3][r & 7] = (T)pp[0];
+                        pf[u][r >> 3][(r & 7) + 1] = (T)pp[1];
+                    }
+                };
+                // stage 1
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Sq[0] = mfma32(kf[s], qf[0][s], Sq[0]);
+                AVX_FENCE();
+                AVX_TS(1)
+                // stage 2
+                Sq[1] = mfma32(kf[0], qf[1][0], Sq[1]);
+                Sq[1] = mfma32(kf[1], qf[1][1], Sq[1]);
+                AVX_FENCE();
+                ls[0] = (f32x2){0.f, 0.f};
+                exp8(0, 0);
+                AVX_FENCE();
+                Sq[1] = mfma32(kf[2], qf[1][2], Sq[1]);
+                AVX_FENCE();
+                exp8(0, 8);
+                AVX_FENCE();
+                Sq[1] = mfma32(kf[3], qf[1][3], Sq[1]);
+                AVX_FENCE();
+                AVX_TS(2)
+                if (__any(!ref_set[0] || !(hsum2(ls[0]) < 4096.f))) redo_u(0);
+                l_run[0] += hsum2(ls[0]);
+                // the V fragments (issued at the top), then the next tile's K fragment and bias values go out behind them
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                               "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]));
+                v8 vf[2][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int dh = 0; dh < 2; ++dh) {
+                        const v4 lo = __builtin_bit_cast(v4, vt[s2][dh][0]), hi = __builtin_bit_cast(v4, vt[s2][dh][1]);
+                        vf[s2][dh] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                f32x4 t4n[NQ][4];
+                if (ktl + 1 < 8) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) t4n[u][g4] = *(const f32x4*)(tp[u] + (ktl + 1) * 32 + 8 * g4);
+                }
+                AVX_FENCE();
+                AVX_TS(3)
+                // stage 3
+                o0[0] = mfma32(vf[0][0], pf[0][0], o0[0]);
+                o1[0] = mfma32(vf[0][1], pf[0][0], o1[0]);
+                AVX_FENCE();
+                ls[1] = (f32x2){0.f, 0.f};
+                exp8(1, 0);
+                AVX_FENCE();
+                o0[0] = mfma32(vf[1][0], pf[0][1], o0[0]);
+                AVX_FENCE();
+                exp8(1, 8);
+                AVX_FENCE();
+                o1[0] = mfma32(vf[1][1], pf[0][1], o1[0]);
+                AVX_FENCE();
+                AVX_TS(4)
+                if (__any(!ref_set[1] || !(hsum2(ls[1]) < 4096.f))) redo_u(1);
+                l_run[1] += hsum2(ls[1]);
+                AVX_FENCE();
+                AVX_TS(5)
+                // stage 4
+                o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
+                if (ktl + 1 < 8) { acc_start(0, 0, t4n[0][0]); acc_start(0, 1, t4n[0][1]); }
+                AVX_FENCE();
+                o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
+                if (ktl + 1 < 8) { acc_start(0, 2, t4n[0][2]); acc_start(0, 3, t4n[0][3]); }
+                AVX_FENCE();
+                o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
+                if (ktl + 1 < 8) { acc_start(1, 0, t4n[1][0]); acc_start(1, 1, t4n[1][1]); }
+                AVX_FENCE();
+                o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
+                if (ktl + 1 < 8) { acc_start(1, 2, t4n[1][2]); acc_start(1, 3, t4n[1][3]); }
+                AVX_FENCE();
+                AVX_TS(6)
+                if (ktl + 1 < 8 && masked_at(ktl + 1)) { mask_acc(0, ktl + 1); mask_acc(1, ktl + 1); }
+#if ATT_STAMPS
+                if (ktl == 3 && ph == 6 && blockIdx.x < 64 && lane == 0) {
+                    unsigned long long* d = g_att_stamps + (((size_t)blockIdx.x * 8 + wave) * 32 + 31) * 8;
+                    for (int i = 0; i < 7; ++i) d[i] = ts[i];
+                }
+#endif
+#undef AVX_TS
+            };
+#undef AVX_FENCE
+#else
             auto tile = [&](auto KT) __attribute__((always_inline)) {
                 constexpr int ktl = decltype(KT)::value;
                 const int kt = half * 8 + ktl;
@@ -724,6 +886,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                             else o1[u] = mfma32(vf[s2][1], pf[u][s2], o1[u]);
                         }
             };
+#endif
             if (0 < kt_end) tile(a_ic<0>{});
             if (1 < kt_end) tile(a_ic<1>{});
             if (2 < kt_end) tile(a_ic<2>{});

@@ -29,3 +29,11 @@ for half in (0, 1):
     print(f"half {half}: median cycles per wave  " + "  ".join(f"{n}" for n in names))
     for w in range(8):
         print(f"   wave {w}: " + "  ".join(f"{int(med[w, i]):6d}" for i in range(6)))
+
+# one key tile's stage stamps (interleaved tile body: phase 6, key tile 3), slot 31
+t = s[:, :, 31, :7]
+if t[:, :, 0].min() > 0:
+    dt = np.diff(t, axis=2)
+    print("one key tile (phase 6, tile 3), median cycles per stage:  S(q0) | S(q1)+exp(q0) | check, V wait, next K/bias loads | PV(q0)+exp(q1) | check | PV(q1)+next start | total")
+    for w in range(8):
+        print(f"   wave {w}: " + "  ".join(f"{int(np.median(dt[:, w, i])):6d}" for i in range(6)) + f"  {int(np.median(t[:, w, 6] - t[:, w, 0])):6d}")
