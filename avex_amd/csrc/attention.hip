@@ -316,7 +316,7 @@ static __device__ __forceinline__ void a2_dma16(const void* src, const char* lds
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
 }
 
-template <typename T, bool LONG>
+template <typename T, bool LONG, bool BIAS>      // BIAS false: no relative-position table (EAT, wav2vec2): the S accumulators start at -m alone
 __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block, int nqb_main,
                                                         const float* __restrict__ bias_tab,
                                                         const float* __restrict__ grep_w,
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     auto write_window = [&](int ph) __attribute__((always_inline)) {
         float* win = tab + (ph & 1) * (4 * A2_WLD);
         const int r0 = half_ld * 256 - qb_ld * 512 - 511 + (Tn - 1);     // bias-row index of window entry 0
-        for (int r = tid; r < A2_WLD; r += NT) {
+        for (int r = tid; r < A2_WLD && (BIAS || !ATT_IL); r += NT) {   // (the interleaved tile body does not read the window without a table)
             const int g = r0 + r;
             float v = 0.f;
             if (bias_tab && g >= 0 && g < 2 * Tn - 1) v = bias_tab[(int64_t)h_ld * (2 * Tn - 1) + g] * 1.4426950408889634f;
@@ -631,10 +631,18 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 const f32x2 eb = __builtin_elementwise_fma(g2, (f32x2){t4[2], t4[3]}, nm2);
                 Sq[u][4 * g4] = ea[0]; Sq[u][4 * g4 + 1] = ea[1]; Sq[u][4 * g4 + 2] = eb[0]; Sq[u][4 * g4 + 3] = eb[1];
             };
+            // without a bias table (EAT, wav2vec2) the start is -m alone: no table reads, no FMAs (workgroup-uniform branch)
+            constexpr bool has_bias = BIAS || !ATT_IL;
+            auto acc_plain = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < NQ; ++u)
+                for (int r = 0; r < 16; ++r) Sq[u][r] = -m_run[u];
+            };
+            if (has_bias) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) acc_start(u, g4, *(const f32x4*)(tp[u] + 8 * g4));
+                for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) acc_start(u, g4, *(const f32x4*)(tp[u] + 8 * g4));
+            } else { acc_plain(0); acc_plain(1); }
             if (masked_at(0)) { mask_acc(0, 0); mask_acc(1, 0); }
 #define AVX_FENCE() __builtin_amdgcn_sched_barrier(0)
             auto tile = [&](auto KT) __attribute__((always_inline)) {
@@ -720,10 +728,10 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 if (ktl + 1 < 8) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
+                    if (has_bias) {
 #pragma unroll
-                    for (int u = 0; u < NQ; ++u)
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) t4n[u][g4] = *(const f32x4*)(tp[u] + (ktl + 1) * 32 + 8 * g4);
+                        for (int g4 = 0; g4 < 4; ++g4) t4n[0][g4] = *(const f32x4*)(tp[0] + (ktl + 1) * 32 + 8 * g4);
+                    }
                 }
                 AVX_FENCE();
                 AVX_TS(3)
@@ -746,18 +754,33 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 AVX_FENCE();
                 AVX_TS(5)
                 // stage 4
-                o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
-                if (ktl + 1 < 8) { acc_start(0, 0, t4n[0][0]); acc_start(0, 1, t4n[0][1]); }
-                AVX_FENCE();
-                o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
-                if (ktl + 1 < 8) { acc_start(0, 2, t4n[0][2]); acc_start(0, 3, t4n[0][3]); }
-                AVX_FENCE();
-                o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
-                if (ktl + 1 < 8) { acc_start(1, 0, t4n[1][0]); acc_start(1, 1, t4n[1][1]); }
-                AVX_FENCE();
-                o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
-                if (ktl + 1 < 8) { acc_start(1, 2, t4n[1][2]); acc_start(1, 3, t4n[1][3]); }
-                AVX_FENCE();
+                if (has_bias) {
+                    o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
+                    if (ktl + 1 < 8) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) t4n[1][g4] = *(const f32x4*)(tp[1] + (ktl + 1) * 32 + 8 * g4);    // tile 1's values: two MFMAs ahead of their use
+                        acc_start(0, 0, t4n[0][0]); acc_start(0, 1, t4n[0][1]);
+                    }
+                    AVX_FENCE();
+                    o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
+                    if (ktl + 1 < 8) { acc_start(0, 2, t4n[0][2]); acc_start(0, 3, t4n[0][3]); }
+                    AVX_FENCE();
+                    o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
+                    if (ktl + 1 < 8) { acc_start(1, 0, t4n[1][0]); acc_start(1, 1, t4n[1][1]); }
+                    AVX_FENCE();
+                    o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
+                    if (ktl + 1 < 8) { acc_start(1, 2, t4n[1][2]); acc_start(1, 3, t4n[1][3]); }
+                    AVX_FENCE();
+                } else {
+                    o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
+                    o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
+                    if (ktl + 1 < 8) acc_plain(0);
+                    AVX_FENCE();
+                    o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
+                    o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
+                    if (ktl + 1 < 8) acc_plain(1);
+                    AVX_FENCE();
+                }
                 AVX_TS(6)
                 if (ktl + 1 < 8 && masked_at(ktl + 1)) { mask_acc(0, ktl + 1); mask_acc(1, ktl + 1); }
 #if ATT_STAMPS
@@ -1011,8 +1034,6 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
     int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
     if (Tn > TMAX) variant = 2;          // variant 1 keeps a whole head in LDS (T <= 512)
     if (variant == 2) {
-        AVX_ENSURE_LDS((attention2_kernel<T, false>), ATT2_LDS);
-        AVX_ENSURE_LDS((attention2_kernel<T, true>), ATT2L_LDS);
         int n_cu = 256;
         { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
         const int n_items = B * H;
@@ -1025,8 +1046,15 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
             const int rem = Tn % 512;
             const bool use_tail = rem > 0 && rem <= 32 && !getenv("AVEX_AMD_ATT_NO_TAIL");
             const int nqb_main = use_tail ? Tn / 512 : (Tn + 511) / 512;
-            hipLaunchKernelGGL((attention2_kernel<T, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
-                               grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+            if (bias_tab) {
+                AVX_ENSURE_LDS((attention2_kernel<T, true, true>), ATT2L_LDS);
+                hipLaunchKernelGGL((attention2_kernel<T, true, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
+                                   grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+            } else {
+                AVX_ENSURE_LDS((attention2_kernel<T, true, false>), ATT2L_LDS);
+                hipLaunchKernelGGL((attention2_kernel<T, true, false>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
+                                   grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+            }
             AVX_LAUNCH_CHECK();
             if (use_tail) {
                 AVX_REQUIRE((int64_t)B * H * rem < (1ll << 31), "attention: too many tail rows");
@@ -1035,8 +1063,13 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
                 hipLaunchKernelGGL(attention_tail_kernel<T>, dim3(B * H * rem), dim3(64), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b,
                                    grep_a, key_pad, (T*)out);
             }
+        } else if (bias_tab) {
+            AVX_ENSURE_LDS((attention2_kernel<T, false, true>), ATT2_LDS);
+            hipLaunchKernelGGL((attention2_kernel<T, false, true>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, 1, bias_tab,
+                               grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
         } else {
-            hipLaunchKernelGGL((attention2_kernel<T, false>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, 1, bias_tab,
+            AVX_ENSURE_LDS((attention2_kernel<T, false, false>), ATT2_LDS);
+            hipLaunchKernelGGL((attention2_kernel<T, false, false>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, 1, bias_tab,
                                grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
         }
         AVX_LAUNCH_CHECK();
