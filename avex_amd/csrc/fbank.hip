@@ -81,6 +81,11 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     float2 x[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) x[q] = make_float2(0.f, 0.f);
+    // A frame that is exactly zero after DC removal (digital silence, zero padding, a constant) must come out at the log floor
+    // in every bin, as the reference's per-frame FFT gives it.  Packed beside a loud partner its spectrum is the difference of two
+    // large numbers and picks up the partner's rounding noise (-158 dB of the partner: e^-13.5 instead of the floor e^-15.9 next
+    // to a full-scale impulse), so such a frame is flagged here and its power written as 0.
+    bool live[2];
 #pragma unroll
     for (int fr = 0; fr < 2; ++fr) {
         float cur[8], prev[8];
@@ -108,6 +113,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
             }
             if (fr == 0) x[q].x = y; else x[q].y = y;
         }
+        bool nz = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nz = nz || (fr == 0 ? x[q].x : x[q].y) != 0.f;
+        live[fr] = __any(nz);
     }
 
     // ---- 512-point complex FFT: three radix-8 passes ------------------------------------------
@@ -173,8 +182,8 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
             const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
             const float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);
             const float ma = sqrtf(ar * ar + ai * ai), mb = sqrtf(br * br + bi * bi);
-            pw[wave][0][k] = ma * ma;
-            pw[wave][1][k] = mb * mb;
+            pw[wave][0][k] = live[0] ? ma * ma : 0.f;
+            pw[wave][1][k] = live[1] ? mb * mb : 0.f;
         }
     }
     AVX_WAVE_SYNC();

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         float2* Bf = buf + N;
         // window, reflect padding (torch.stft center=True), pack
         const int64_t base = (int64_t)fa * md.hop - (md.center ? N / 2 : 0);
+        bool nza = false, nzb = false;                            // an all-zero frame beside a loud partner: see fbank.hip
         for (int n = lane; n < N; n += 64) {
             float2 z;
 #pragma unroll
@@ -232,7 +233,10 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
                 if (h == 0) z.x = x; else z.y = x;
             }
             A[n] = z;
+            nza = nza || z.x != 0.f;
+            nzb = nzb || z.y != 0.f;
         }
+        const bool live_a = __any(nza), live_b = __any(nzb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private buffers: a wave's LDS operations execute in order
         int Ns = 1;
         for (int p = 0; p < md.n_pass; ++p) {
@@ -252,8 +256,8 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
             const float2 zk = A[k], zn = A[k == 0 ? 0 : N - k];
             const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
             const float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);
-            pa[k] = ar * ar + ai * ai;
-            pb[k] = br * br + bi * bi;
+            pa[k] = live_a ? ar * ar + ai * ai : 0.f;
+            pb[k] = live_b ? br * br + bi * bi : 0.f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // mel (CSR) or plain bins, log -> staging tile

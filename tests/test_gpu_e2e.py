@@ -99,6 +99,29 @@ def test_oracle_agrees_on_fresh_input(encoder, base_sd):
     assert rel_l2(r["hooks"][5].cpu().numpy().mean(1), taps["backbone.encoder.layers.4.fc2"].mean(1)) < tol
 
 
+def test_degenerate_signals(encoder, base_sd):
+    """Signals at the ends of the frontend's range, GPU path vs the CPU oracle: digital silence (every mel bin at the log floor,
+    every LayerNorm row of the patch embedding constant), a DC offset (removed per frame), one impulse, a full-scale square wave,
+    white noise at the reference tests' own amplitude (std 1, i.e. 8x beyond full scale: tests/unittests/test_batched_fbank.py:62-64)
+    and a clip that is silent in its second half.  Nothing may overflow the 16-bit operands or turn into NaN."""
+    n = 32000
+    rng = np.random.default_rng(17)
+    x = np.zeros((6, n), np.float32)
+    x[1] = 0.25
+    x[2, 12345] = 1.0
+    x[3] = np.where((np.arange(n) // 40) % 2 == 0, 1.0, -1.0)
+    x[4] = rng.standard_normal(n).astype(np.float32)
+    x[5, :n // 2] = 0.1 * rng.standard_normal(n // 2).astype(np.float32)
+    f, _ = O.beats_forward(x, base_sd, synth.BEATS_BASE_CFG)
+    r = encoder.forward(torch.from_numpy(x).cuda(), want_features=True, want_pooled=True)
+    got = r["pooled"].cpu().numpy()
+    assert np.isfinite(got).all() and np.isfinite(r["features"].cpu().numpy()).all()
+    want = O.pooled(f)
+    tol = POOLED_TOL[encoder.dtype_name]
+    for i in range(x.shape[0]):
+        assert rel_l2(got[i:i + 1], want[i:i + 1]) < tol, (i, rel_l2(got[i:i + 1], want[i:i + 1]))
+
+
 def test_edge_sizes(encoder, base_sd):
     """Smallest and unusual inputs the path takes, and the ones it refuses loudly: 16 frames -> 8 tokens, 1024 frames -> 512
     tokens (the last size of the single-block attention path), one token row more (520 tokens: two query blocks, three key

@@ -453,6 +453,40 @@ def test_fbank_edge_lengths(built_lib):
             assert max_abs(y.cpu().numpy(), ref) < 1e-3
 
 
+def test_fbank_silent_frame_beside_a_loud_one(built_lib):
+    """Two frames share one complex FFT; an all-zero frame packed beside a full-scale impulse must still come out at the log
+    floor in every bin (the reference transforms every frame alone: beats.py:154), not at the partner's rounding noise.  Also a
+    clip whose second half is zero padding, and a constant (zero after the per-frame DC removal)."""
+    from avex_amd import kernels as K
+    n = 16000
+    x = np.zeros((3, n), np.float32)
+    x[0, 12345 - 8000] = 1.0
+    x[1, : n // 2] = synth.noise_clips(1, n // 2, seed=3)[0] * np.float32(5.0)
+    x[2] = 0.25
+    got = K.FbankPlan()(_dev(x)).cpu().numpy()
+    ref = O.fbank(x * np.float32(2 ** 15))
+    floor = np.float32(np.log(np.float32(1.1920929e-07)))
+    silent = (ref == floor).all(axis=-1)                          # frames the reference puts at the floor everywhere
+    assert silent[0].sum() > 90 and silent[1].sum() > 45 and silent[2].all()
+    assert (got[silent] == floor).all()
+    assert max_abs(got[~silent], ref[~silent]) < 1e-3
+
+
+def test_stft_silent_frame_beside_a_loud_one(built_lib):
+    """The same for the STFT frontend (frame pairs per complex FFT): zero power, not leakage, for all-zero frames."""
+    from avex_amd import kernels as K
+    x = np.zeros((2, 24000), np.float32)
+    x[0, :9000] = synth.noise_clips(1, 9000, seed=5)[0] * np.float32(8.0)
+    x[1, 15000] = 1.0
+    for n_fft, hop in ((800, 160), (512, 128)):
+        spec = K.MelspecPlan(n_fft=n_fft, hop_length=hop, mel=False, normalize=False)(_dev(x)).cpu().numpy()
+        ts = torch.stft(torch.from_numpy(x), n_fft=n_fft, hop_length=hop, window=torch.hann_window(n_fft), center=True, return_complex=True).abs().pow(2).numpy()
+        zero = (ts == 0).all(axis=1)                              # [clip, frame]
+        assert zero.sum() > 50
+        assert (spec.transpose(0, 2, 1)[zero] == 0).all()
+        assert np.abs(spec - ts).max() <= 3e-5 * ts.max()
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # AVES / wav2vec2 path (SURVEY.md section 8 a18): parity unpinned vs torchaudio (absent); checker = oracle/aves_oracle.py
 # ------------------------------------------------------------------------------------------------------------------------
