@@ -65,6 +65,60 @@ def cpu_baseline(sd, cfg, seconds_budget=20.0):
             "reference_fixture": fixture}
 
 
+def board_power(step, sync, seconds: float = 3.0):
+    """Outside the timed region, rank 0, one GPU: loop the same step for a few seconds while a thread samples `rocm-smi` (board power,
+    shader clock, power cap).  The line then says by itself whether the step ran at the cap -- where only joules per clip, not idle
+    cycles, are left to win.  None if rocm-smi is missing or unreadable; never raises."""
+    import re
+    import subprocess
+    import threading
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    try:
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                try:
+                    r = subprocess.run([smi, "-d", "0", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                    pw = re.findall(r"Power \(W\):\s*([0-9.]+)", r)
+                    sc = re.findall(r"sclk clock level:.*\((\d+)Mhz\)", r)
+                    if pw and sc:
+                        samples.append((float(pw[0]), int(sc[0])))
+                except Exception:  # noqa: BLE001
+                    pass
+                time.sleep(0.15)
+
+        cap = None
+        try:
+            r = subprocess.run([smi, "-d", "0", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+            m = re.findall(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", r)
+            cap = float(m[0]) if m else None
+        except Exception:  # noqa: BLE001
+            pass
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < seconds:
+            step()
+            n += 1
+            if n % 4 == 0:
+                sync()
+        sync()
+        stop.set()
+        th.join(timeout=6)
+        if len(samples) < 3:
+            return None
+        pw = sorted(p for p, _ in samples)
+        ck = sorted(c for _, c in samples)
+        return {"median_w": pw[len(pw) // 2], "max_w": pw[-1], "cap_w": cap, "sclk_median_mhz": ck[len(ck) // 2], "sclk_peak_mhz": 2400,
+                "samples": len(samples), "how": f"rocm-smi every 0.15 s while the same step loops for {seconds:.0f} s after the timed region"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 DTYPE_NOTE = ("BASELINE.json's config says bf16; the MFMA operands here are f16 (same width, same 2.5 PFLOP/s dense rate on gfx950): bf16's 8-bit "
               "mantissa on the WEIGHTS alone puts the pooled embedding at 2e-3 of the fp32 reference, outside north_star's 1e-3; f16 is at 3e-4 "
               "(both measured live in `parity`).  Accumulation, residual sums, LayerNorm, softmax statistics and the frontend are fp32; --dtype bf16 "
@@ -127,6 +181,7 @@ def main():
     ap.add_argument("--residual", default=os.environ.get("AVEX_AMD_RESIDUAL", "half"), choices=["f32", "half"],
                     help="inter-kernel residual stream: fp32, or the operand type (default; pooled parity unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the post-run board power / clock sample (rocm-smi)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="tests only: run the launch / barrier / timing / all-gather / JSON control flow on the CPU with gloo and a stub "
                          "in place of the encoder (no number it prints is a measurement)")
@@ -292,6 +347,8 @@ def main():
             line["data"] = "cpu dry run (control flow only, not a measurement)"
         if world == 1 and not dry:
             line["parity"] = parity_vs_golden(cfg, sd, args, enc, wav)
+        if world == 1 and not dry and not args.no_power:
+            line["power"] = board_power(step, sync)
         if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(sd, cfg)
         print(json.dumps(line), flush=True)
