@@ -193,15 +193,18 @@ def layer_norm(x: np.ndarray, w: np.ndarray, b: np.ndarray, eps: float = 1e-5) -
 
 def gelu_erf(x: np.ndarray) -> np.ndarray:
     """Exact-erf GELU (modules.py:191-200 -> F.gelu; nn.GELU() at backbone.py:68)."""
-    x = x.astype(np.float32)
-    return (np.float32(0.5) * x * (np.float32(1.0) + _erf(x * np.float32(1.0 / math.sqrt(2.0))).astype(np.float32))).astype(np.float32)
+    x = x.astype(np.float32, copy=False)
+    t = _erf(x * np.float32(1.0 / math.sqrt(2.0))).astype(np.float32, copy=False)
+    t += np.float32(1.0)
+    t *= np.float32(0.5) * x          # same operations in the same order as 0.5 * x * (1 + erf(.)), without the temporaries
+    return t
 
 
 def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray]) -> np.ndarray:
-    y = x.astype(np.float32) @ w.T.astype(np.float32)
+    y = x.astype(np.float32, copy=False) @ w.T.astype(np.float32, copy=False)
     if b is not None:
-        y = y + b
-    return y.astype(np.float32)
+        y += b.astype(np.float32, copy=False)
+    return y.astype(np.float32, copy=False)
 
 
 def relative_position_bucket(rel: np.ndarray, num_buckets: int, max_distance: int) -> np.ndarray:
@@ -282,10 +285,11 @@ def attention(x: np.ndarray, p: Mapping[str, np.ndarray], pre: str, H: int, bias
             scores = scores + bias_hTT[None]
     if key_padding_mask is not None:
         scores = np.where(key_padding_mask[:, None, None, :], -np.inf, scores)
-    scores = scores - scores.max(axis=-1, keepdims=True)
-    e = np.exp(scores.astype(np.float32))
-    attn = e / e.sum(axis=-1, keepdims=True, dtype=np.float32)
-    o = (attn.astype(np.float32) @ v).transpose(0, 2, 1, 3).reshape(B, T, E)
+    scores = scores.astype(np.float32, copy=False)
+    scores -= scores.max(axis=-1, keepdims=True)
+    e = np.exp(scores, out=scores)
+    e /= e.sum(axis=-1, keepdims=True, dtype=np.float32)
+    o = (e @ v).transpose(0, 2, 1, 3).reshape(B, T, E)
     return linear(o, p[pre + "out_proj.weight"], p[pre + "out_proj.bias"])
 
 
