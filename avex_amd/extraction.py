@@ -19,7 +19,7 @@ import torch
 
 logger = logging.getLogger(__name__)
 
-__all__ = ["extract_embeddings_in_memory"]
+__all__ = ["extract_embeddings_in_memory", "extract_embeddings_streaming", "write_embedding_metadata"]
 
 
 def _stage(batch: Dict[str, Any], device: torch.device, stream: Optional["torch.cuda.Stream"]):
@@ -123,3 +123,149 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
         if original_disable_layerdrop is not None and hasattr(model, "disable_layerdrop"):
             model.disable_layerdrop = original_disable_layerdrop
         model.deregister_all_hooks()                                                 # embedding_utils.py:143-144
+
+
+def write_embedding_metadata(h5f: Any, *, aggregation: str, layer_names: List[str], embedding_dims: List[tuple], multi_layer: bool) -> None:
+    """The cache attributes a reader needs to interpret the stored shapes (reference: embedding_utils.py:147-161, same keys and
+    value forms).  ``h5f`` is an ``h5py.File`` or anything with a mapping ``.attrs``."""
+    h5f.attrs["embedding_aggregation"] = aggregation
+    h5f.attrs["aggregation"] = aggregation
+    h5f.attrs["stored_embedding_rank"] = [len(tuple(dim)) for dim in embedding_dims]
+    h5f.attrs["layer_names"] = layer_names
+    h5f.attrs["embedding_dims"] = [str(tuple(dim)) for dim in embedding_dims]
+    h5f.attrs["multi_layer"] = multi_layer
+
+
+def extract_embeddings_streaming(model: Any, dataloader: Any, target_layers: List[Any], device: Any, save_path: Any,
+                                 chunk_size: int = 1000, compression: Optional[str] = "gzip", compression_level: int = 4,
+                                 aggregation: str = "mean", disable_layerdrop: Optional[bool] = None, h5_module: Any = None,
+                                 prefetch: Optional[bool] = None) -> List[tuple]:
+    """Extraction straight into an HDF5 cache (reference: ``_extract_embeddings_streaming`` + ``_create_and_fill_h5_datasets_hybrid``,
+    embedding_utils.py:164-346, 349-822): one float32 dataset ``embeddings_<layer>`` per hooked layer, shape ``(N, *dim)`` in chunks of
+    ``(chunk_size, *dim)``, an int64 ``labels`` dataset, the attributes of ``write_embedding_metadata`` plus ``num_labels`` /
+    ``label_shape`` / ``extraction_complete`` / ``skipped_batches``.  Returns the per-layer embedding dims like the reference.
+
+    The device side is the loop of ``extract_embeddings_in_memory`` (overlapped PCIe copies); rows are written as each batch's
+    device-to-host copy completes, so host memory holds a few batches, not the data set.  HDF5 itself is a storage concern outside
+    the accelerated path: ``h5py`` is imported here, at call time (``h5_module`` lets a caller or a test inject a compatible
+    module); without it this raises ``ImportError`` and nothing else in the package is affected."""
+    import os
+
+    import numpy as np
+    if h5_module is None:
+        try:
+            import h5py as h5_module                     # type: ignore[no-redef]
+        except ImportError as e:                         # pragma: no cover - environment dependent
+            raise ImportError("extract_embeddings_streaming writes an HDF5 cache and needs h5py") from e
+    total = len(dataloader.dataset)                       # embedding_utils.py:240
+    if chunk_size <= 0:
+        raise ValueError(f"Invalid chunk size: {chunk_size}. Must be positive.")
+    parent = os.path.dirname(os.fspath(save_path))
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    kwargs: Dict[str, Any] = {}
+    if compression and str(compression).lower() not in {"none", "null", "false"}:         # embedding_utils.py:416-421
+        kwargs["compression"] = compression
+        if str(compression).lower() != "lzf":
+            kwargs["compression_opts"] = int(compression_level)
+
+    state: Dict[str, Any] = {"dsets": None, "labels": None, "dims": None, "row": 0, "label_shape": None}
+
+    def sink(h5f: Any, names: List[str], embs: List[torch.Tensor], labels: torch.Tensor) -> None:
+        n = int(embs[0].shape[0])
+        if state["dsets"] is None:                        # first batch fixes names, dims and the label layout
+            dims = [tuple(e.shape[1:]) for e in embs]
+            per_sample = int(sum(int(np.prod(d)) if len(d) else 1 for d in dims))
+            cs = min(chunk_size, max(1, int(4 * 1024 ** 3 / max(1, per_sample * 4))), max(1, total))      # HDF5's 4 GB chunk limit (:276-291)
+            state["dsets"] = {nm: h5f.create_dataset(f"embeddings_{nm}", shape=(total,) + d, maxshape=(None,) + d, dtype=np.float32,
+                                                     chunks=(cs,) + d, **kwargs) for nm, d in zip(names, dims)}
+            ls = tuple(labels.shape[1:]) if labels.dim() > 1 else ()
+            np_dt = np.dtype(str(labels.dtype).replace("torch.", "")) if str(labels.dtype) != "torch.bool" else np.bool_
+            state["labels"] = h5f.create_dataset("labels", shape=(total,) + ls, maxshape=(None,) + ls, dtype=np_dt, chunks=(cs,) + ls, **kwargs)
+            state["dims"], state["label_shape"] = dims, ls
+        r = state["row"]
+        for nm, e in zip(names, embs):
+            state["dsets"][nm][r:r + n] = e.numpy().astype(np.float32)
+        state["labels"][r:r + n] = labels.numpy().astype(np.int64)                           # embedding_utils.py:548
+        state["row"] = r + n
+
+    device = torch.device(device)
+    if prefetch is None:
+        prefetch = device.type == "cuda"
+    prefetch = bool(prefetch) and device.type == "cuda" and torch.cuda.is_available()
+    original_disable_layerdrop = None
+    if disable_layerdrop is not None and hasattr(model, "disable_layerdrop"):
+        original_disable_layerdrop = model.disable_layerdrop
+        model.disable_layerdrop = disable_layerdrop
+    copy_stream = torch.cuda.Stream(device=device) if prefetch else None
+    try:
+        with torch.no_grad(), h5_module.File(os.fspath(save_path), "w") as h5f:
+            resolved_layers = model.register_hooks_for_layers(target_layers)
+            pending: List[Tuple[Any, List[str], List[torch.Tensor], torch.Tensor]] = []
+
+            def drain(keep: int) -> None:
+                while len(pending) > keep:
+                    ev, names, embs, lab = pending.pop(0)
+                    if ev is not None:
+                        ev.synchronize()
+                    sink(h5f, names, embs, lab)
+
+            it = iter(dataloader)
+            nxt = next(it, None)
+            staged = _stage(nxt, device, copy_stream) if nxt is not None else None
+            while nxt is not None:
+                batch, (wav, mask, ready) = nxt, staged
+                nxt = next(it, None)
+                if ready is not None:
+                    cur = torch.cuda.current_stream(device)
+                    cur.wait_event(ready)
+                    wav.record_stream(cur)
+                    if mask is not None:
+                        mask.record_stream(cur)
+                if nxt is not None:
+                    staged = _stage(nxt, device, copy_stream)
+                emb = model.extract_embeddings(wav if mask is None else {"raw_wav": wav, "padding_mask": mask}, aggregation=aggregation)
+                if isinstance(emb, list):
+                    names = [resolved_layers[i] if i < len(resolved_layers) else f"layer_{i}" for i in range(len(emb))]
+                    embs = list(emb)
+                elif isinstance(emb, dict):
+                    names, embs = list(emb.keys()), list(emb.values())
+                else:
+                    names, embs = [resolved_layers[0] if resolved_layers else "embeddings"], [emb]
+                host: List[torch.Tensor] = []
+                for t in embs:
+                    if copy_stream is not None and t.is_cuda:
+                        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                        h.copy_(t, non_blocking=True)
+                        host.append(h)
+                    else:
+                        host.append(t.cpu())
+                ev = None
+                if copy_stream is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(device))
+                pending.append((ev, names, host, batch["label"].cpu()))
+                drain(2)                                   # at most two batches of embeddings wait on the host
+            drain(0)
+            if state["dsets"] is None:
+                raise ValueError("No data processed. Check if dataloader is empty or has invalid batches.")
+            ls = state["label_shape"]
+            if ls:                                         # embedding_utils.py:773-787
+                if len(ls) == 1 and ls[0] > 1:
+                    h5f.attrs["num_labels"] = ls[0]
+                else:
+                    h5f.attrs["num_labels"] = -1
+                    h5f.attrs["label_shape"] = ls
+            else:
+                h5f.attrs["num_labels"] = len(np.unique(np.asarray(state["labels"][:])))
+            write_embedding_metadata(h5f, aggregation=aggregation, layer_names=list(state["dsets"].keys()),
+                                     embedding_dims=state["dims"], multi_layer=True)
+            if state["row"] != total:
+                logger.warning("Expected to process %d samples, but processed %d", total, state["row"])
+            h5f.attrs["extraction_complete"] = state["row"] == total
+            h5f.attrs["skipped_batches"] = 0
+        return [tuple(d) for d in state["dims"]]
+    finally:
+        if original_disable_layerdrop is not None and hasattr(model, "disable_layerdrop"):
+            model.disable_layerdrop = original_disable_layerdrop
+        model.deregister_all_hooks()

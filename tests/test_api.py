@@ -250,6 +250,94 @@ def test_extraction_loop_semantics_cpu():
     assert m.deregistered == 1 and m.disable_layerdrop is False
 
 
+def test_streaming_extraction_cache_layout_cpu(tmp_path):
+    """The HDF5 cache writer (reference: evaluation/embedding_utils.py:147-161, 164-346, 349-822) against an in-memory stand-in for
+    h5py (not installed here): dataset names / shapes / dtypes / chunking, row order, and every attribute the reference's reader
+    (`_load_metadata`, embedding_utils.py:1085-1101) looks for; hooks deregistered afterwards."""
+    import numpy as np
+    import torch
+    from avex_amd.extraction import extract_embeddings_streaming, write_embedding_metadata
+
+    class Dset:
+        def __init__(self, shape, dtype, **kw):
+            self.a, self.kw = np.zeros(shape, dtype), kw
+            self.shape = tuple(shape)
+
+        def __setitem__(self, k, v):
+            self.a[k] = v
+
+        def __getitem__(self, k):
+            return self.a[k]
+
+    class File(dict):
+        opened = []
+
+        def __init__(self, path, mode):
+            super().__init__()
+            self.attrs, self.path, self.mode = {}, path, mode
+            File.opened.append(self)
+
+        def create_dataset(self, name, shape, maxshape, dtype, chunks, **kw):
+            self[name] = Dset(shape, dtype, maxshape=maxshape, chunks=chunks, **kw)
+            return self[name]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class H5:
+        pass
+    H5.File = File
+
+    class Fake:
+        deregistered = 0
+
+        def register_hooks_for_layers(self, layers):
+            return ["backbone.post_extract_proj", "backbone.encoder.layers.11.fc2"][: len(layers)]
+
+        def deregister_all_hooks(self):
+            self.deregistered += 1
+
+        def extract_embeddings(self, x, aggregation="none"):
+            wav = x["raw_wav"] if isinstance(x, dict) else x
+            base = wav.sum(dim=1, keepdim=True)
+            if aggregation == "none":
+                return [base[:, None, :].repeat(1, 5, 4), base[:, None, :].repeat(1, 5, 3) * 2]
+            return base.repeat(1, 8)
+
+    class Loader(list):
+        pass
+    batches = Loader({"raw_wav": torch.full((2 if i < 2 else 1, 8), float(i + 1)), "label": torch.tensor([i, i + 10][: 2 if i < 2 else 1])} for i in range(3))
+    batches.dataset = list(range(5))
+    m = Fake()
+    out = tmp_path / "cache" / "emb.h5"
+    dims = extract_embeddings_streaming(m, batches, [0], "cpu", out, chunk_size=4, compression="gzip", compression_level=4, aggregation="mean", h5_module=H5)
+    f = File.opened[-1]
+    assert dims == [(8,)] and f.mode == "w" and out.parent.is_dir()
+    assert set(f) == {"embeddings_backbone.post_extract_proj", "labels"}
+    d = f["embeddings_backbone.post_extract_proj"]
+    assert d.shape == (5, 8) and d.a.dtype == np.float32 and d.kw["chunks"] == (4, 8) and d.kw["maxshape"] == (None, 8)
+    assert d.kw["compression"] == "gzip" and d.kw["compression_opts"] == 4
+    assert d.a[:, 0].tolist() == [8.0, 8.0, 16.0, 16.0, 24.0]
+    assert f["labels"].a.dtype == np.int64 and f["labels"].a.tolist() == [0, 10, 1, 11, 2]
+    assert f.attrs == {"num_labels": 5, "embedding_aggregation": "mean", "aggregation": "mean", "stored_embedding_rank": [1],
+                       "layer_names": ["backbone.post_extract_proj"], "embedding_dims": ["(8,)"], "multi_layer": True,
+                       "extraction_complete": True, "skipped_batches": 0}
+    assert m.deregistered == 1
+    # two layers, unpooled, no compression (lzf takes no level): per-layer datasets of their own rank
+    dims = extract_embeddings_streaming(m, batches, [0, -1], "cpu", out, chunk_size=100, compression="lzf", aggregation="none", h5_module=H5)
+    f = File.opened[-1]
+    assert dims == [(5, 4), (5, 3)]
+    assert f["embeddings_backbone.encoder.layers.11.fc2"].shape == (5, 5, 3) and f["embeddings_backbone.encoder.layers.11.fc2"].kw["chunks"] == (5, 5, 3)
+    assert "compression_opts" not in f["embeddings_backbone.post_extract_proj"].kw
+    assert f.attrs["stored_embedding_rank"] == [2, 2] and f.attrs["embedding_dims"] == ["(5, 4)", "(5, 3)"]
+    store = File("x", "w")
+    write_embedding_metadata(store, aggregation="max", layer_names=["a"], embedding_dims=[(3, 4)], multi_layer=False)
+    assert store.attrs["stored_embedding_rank"] == [2] and store.attrs["multi_layer"] is False and store.attrs["aggregation"] == "max"
+
+
 def test_aves_class_contract_cpu():
     """AVES mirror (reference: avex/models/aves_model.py:62-262) without a GPU: torchaudio wav2vec2 key names (210 tensors),
     hookable layers = the 12 output_dense modules, name/index resolution, prefix-less and old-style weight_norm checkpoints
