@@ -77,6 +77,7 @@ SYMBOLS = {
     "avexhip_effnet_dwconv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_effnet_se": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_resample_plan_create": (_P, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "avexhip_resample_interp_plan_create": (_P, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "avexhip_resample_plan_destroy": (None, [_P]),
     "avexhip_resample_out_length": (C.c_int64, [_P, C.c_int64]),
     "avexhip_resample_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, _P]),

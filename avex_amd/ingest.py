@@ -60,16 +60,31 @@ def parse_wav(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int, i
     return np.frombuffer(payload, dtype=np.uint8, count=n * frame_bytes), sr, ch, code
 
 
+# resampy's published filters: (num_zeros, precision, rolloff, Kaiser beta)
+RESAMPY_FILTERS = {"kaiser_best": (64, 9, 0.9475937167399596, 14.769656459379492),
+                   "kaiser_fast": (16, 9, 0.85, 8.555504641634386)}
+
+
 class Resampler:
     """``torchaudio.transforms.Resample(orig_freq, new_freq)`` on the device (defaults as torchaudio's: ``sinc_interp_hann``,
     ``lowpass_filter_width=6``, ``rolloff=0.99``; ``beta`` > 0 selects the Kaiser window, ``sinc_interp_kaiser``)."""
 
-    def __init__(self, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99, beta: float = 0.0) -> None:
+    def __init__(self, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99, beta: float = 0.0,
+                 res_type: Optional[str] = None, scale: bool = True) -> None:
+        """``res_type="kaiser_best"`` selects librosa's resampler instead (``librosa.resample(y, orig_sr=, target_sr=, scale=True,
+        res_type="kaiser_best")``, birdset_train_splits.py:190-196 = resampy's interpolating kernel with its published kaiser_best
+        filter); ``scale`` is librosa's energy-preserving ``scale`` flag."""
         _capi.require_gpu()
         self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
         self._h = None
         if self.orig_freq != self.new_freq:
-            self._h = lib().avexhip_resample_plan_create(self.orig_freq, self.new_freq, int(lowpass_filter_width), float(rolloff), float(beta))
+            if res_type is None:
+                self._h = lib().avexhip_resample_plan_create(self.orig_freq, self.new_freq, int(lowpass_filter_width), float(rolloff), float(beta))
+            elif res_type in RESAMPY_FILTERS:
+                nz, prec, ro, kb = RESAMPY_FILTERS[res_type]
+                self._h = lib().avexhip_resample_interp_plan_create(self.orig_freq, self.new_freq, nz, prec, ro, kb, int(bool(scale)))
+            else:
+                raise ValueError(f"res_type {res_type!r}: only {sorted(RESAMPY_FILTERS)} (librosa / resampy) or None (torchaudio sinc) are built")
             if not self._h:
                 raise AvexHipError(f"resample_plan_create failed: {_capi.last_error()}")
 

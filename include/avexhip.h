@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 3
+#define AVEXHIP_ABI_VERSION 4
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -138,6 +138,13 @@ int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, i
  *                            x [B, T] -> out [B, ceil(new * T / orig)] (avexhip_resample_out_length).  Parity unpinned (torchaudio absent). */
 typedef struct avexhip_resample_plan avexhip_resample_plan;
 avexhip_resample_plan* avexhip_resample_plan_create(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff, double kaiser_beta);
+/* librosa.resample(y, orig_sr, target_sr, res_type="kaiser_best", scale=True) (birdset_train_splits.py:190-196) = resampy's interpolating
+ * resampler: half-window table of a Kaiser-windowed sinc (kaiser_best: num_zeros 64, precision 9, rolloff 0.9475937167399596,
+ * beta 14.769656459379492), two wings per output sample with linearly interpolated weights; out [B, ceil(T * new / orig)], the samples past
+ * int(T * new / orig) zero (librosa's fix_length), everything divided by sqrt(new / orig) when scale_energy.  The plan works with
+ * avexhip_resample_out_length / _forward / _plan_destroy.  Parity unpinned (resampy / librosa absent). */
+avexhip_resample_plan* avexhip_resample_interp_plan_create(int orig_freq, int new_freq, int num_zeros, int precision, double rolloff, double kaiser_beta,
+                                                           int scale_energy);
 void avexhip_resample_plan_destroy(avexhip_resample_plan* plan);
 int64_t avexhip_resample_out_length(const avexhip_resample_plan* plan, int64_t T);
 int avexhip_resample_forward(const avexhip_resample_plan* plan, const float* x_dev, int B, int64_t T, int64_t x_stride, float* out_dev,

@@ -58,3 +58,64 @@ def resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width:
     out = np.einsum("bfk,pk->bfp", xp[:, win_idx].astype(np.float64), kern.astype(np.float64)).reshape(xp.shape[0], -1)
     tgt = math.ceil(new * T / orig)
     return out[:, :tgt].astype(np.float32).reshape(*lead, tgt)
+
+
+# resampy's published filters: (num_zeros, precision, rolloff, Kaiser beta)
+RESAMPY_FILTERS = {"kaiser_best": (64, 9, 0.9475937167399596, 14.769656459379492),
+                   "kaiser_fast": (16, 9, 0.85, 8.555504641634386)}
+
+
+def resampy_filter(res_type: str = "kaiser_best"):
+    """``resampy.filters.sinc_window(num_zeros, precision, window=kaiser(beta), rolloff)``: the right half of a Kaiser-windowed sinc,
+    ``num_zeros * 2**precision + 1`` points (what resampy ships precomputed as ``data/kaiser_best.npz``).  UNPINNED (resampy absent)."""
+    nz, prec, rolloff, beta = RESAMPY_FILTERS[res_type]
+    num_bits = 2 ** prec
+    n = num_bits * nz
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, nz, num=n + 1, endpoint=True))
+    taper = np.kaiser(2 * n + 1, beta)[n:]
+    return taper * sinc_win, num_bits
+
+
+def resample_librosa(x: np.ndarray, orig_sr: int, target_sr: int, res_type: str = "kaiser_best", scale: bool = True) -> np.ndarray:
+    """``librosa.resample(y=x, orig_sr=, target_sr=, scale=, res_type="kaiser_best")`` for a mono fp32 signal, as the reference calls
+    it (birdset_train_splits.py:190-196): resampy's ``resample_f`` loop restated sample by sample (two wings over the half-window
+    table, weights linearly interpolated between table entries, window scaled by the ratio when decimating), ``int(T * ratio)``
+    samples zero-padded to ``ceil(T * ratio)`` (librosa's ``fix_length``), divided by ``sqrt(ratio)`` when ``scale``.
+    PARITY UNPINNED: neither librosa nor resampy is in the image; restated from their published source."""
+    x = np.asarray(x, np.float32)
+    if orig_sr == target_sr:
+        return x
+    ratio = float(target_sr) / orig_sr
+    interp_win, num_table = resampy_filter(res_type)
+    if ratio < 1:
+        interp_win = interp_win * ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    sc = min(1.0, ratio)
+    index_step = int(sc * num_table)
+    nwin, n_orig = interp_win.shape[0], x.shape[0]
+    n_res = int(n_orig * ratio)
+    t_out = np.arange(n_res) * (1.0 / ratio)
+    n = t_out.astype(np.int64)
+    xd = x.astype(np.float64)
+    y = np.zeros(n_res, np.float64)
+    frac = sc * (t_out - n)
+    for wing in (0, 1):
+        if wing:
+            frac = sc - frac
+        index_frac = frac * num_table
+        offset = index_frac.astype(np.int64)
+        eta = index_frac - offset
+        lim = (nwin - offset) // index_step
+        cnt = np.minimum(n + 1, lim) if wing == 0 else np.minimum(n_orig - n - 1, lim)
+        for i in range(int(cnt.max()) if cnt.size else 0):
+            m = i < cnt
+            k = offset[m] + i * index_step
+            src = (n[m] - i) if wing == 0 else (n[m] + i + 1)
+            y[m] += (interp_win[k] + eta[m] * interp_delta[k]) * xd[src]
+    n_samples = int(math.ceil(n_orig * ratio))
+    out = np.zeros(n_samples, np.float64)
+    out[:n_res] = y
+    if scale:
+        out /= np.sqrt(ratio)
+    return out.astype(np.float32)

@@ -80,6 +80,41 @@ def test_device_resampler_matches_oracle(built_lib, orig, new):
     assert np.abs(yk.cpu().numpy() - IO.resample(x, orig, new, 16, 0.945, 14.77)).max() < 2e-6
 
 
+def test_oracle_librosa_resampler_properties():
+    """The restated resampy / librosa `kaiser_best` path (birdset_train_splits.py:190-196): ceil(T ratio) samples, the last one(s) beyond
+    int(T ratio) zero-filled, integer table steps (2:1, 1:2) reproduce DC exactly, the others carry resampy's index_step truncation
+    (int(scale * 512): a few 1e-3 of gain), a tone keeps its frequency, `scale` divides by sqrt(ratio)."""
+    y = IO.resample_librosa(np.ones(32000, np.float32), 32000, 16000, scale=False)
+    assert y.shape == (16000,) and np.abs(y[200:-200] - 1.0).max() < 1e-6
+    y = IO.resample_librosa(np.ones(22051, np.float32), 22050, 16000, scale=False)
+    assert y.shape == (16001,) and y[-1] == 0.0 and np.abs(y[200:-200] - 1.0).max() < 1e-3
+    t = np.arange(48000) / 48000.0
+    y = IO.resample_librosa(np.sin(2 * np.pi * 1000 * t).astype(np.float32), 48000, 16000, scale=False)
+    ref = np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)
+    assert np.abs(y[300:-300] - 1.0027175 * ref[300:-300]).max() < 5e-4
+    ys = IO.resample_librosa(np.sin(2 * np.pi * 1000 * t).astype(np.float32), 48000, 16000, scale=True)
+    assert np.allclose(ys, y / np.sqrt(1 / 3), atol=1e-6)
+    x = synth.normal("rsl", (500,), 1.0)
+    assert np.array_equal(IO.resample_librosa(x, 16000, 16000), x)
+    assert IO.resample_librosa(x, 8000, 16000).shape == (1000,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orig,new", [(44100, 16000), (48000, 16000), (22050, 16000), (8000, 16000), (32000, 16000), (16000, 22050)])
+def test_device_librosa_resampler_matches_oracle(built_lib, orig, new):
+    x = synth.normal(f"rsl{orig}", (3, 30011), 0.3)
+    rs = ingest.Resampler(orig, new, res_type="kaiser_best")
+    y = rs(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert y.shape == (3, rs.out_length(30011)) and rs.out_length(30011) == int(np.ceil(30011 * new / orig))
+    for b in range(3):
+        ref = IO.resample_librosa(x[b], orig, new)
+        assert ref.shape == y[b].shape and np.abs(y[b] - ref).max() < 5e-6
+    yf = ingest.Resampler(orig, new, res_type="kaiser_fast", scale=False)(torch.from_numpy(x[0]).cuda()).cpu().numpy()
+    assert np.abs(yf - IO.resample_librosa(x[0], orig, new, res_type="kaiser_fast", scale=False)).max() < 5e-6
+    with pytest.raises(ValueError):
+        ingest.Resampler(orig, new, res_type="soxr_hq")
+
+
 @pytest.mark.gpu
 def test_load_audio_end_to_end(built_lib, tmp_path):
     """A 44.1 kHz stereo 24-bit file -> mono 16 kHz on the device, then through the BEATs frontend like any clip."""
