@@ -320,8 +320,10 @@ def main():
                 "note": "peak is the 2.4 GHz dense MFMA figure; this kernel (and the step as a whole) runs at the board's 1400 W power cap, "
                         "shader clock 1.5-1.9 GHz on random operands (profiles/r01c_gemm_power.txt, profiles/r01e_step_power.txt); a register-only MFMA loop "
                         "on random halves sustains 1.8 PFLOP/s under that cap, 1.4 with this kernel's LDS traffic (profiles/r01h_mfma_power.txt); "
-                        "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE doubled, "
-                        "the gfx950 correction), algorithmic bytes per launch 0.88 GB"}
+                        "traffic = bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE doubled, "
+                        "the gfx950 correction), algorithmic bytes per launch 0.88 GB; the counters sit between the L2s and the fabric, so the A panels "
+                        "re-fetched by the wide K = 768 products (195 MB, inside the 256 MB Infinity Cache) are counted although they need not reach HBM "
+                        "(DESIGN.md section 4, 'What the traffic figure is')"}
 
     if rank == 0:
         clips = world * B * args.steps
