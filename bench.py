@@ -65,38 +65,46 @@ def cpu_baseline(sd, cfg, seconds_budget=20.0):
             "reference_fixture": fixture}
 
 
-def board_power(step, sync, seconds: float = 3.0):
-    """Outside the timed region, rank 0, one GPU: loop the same step for a few seconds while a thread samples `rocm-smi` (board power,
-    shader clock, power cap).  The line then says by itself whether the step ran at the cap -- where only joules per clip, not idle
-    cycles, are left to win.  None if rocm-smi is missing or unreadable; never raises."""
-    import re
-    import subprocess
+def board_power(step, sync, device_index: int = 0, seconds: float = 3.0):
+    """Outside the timed region, rank 0, one GPU: loop the same step for a few seconds while a thread reads the board's hwmon files
+    (power1_input, power1_cap, freq1_input = sclk) straight from sysfs.  The line then says by itself whether the step ran at the power
+    cap -- where only joules per clip, not idle cycles, are left to win.  No child process is started (a process
+    that has initialised the GPU must not fork-and-exec on this pool, least of all under a profiler).  None if the files are not
+    there; never raises."""
+    import glob
     import threading
-    smi = "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
-        return None
     try:
-        samples, stop = [], threading.Event()
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        cands = []
+        try:
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cands = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        except Exception:  # noqa: BLE001
+            cands = []
+        by_bdf = bool(cands)
+        if not cands:
+            cands = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(os.path.join(d, "power1_input"))]
+        if not cands:
+            return None
+
+        def rd(path):
+            try:
+                with open(path) as f:
+                    return float(f.read().strip())
+            except Exception:  # noqa: BLE001
+                return None
+
+        samples, stop = {d: [] for d in cands}, threading.Event()
 
         def sampler():
             while not stop.is_set():
-                try:
-                    r = subprocess.run([smi, "-d", "0", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
-                    pw = re.findall(r"Power \(W\):\s*([0-9.]+)", r)
-                    sc = re.findall(r"sclk clock level:.*\((\d+)Mhz\)", r)
-                    if pw and sc:
-                        samples.append((float(pw[0]), int(sc[0])))
-                except Exception:  # noqa: BLE001
-                    pass
-                time.sleep(0.15)
+                for d in cands:
+                    pw, ck = rd(os.path.join(d, "power1_input")), rd(os.path.join(d, "freq1_input"))
+                    if pw is not None and ck is not None:
+                        samples[d].append((pw * 1e-6, ck * 1e-6))
+                time.sleep(0.1)
 
-        cap = None
-        try:
-            r = subprocess.run([smi, "-d", "0", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
-            m = re.findall(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", r)
-            cap = float(m[0]) if m else None
-        except Exception:  # noqa: BLE001
-            pass
         th = threading.Thread(target=sampler, daemon=True)
         th.start()
         t0 = time.time()
@@ -108,13 +116,18 @@ def board_power(step, sync, seconds: float = 3.0):
                 sync()
         sync()
         stop.set()
-        th.join(timeout=6)
-        if len(samples) < 3:
+        th.join(timeout=3)
+        med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
+        best = max((d for d in cands if len(samples[d]) >= 3), key=lambda d: med([p for p, _ in samples[d]]), default=None)
+        if best is None:
             return None
-        pw = sorted(p for p, _ in samples)
-        ck = sorted(c for _, c in samples)
-        return {"median_w": pw[len(pw) // 2], "max_w": pw[-1], "cap_w": cap, "sclk_median_mhz": ck[len(ck) // 2], "sclk_peak_mhz": 2400,
-                "samples": len(samples), "how": f"rocm-smi every 0.15 s while the same step loops for {seconds:.0f} s after the timed region"}
+        pw = [p for p, _ in samples[best]]
+        ck = [c for _, c in samples[best]]
+        cap = rd(os.path.join(best, "power1_cap"))
+        return {"median_w": round(med(pw), 1), "max_w": round(max(pw), 1), "cap_w": round(cap * 1e-6, 1) if cap else None,
+                "sclk_median_mhz": round(med(ck)), "sclk_peak_mhz": 2400, "samples": len(pw),
+                "how": f"sysfs hwmon (power1_input, freq1_input) every 0.1 s while the same step loops for {seconds:.0f} s after the timed region"
+                       + ("" if by_bdf else "; device picked as the busiest hwmon on the node")}
     except Exception:  # noqa: BLE001
         return None
 
@@ -350,7 +363,7 @@ def main():
         if world == 1 and not dry:
             line["parity"] = parity_vs_golden(cfg, sd, args, enc, wav)
         if world == 1 and not dry and not args.no_power:
-            line["power"] = board_power(step, sync)
+            line["power"] = board_power(step, sync, local_rank)
         if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(sd, cfg)
         print(json.dumps(line), flush=True)
