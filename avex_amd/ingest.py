@@ -118,7 +118,11 @@ def to_device_mono(raw: Union[np.ndarray, torch.Tensor], channels: int, sample_f
     float32 ``[frames]`` on the device, channels averaged."""
     _capi.require_gpu()
     dev = device or torch.device("cuda", torch.cuda.current_device())
-    t = torch.from_numpy(np.ascontiguousarray(raw)) if isinstance(raw, np.ndarray) else raw
+    if isinstance(raw, np.ndarray):
+        a = np.ascontiguousarray(raw)
+        t = torch.from_numpy(a if a.flags.writeable else a.copy())      # (views of a bytes object are read-only; torch wants to own writable memory)
+    else:
+        t = raw
     buf = t.contiguous().view(torch.uint8).reshape(-1)
     width = {8: 1, 16: 2, 24: 3, 32: 4, 0: 4, 64: 8}[sample_format]
     frames = buf.numel() // (width * channels)
