@@ -181,9 +181,17 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
             const float2 zk = z[k], zn = z[(512 - k) & 511];
             const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
             const float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);
+#ifndef FBANK_ABS_SQ
+#define FBANK_ABS_SQ 1     // 1: |X|^2 as the reference forms it, abs() then ** 2 (beats.py:155); 0: re^2 + im^2 directly (differs in the last bit)
+#endif
+#if FBANK_ABS_SQ
             const float ma = sqrtf(ar * ar + ai * ai), mb = sqrtf(br * br + bi * bi);
             pw[wave][0][k] = live[0] ? ma * ma : 0.f;
             pw[wave][1][k] = live[1] ? mb * mb : 0.f;
+#else
+            pw[wave][0][k] = live[0] ? ar * ar + ai * ai : 0.f;
+            pw[wave][1][k] = live[1] ? br * br + bi * bi : 0.f;
+#endif
         }
     }
     AVX_WAVE_SYNC();
