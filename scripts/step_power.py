@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Board power and shader clock while the whole 256-clip step loops (rocm-smi sampled every 0.2 s), plus each kernel family
+"""Board power and shader clock while the whole 256-clip step loops (sysfs hwmon sampled every 0.1 s), plus each kernel family
 looped on its own: which parts of the step sit at the power cap (energy-bound) and which do not (cycle-bound)."""
 import os, sys, subprocess, threading, time, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,15 +7,26 @@ sys.path.insert(0, ROOT)
 import torch
 from avex_amd import synth, kernels as K
 
+def _hwmon():
+    """hwmon directory of torch's device 0 (sysfs; no child process from a GPU-initialised process)."""
+    import glob
+    pr = torch.cuda.get_device_properties(0)
+    c = glob.glob(f"/sys/bus/pci/devices/{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0/hwmon/hwmon*")
+    return c[0] if c else None
+
+HW = None
+
 def sampler(stop, out):
+    global HW
+    HW = HW or _hwmon()
     while not stop.is_set():
         try:
-            r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
-            pw = re.findall(r"Power \(W\):\s*([0-9.]+)", r); sc = re.findall(r"sclk clock level:.*\((\d+)Mhz\)", r)
-            out.append((float(pw[0]) if pw else None, int(sc[0]) if sc else None))
+            pw = float(open(os.path.join(HW, "power1_input")).read()) * 1e-6
+            sc = float(open(os.path.join(HW, "freq1_input")).read()) * 1e-6
+            out.append((pw, int(sc)))
         except Exception:  # noqa: BLE001
             pass
-        time.sleep(0.2)
+        time.sleep(0.1)
 
 def loop(name, fn, seconds=4.0):
     for _ in range(3): fn()
@@ -46,3 +57,11 @@ gw = torch.randn(8, 64, device="cuda") * 0.1; gb = torch.randn(8, device="cuda")
 loop("attention", lambda: K.attention(qkv, B, T, H, tab, gw, gb, ga))
 g = torch.ones(E, device="cuda"); bb = torch.zeros(E, device="cuda")
 loop("layernorm (half in, f32+half out)", lambda: K.layernorm(x, g, bb))
+xh = x
+loop("layernorm (half in, half out)", lambda: K.layernorm(xh, g, bb, want_f32=False))
+w2 = (torch.randn(E, 3072, device="cuda") * 0.02).half(); hmid = torch.randn(M, 3072, device="cuda").half(); b2 = torch.randn(E, device="cuda")
+loop("gemm fc2 (+half residual)", lambda: K.gemm(hmid, w2, bias=b2, resid_half=x, alpha=2.2, out_f32=False, out_half=True))
+wq = (torch.randn(2304, E, device="cuda") * 0.05).half(); bq = torch.randn(2304, device="cuda")
+loop("gemm qkv", lambda: K.gemm(x, wq, bias=bq, out_f32=False, out_half=True))
+plan = K.FbankPlan()
+loop("fbank (256 clips, f32 out)", lambda: plan(wav))
