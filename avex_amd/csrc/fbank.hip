@@ -90,26 +90,37 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     for (int fr = 0; fr < 2; ++fr) {
         float cur[8], prev[8];
         float s = 0.f;
-        const float* src = wav + (int64_t)b * stride + (int64_t)(f0 + fr) * fb.hop;
+        // branch-free: every lane loads from an in-range address (index clamped to the window, frame clamped to the clip's last one)
+        // and the values outside the window / of a frame that does not exist are zeroed by a select; a conditional load per element
+        // put each of the 40 loads in its own basic block with its own wait
+        const bool vfr = valid[fr];
+        const int fsafe = vfr ? f0 + fr : (frames > 0 ? frames - 1 : 0);
+        const float* src = wav + (int64_t)b * stride + (int64_t)fsafe * fb.hop;
         const float coff = clip_offset ? clip_offset[b] : 0.f;   // EAT: mono - mono.mean() (eat/audio_processor.py:107)
+        float wn[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = lane + 64 * q;
-            cur[q] = 0.f; prev[q] = 0.f;
-            if (valid[fr] && n < fb.win) {
-                cur[q] = (src[n] - coff) * fb.input_scale;
-                prev[q] = (src[n > 0 ? n - 1 : 0] - coff) * fb.input_scale;
-                s += cur[q];
+            const int nc = n < fb.win ? n : fb.win - 1;
+            float c = 0.f, pv = 0.f;
+            if (frames > 0) {                                    // (block-uniform: a clip shorter than one window has nothing to read)
+                c = src[nc];
+                pv = src[nc > 0 ? nc - 1 : 0];
             }
+            wn[q] = fb.window[nc];
+            const bool in = vfr && n < fb.win;
+            cur[q] = in ? (c - coff) * fb.input_scale : 0.f;
+            prev[q] = in ? (pv - coff) * fb.input_scale : 0.f;
+            s += cur[q];
         }
         const float mean = fb.remove_dc ? wave_sum(s) / (float)fb.win : 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = lane + 64 * q;
             float y = 0.f;
-            if (valid[fr] && n < fb.win) {
+            if (vfr && n < fb.win) {
                 const float c = cur[q] - mean, pv = prev[q] - mean;
-                y = (c - fb.preemph * pv) * fb.window[n];
+                y = (c - fb.preemph * pv) * wn[q];
             }
             if (fr == 0) x[q].x = y; else x[q].y = y;
         }
@@ -199,26 +210,31 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
     // ---- mel, log, affine (beats.py:159-163,323) -----------------------------------------------
     const int nm = fb.n_mels;
     const int nt = out_frames / P, nf = nm / P;
-    for (int o = lane; o < 2 * nm; o += 64) {
-        const int fr = o >= nm ? 1 : 0;
-        const int m = o - fr * nm;
-        const int f = f0 + fr;
-        if (f >= out_frames) continue;
-        float y;
-        if (f < frames) {
-            const int st = fb.mel_start[m], len = fb.mel_len[m], off = fb.mel_off[m];
-            float e = 0.f;
-            for (int t = 0; t < len; ++t) e += pw[wave][fr][st + t] * fb.mel_w[off + t];
-            y = (logf(fmaxf(e, fb.log_floor)) - fb.norm_mean) / fb.norm_div;
-        } else {
-            y = (0.f - fb.norm_mean) / fb.norm_div;      // zero-padded log-mel rows, normalised like the rest (audio_processor.py:121-135)
+    // one mel bin of BOTH frames per lane and step: the filter's taps and weights are read once for the pair (same per-frame summation
+    // order as one bin at a time: bit-identical)
+    for (int m = lane; m < nm; m += 64) {
+        const int st = fb.mel_start[m], len = fb.mel_len[m], off = fb.mel_off[m];
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < len; ++t) {
+            const float wt = fb.mel_w[off + t];
+            e0 += pw[wave][0][st + t] * wt;
+            e1 += pw[wave][1][st + t] * wt;
         }
-        if (out_f32) out_f32[((int64_t)b * out_frames + f) * nm + m] = y;
-        if (out_patch) {
-            const int tp = f / P;
-            if (tp < nt && m < nf * P) {
-                const int64_t tok = ((int64_t)b * nt + tp) * nf + m / P;
-                out_patch[(tok * P + (f % P)) * P + (m % P)] = Half<T>::from(y);
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+            const int f = f0 + fr;
+            if (f >= out_frames) continue;
+            float y;
+            if (f < frames) y = (logf(fmaxf(fr ? e1 : e0, fb.log_floor)) - fb.norm_mean) / fb.norm_div;
+            else y = (0.f - fb.norm_mean) / fb.norm_div;      // zero-padded log-mel rows, normalised like the rest (audio_processor.py:121-135)
+            if (out_f32) out_f32[((int64_t)b * out_frames + f) * nm + m] = y;
+            if (out_patch) {
+                const int tp = f / P;
+                if (tp < nt && m < nf * P) {
+                    const int64_t tok = ((int64_t)b * nt + tp) * nf + m / P;
+                    out_patch[(tok * P + (f % P)) * P + (m % P)] = Half<T>::from(y);
+                }
             }
         }
     }
