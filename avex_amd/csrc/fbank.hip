@@ -97,20 +97,26 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
         const int fsafe = vfr ? f0 + fr : (frames > 0 ? frames - 1 : 0);
         const float* src = wav + (int64_t)b * stride + (int64_t)fsafe * fb.hop;
         const float coff = clip_offset ? clip_offset[b] : 0.f;   // EAT: mono - mono.mean() (eat/audio_processor.py:107)
-        float wn[8];
+        float wn[8], cv[8], pvv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { cv[q] = 0.f; pvv[q] = 0.f; }
+        if (frames > 0) {                                        // (block-uniform: a clip shorter than one window has nothing to read)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int n = lane + 64 * q;
+                const int nc = n < fb.win ? n : fb.win - 1;
+                cv[q] = src[nc];
+                pvv[q] = src[nc > 0 ? nc - 1 : 0];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int n = lane + 64 * q;
             const int nc = n < fb.win ? n : fb.win - 1;
-            float c = 0.f, pv = 0.f;
-            if (frames > 0) {                                    // (block-uniform: a clip shorter than one window has nothing to read)
-                c = src[nc];
-                pv = src[nc > 0 ? nc - 1 : 0];
-            }
             wn[q] = fb.window[nc];
             const bool in = vfr && n < fb.win;
-            cur[q] = in ? (c - coff) * fb.input_scale : 0.f;
-            prev[q] = in ? (pv - coff) * fb.input_scale : 0.f;
+            cur[q] = in ? (cv[q] - coff) * fb.input_scale : 0.f;
+            prev[q] = in ? (pvv[q] - coff) * fb.input_scale : 0.f;
             s += cur[q];
         }
         const float mean = fb.remove_dc ? wave_sum(s) / (float)fb.win : 0.f;
