@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
-            const float inv = 1.f / l_tot;
+            const float inv = __builtin_amdgcn_rcpf(l_tot);       // (1 ulp; the quotient is rounded to 11 or 8 bits two lines below)
             T* orow = out + ((int64_t)b * Tn + qi[u]) * E + h * 64 + 8 * hh;
 #pragma unroll
             for (int oh = 0; oh < 2; ++oh) {
@@ -472,8 +472,9 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                     v4 x, y;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        x[e] = Half<T>::from((oh ? o1[u] : o0[u])[8 * gp + e] * inv);
-                        y[e] = Half<T>::from((oh ? o1[u] : o0[u])[8 * gp + 4 + e] * inv);
+                        // plain conversions: an output row is a convex combination of V rows, it cannot leave the operand type's range
+                        x[e] = (T)((oh ? o1[u] : o0[u])[8 * gp + e] * inv);
+                        y[e] = (T)((oh ? o1[u] : o0[u])[8 * gp + 4 + e] * inv);
                     }
                     a_i32x2 xi = __builtin_bit_cast(a_i32x2, x), yi = __builtin_bit_cast(a_i32x2, y);
                     int x0 = xi[0], x1 = xi[1], y0 = yi[0], y1 = yi[1];
