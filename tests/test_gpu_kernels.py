@@ -702,7 +702,7 @@ def test_effnet_b0_matches_oracle(built_lib):
     assert names == list(taps.keys()) and len(names) == 17
     r = enc.forward(_dev(mel), hook_layers=[names[0], names[3], names[-1]], want_features=True, want_pooled=True)
     assert r["features"].shape == ref.shape == (2, 1280, 2, 4)
-    # measured (scripts/effnet_tap_errors.py, f16): every tap 4e-4 .. 6e-4, features 3.5e-4, pooled 2.2e-4 -- the rounding of one layer's
+    # measured (tests/tools/effnet_tap_errors.py, f16): every tap 4e-4 .. 6e-4, features 3.5e-4, pooled 2.2e-4 -- the rounding of one layer's
     # operands; eval-mode BatchNorm renormalises every layer, so nothing accumulates over the ~50 layers (bf16: 4e-3 / 2.8e-3 / 1.8e-3)
     assert rel_l2(r["features"].cpu().numpy(), ref) < 1.2e-3
     assert rel_l2(r["pooled"].cpu().numpy(), ref.mean((2, 3))) < 8e-4

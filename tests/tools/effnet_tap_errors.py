@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Relative L2 error of every EfficientNet-B0 hook tap and of the final features against the NumPy restatement (synthetic weights)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from avex_amd import synth

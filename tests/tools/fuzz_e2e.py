@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the BEATs path against the CPU oracle: random batch sizes, clip lengths (0.2 s .. 26 s, i.e. both
 attention instantiations and the tail kernel), amplitudes, padding masks, chunk sizes, operand types and residual modes.
-    python scripts/fuzz_e2e.py [cases] [seed]
+    python tests/tools/fuzz_e2e.py [cases] [seed]
 Prints one line per case and the worst ratio to the tolerance; exits 1 on the first violation."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from avex_amd import synth, kernels as K

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised checks of the GEMM (every kernel variant and epilogue the model uses, ragged M, forced small grids) and of the attention
 kernels (random token counts on both sides of 512, heads, key padding, bias on / off, gate on / off) against fp64 / NumPy.
-    python scripts/fuzz_kernels.py [cases] [seed]"""
+    python tests/tools/fuzz_kernels.py [cases] [seed]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from avex_amd import kernels as K
