@@ -104,3 +104,33 @@ def test_graft_entry_build():
     import importlib
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_oracle_is_test_infrastructure_only():
+    """Nothing the product ships or measures with may import `oracle/`: the package, the native sources, and scripts/ (measurement
+    helpers) stay clear of it; bench.py touches it in the cpu_baseline leg only, __graft_entry__ in build() (load check) and smoke()."""
+    import ast
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+
+    def oracle_imports(path):
+        tree = ast.parse(path.read_text())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
+                hits.append(node.lineno)
+            elif isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+        return hits
+
+    for d in ("avex_amd", "scripts"):
+        for f in sorted((root / d).rglob("*.py")):
+            assert oracle_imports(f) == [], f"{f.relative_to(root)} imports the test oracle"
+    src = (root / "bench.py").read_text()
+    tree = ast.parse(src)
+    owners = {}
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
+                owners[fn.name] = node.lineno
+    assert set(owners) == {"cpu_baseline"}, owners
