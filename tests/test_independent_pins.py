@@ -100,3 +100,27 @@ def test_aves_oracle_matches_transformers_wav2vec2(layers, samples):
     rel = np.linalg.norm(ours - theirs) / np.linalg.norm(theirs)
     assert rel < 2e-5, rel
     np.testing.assert_allclose(ours, theirs, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("orig,new", [(44100, 16000), (48000, 16000), (22050, 16000), (8000, 16000), (16000, 22050)])
+def test_sinc_resampler_matches_scipy_polyphase_engine(orig, new):
+    """`oracle/ingest_oracle.resample` (torchaudio's `Resample`: a bank of `new` phase kernels applied with stride `orig`) against an
+    unrelated polyphase engine, `scipy.signal.resample_poly`, driven with torchaudio's published prototype filter sampled on the fine
+    grid of step 1 / (orig * new): tap j of phase p is prototype sample (j - width) * new - p * orig.  Checks the phase / stride /
+    offset / length bookkeeping and the edges; the filter formula itself is common to both sides."""
+    import math
+    from scipy.signal import resample_poly
+    from oracle import ingest_oracle as IO
+    g = math.gcd(orig, new)
+    o, n = orig // g, new // g
+    lpw, rolloff = 6, 0.99
+    base = min(o, n) * rolloff
+    width = math.ceil(lpw * o / base)
+    M = (width + o) * n
+    t = np.clip(np.arange(-M, M + 1, dtype=np.float64) / (o * n) * base, -lpw, lpw)
+    proto = np.sinc(t) * np.cos(t * math.pi / lpw / 2) ** 2 * (base / o)
+    x = np.random.default_rng(orig).standard_normal(5003).astype(np.float32)
+    theirs = resample_poly(x.astype(np.float64), n, o, window=proto / n)          # scipy scales an explicit filter by `up`
+    ours = IO.resample(x, orig, new)
+    assert ours.shape == theirs.shape == (math.ceil(n * 5003 / o),)
+    np.testing.assert_allclose(ours, theirs, rtol=0, atol=2e-6)
