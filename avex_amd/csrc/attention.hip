@@ -267,8 +267,11 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
 // removes the scalar transposing stores of variant 1.  The next item's Q fragment is prefetched into registers
 // during the last phase of the current one, and an item's output is stored after the next phase's DMA has been
 // issued.  The softmax uses a deferred running maximum (rescale only when a row's maximum grows by more than 2^8):
-// the reference value is subtracted inside the score FMA, so a score costs two packed FMAs, one v_exp_f32, one
-// add and half a convert.
+// the S accumulators START at gate * bias - reference (+ key mask) and the query fragment carries log2(e) / 8, so the S chain delivers
+// the exponent itself: a score costs half a packed FMA (the start), one v_exp_f32, half a packed add and half a convert.
+// A key tile is issued as four stages, each one query tile's MFMA chain with the other tile's vector work between its instructions
+// (ATT_IL, below): an MFMA waiting for the matrix pipe blocks the SIMD's vector issue for the OTHER wave, not for its own.
+// Instantiations: <T, LONG> (more than 512 tokens: query blocks of 512, bias windows per phase) x <BIAS> (no table: EAT, wav2vec2).
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void a_gptr_t;
 typedef __attribute__((address_space(3))) void a_lptr_t;
