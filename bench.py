@@ -310,7 +310,9 @@ def main():
         layer_gemms = ("gemm.qkv", "gemm.out_proj", "gemm.fc1", "gemm.fc2")
         gemm_ms = sum(ms for n, ms, fl in prof if n in layer_gemms)
         gemm_fl = sum(fl for n, ms, fl in prof if n in layer_gemms)
-        n_gemm_launch = 4 * int(cfg["encoder_layers"]) * ((B + args.chunk - 1) // args.chunk)
+        n_streams = max(1, min(4, int(os.environ.get("AVEX_AMD_STREAMS", "1") or 1)))       # (a knob, default 1: api.cpp plan_chunks)
+        eff_chunk = args.chunk if n_streams == 1 or B < 2 else min(args.chunk, (B + n_streams - 1) // n_streams)
+        n_gemm_launch = 4 * int(cfg["encoder_layers"]) * ((B + eff_chunk - 1) // eff_chunk)
         kernel_name = "gemm256_kernel" if (os.environ.get("AVEX_AMD_LN_FOLD", "0") not in ("", "0") or args.residual != "half") else "gemm256p_kernel"
         total_ms = sum(ms for _, ms, _ in prof)
         stages = {n: {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 and fl > 0 else None} for n, ms, fl in prof}
@@ -352,7 +354,7 @@ def main():
                        "parallelism": f"dp{world}", "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else None), "gathered_rows_in_clip_order": gather_check,
                        "inputs": "avex_amd.synth.noise_clips(seed=0), keyed by global clip index",
-                       "chunk_clips": args.chunk, "residual_stream": args.residual,
+                       "chunk_clips": args.chunk, "streams": max(1, min(4, int(os.environ.get("AVEX_AMD_STREAMS", "1") or 1))), "residual_stream": args.residual,
                        "dtype_note": DTYPE_NOTE,
                        "model_tflops_per_s": round(value * FLOP_PER_CLIP / 1e12, 1),
                        "model_frac_of_mfma_peak": round(value * FLOP_PER_CLIP / 1e12 / (PEAK_TFLOPS * world), 4)},
