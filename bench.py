@@ -300,6 +300,7 @@ def main():
     # ---- roofline of the dominant kernel (rank 0): HIP events around every launch, same stream ----
     roof = None
     stages = None
+    others = None
     if rank == 0 and not dry:
         enc.set_profiling(True)
         enc.forward(wav, want_features=False, want_pooled=True)
@@ -316,6 +317,27 @@ def main():
         kernel_name = "gemm256_kernel" if (os.environ.get("AVEX_AMD_LN_FOLD", "0") not in ("", "0") or args.residual != "half") else "gemm256p_kernel"
         total_ms = sum(ms for _, ms, _ in prof)
         stages = {n: {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 and fl > 0 else None} for n, ms, fl in prof}
+        # the other kernels of the step against their own bounds (same serialised HIP-event times; algorithmic bytes / flops of DESIGN.md section 4)
+        sm = {n: ms for n, ms, _ in prof}
+        sf = {n: fl for n, ms, fl in prof}
+        L, T_, E_ = int(cfg["encoder_layers"]), 496, 768
+        others = {}
+        if sm.get("attention"):
+            others["attention2_kernel"] = {"bound": "mfma", "achieved": round(sf["attention"] / sm["attention"] / 1e9, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": round(sf["attention"] / sm["attention"] / 1e9 / PEAK_TFLOPS, 4), "ms_per_step": round(sm["attention"], 3)}
+        if sm.get("posconv"):
+            others["posconv_kernel"] = {"bound": "mfma", "achieved": round(sf["posconv"] / sm["posconv"] / 1e9, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(sf["posconv"] / sm["posconv"] / 1e9 / PEAK_TFLOPS, 4), "ms_per_step": round(sm["posconv"], 3)}
+        if sm.get("layernorm") and args.residual == "half":
+            ln_bytes = (2 * L) * B * T_ * E_ * 2 * 2 + B * T_ * (512 * 4 + 512 * 2) + B * T_ * E_ * (4 + 2 + 4)       # 24 half -> half, patch LN (f32 -> f16), encoder LN
+            others["layernorm_half_kernel"] = {"bound": "hbm", "achieved": round(ln_bytes / sm["layernorm"] / 1e9, 2), "peak": 8.0, "unit": "TB/s",
+                                               "frac": round(ln_bytes / sm["layernorm"] / 1e9 / 8.0, 4), "ms_per_step": round(sm["layernorm"], 3),
+                                               "note": "read + write mix; torch's device-to-device copy reaches 5.3 TB/s on this board (scripts/hbm_bw.py)"}
+        if sm.get("fbank"):
+            fb_bytes = B * (SAMPLES * 4 + 992 * 128 * 2)
+            others["fbank_kernel"] = {"bound": "hbm", "achieved": round(fb_bytes / sm["fbank"] / 1e9, 2), "peak": 8.0, "unit": "TB/s",
+                                      "frac": round(fb_bytes / sm["fbank"] / 1e9 / 8.0, 4), "ms_per_step": round(sm["fbank"], 3),
+                                      "note": "vector-instruction-bound (898 W, full clock): profiles/r02f_fbank_stages.txt"}
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
         traffic = None     # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (scripts/collect_profiles.sh)
         import glob
@@ -358,7 +380,7 @@ def main():
                        "dtype_note": DTYPE_NOTE,
                        "model_tflops_per_s": round(value * FLOP_PER_CLIP / 1e12, 1),
                        "model_frac_of_mfma_peak": round(value * FLOP_PER_CLIP / 1e12 / (PEAK_TFLOPS * world), 4)},
-            "roofline": roof, "stages_ms": stages,
+            "roofline": roof, "other_kernels": others, "stages_ms": stages,
         }
         if dry:
             line["data"] = "cpu dry run (control flow only, not a measurement)"
