@@ -13,7 +13,7 @@ are registered on the module exactly like ``nn.Module.__call__`` would.
 from __future__ import annotations
 
 import logging
-from typing import Any, Dict, List, Optional, Union
+from typing import Any, Dict, List, Mapping, Optional, Union
 
 import torch
 import torch.nn as nn
@@ -21,6 +21,30 @@ import torch.nn as nn
 from .configs import AudioConfig
 
 logger = logging.getLogger(__name__)
+
+
+def coerce_audio_config(audio_config: Any) -> Optional[AudioConfig]:
+    """This package's ``AudioConfig`` from whatever a caller hands to a model constructor.
+
+    The reference's factory passes ITS OWN pydantic ``avex.configs.AudioConfig`` (factory.py:132-143), YAML loaders pass
+    mappings, and callers of this package pass ``avex_amd.configs.AudioConfig``: all three carry the same fields.  Foreign
+    objects are read through ``model_dump()`` (pydantic v2), ``dict()`` (v1) or their attributes; fields this package does
+    not know are dropped (the schema here is the reference's field list), a missing field keeps its default."""
+    if audio_config is None or isinstance(audio_config, AudioConfig):
+        return audio_config
+    if isinstance(audio_config, Mapping):
+        return AudioConfig(**audio_config)          # a mapping is validated strictly (unknown keys are an error, as in the reference)
+    fields = AudioConfig.model_fields
+    for getter in ("model_dump", "dict"):
+        fn = getattr(audio_config, getter, None)
+        if callable(fn):
+            data = fn()
+            if isinstance(data, Mapping):
+                return AudioConfig(**{k: v for k, v in data.items() if k in fields})
+    data = {k: getattr(audio_config, k) for k in fields if hasattr(audio_config, k)}
+    if not data:
+        raise TypeError(f"audio_config must be an AudioConfig, a mapping or an object with its fields, got {type(audio_config).__name__}")
+    return AudioConfig(**data)
 
 
 class AudioProcessor:
@@ -70,10 +94,12 @@ class ModelBase(nn.Module):
     """Hook registry + generic ``extract_embeddings`` + ``process_audio``."""
 
     def __init__(self, device: str, audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None) -> None:
-        super().__init__()
+        # nn.Module's initialiser by name, not super(): the reference-side binding (INTEGRATION.md section 2) lists the
+        # reference's own ModelBase as a second base so that its isinstance checks hold (registry.py:695), and that class's
+        # __init__(device, audio_config) must not run a second time behind this one in the MRO
+        nn.Module.__init__(self)
         self.device = device          # a plain str, deliberately NOT updated by .to() (reference behaviour)
-        if audio_config is not None and not isinstance(audio_config, AudioConfig):
-            audio_config = AudioConfig(**audio_config)
+        audio_config = coerce_audio_config(audio_config)
         self.audio_processor = AudioProcessor(audio_config) if audio_config else None
         self._hooks: Dict[str, torch.utils.hooks.RemovableHandle] = {}
         self._hook_outputs: Dict[str, torch.Tensor] = {}

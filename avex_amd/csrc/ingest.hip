@@ -221,6 +221,7 @@ extern "C" int avexhip_resample_forward(const avexhip_resample_plan* p, const fl
     const int64_t n_out = avexhip_resample_out_length(p, T);
     if (x_stride <= 0) x_stride = T;
     if (out_stride <= 0) out_stride = n_out;
+    AVX_REQUIRE(B == 1 || x_stride >= T, "resample_forward: x_stride %lld < %lld input samples (rows would overlap)", (long long)x_stride, (long long)T);
     AVX_REQUIRE(out_stride >= n_out, "resample_forward: out_stride %lld < %lld output samples", (long long)out_stride, (long long)n_out);
     if (p->interp) {
         const int64_t n_res = (int64_t)((double)T * p->ratio);

@@ -39,9 +39,18 @@ def parse_wav(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int, i
         cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
         body = data[pos + 8: pos + 8 + size]
         if cid == b"fmt ":
-            tag, ch, sr, _br, _ba, bits = struct.unpack_from("<HHIIHH", body, 0)
-            if tag == 0xFFFE and len(body) >= 26:                       # WAVE_FORMAT_EXTENSIBLE: the real tag is in the sub-format GUID
+            if len(body) < 16:
+                raise ValueError(f"WAVE fmt chunk of {len(body)} bytes (at least 16 expected)")
+            tag, ch, sr, _br, block_align, bits = struct.unpack_from("<HHIIHH", body, 0)
+            if tag == 0xFFFE:                                           # WAVE_FORMAT_EXTENSIBLE: the real tag is in the sub-format GUID
+                if len(body) < 26:
+                    raise ValueError(f"WAVE_FORMAT_EXTENSIBLE fmt chunk of {len(body)} bytes (at least 26 expected)")
                 tag = struct.unpack_from("<H", body, 24)[0]
+            if ch <= 0 or sr <= 0:
+                raise ValueError(f"WAVE fmt chunk with {ch} channels at {sr} Hz")
+            if bits % 8 or block_align != ch * bits // 8:
+                raise ValueError(f"WAVE fmt chunk: block_align {block_align} is not channels x bytes per sample ({ch} x {bits} bits); "
+                                 "padded containers are not decoded here")
             fmt = (tag, ch, sr, bits)
         elif cid == b"data":
             payload = body
@@ -56,7 +65,7 @@ def parse_wav(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int, i
     else:
         raise ValueError(f"unsupported WAVE encoding (format tag {tag}, {bits} bits)")
     frame_bytes = ch * bits // 8
-    n = len(payload) // frame_bytes
+    n = len(payload) // frame_bytes                                     # a truncated last frame is dropped
     return np.frombuffer(payload, dtype=np.uint8, count=n * frame_bytes), sr, ch, code
 
 

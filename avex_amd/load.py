@@ -17,8 +17,8 @@ from pathlib import Path
 from typing import Optional, Union
 
 from . import registry
-from .base_model import ModelBase
-from .configs import AudioConfig, ModelSpec
+from .base_model import ModelBase, coerce_audio_config
+from .configs import ModelSpec
 from .weights import classifier_out_features, is_remote, load_checkpoint_file, load_into
 
 logger = logging.getLogger(__name__)
@@ -29,9 +29,7 @@ def build_model_from_spec(model_spec: ModelSpec, device: str, **kwargs: object) 
     if cls is None:
         raise KeyError(f"Model class '{model_spec.name}' is not registered. "
                        f"Available classes: {registry.list_model_classes()}")
-    audio_config = model_spec.audio_config
-    if audio_config is not None and not isinstance(audio_config, AudioConfig):
-        audio_config = AudioConfig(**audio_config)
+    audio_config = coerce_audio_config(model_spec.audio_config)     # a reference ModelSpec carries the reference's own AudioConfig
     init = {"device": device, "audio_config": audio_config, **kwargs}
     for field in ModelSpec.FORWARDED:
         value = getattr(model_spec, field, None)

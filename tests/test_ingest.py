@@ -47,6 +47,22 @@ def test_parse_wav_and_oracle_decoding():
     assert (sr, ch, code) == (8000, 1, 64) and np.allclose(IO.pcm_to_mono(raw, ch, code), x[:, 0], atol=1e-7)
     with pytest.raises(ValueError):
         ingest.parse_wav(b"fLaC" + b"\\0" * 64)
+    # malformed headers are ValueError, never struct.error / ZeroDivisionError
+    good = _wav_bytes(x, 44100, 2)
+    fmt_at = good.index(b"fmt ") + 8
+
+    def patched(off, fmtc, *vals):
+        b = bytearray(good)
+        struct.pack_into(fmtc, b, fmt_at + off, *vals)
+        return bytes(b)
+    for bad in (patched(2, "<H", 0),                      # zero channels
+                patched(4, "<I", 0),                      # zero sample rate
+                patched(12, "<H", 6),                     # block_align that is not channels x bytes per sample
+                patched(14, "<H", 12),                    # a width that is not whole bytes
+                good[:fmt_at - 4] + struct.pack("<I", 8) + good[fmt_at:fmt_at + 8] + good[fmt_at + 16:],      # fmt chunk of 8 bytes
+                patched(0, "<H", 0xFFFE)):                # WAVE_FORMAT_EXTENSIBLE tag on a 16-byte fmt chunk
+        with pytest.raises(ValueError):
+            ingest.parse_wav(bad)
 
 
 def test_oracle_resampler_properties():
