@@ -187,8 +187,8 @@ def run() -> dict:
         lm.deregister_all_hooks()
 
         # ---- probes (probes/utils/factory.py:56-186; base_probes.py:23-195)
-        if dim is None:                                     # EfficientNet: 4-D taps; width of the last hooked conv
-            dim, tokens = 1280, 1
+        if dim is None:                                     # EfficientNet: the last hooked conv gives (B, 1280, 4, 32) for a 10 s clip; "mean" is
+            dim, tokens = 1280 * 4, 1                       # mean(dim=-1) then view(B, -1) (efficientnet.py:297-311): 1280 x 4 columns
         fam["probe_linear_mean"] = _probe_step(avex, lm, dict(probe_type="linear", target_layers=["last_layer"], aggregation="mean",
                                                              freeze_backbone=True), dim, tokens)
         if key in ("beats_hip", "aves_hip"):

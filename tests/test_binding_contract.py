@@ -106,7 +106,7 @@ def test_probe_factory_call_sequence(contract):
             assert p["model_training_after"] is False and p["requires_grad_any"] is False                               # frozen backbone (base_probes.py:47-53)
             assert p["logits_shape"] == [2, 5]
             if name != "probe_attention_none":
-                assert p["inferred_dim"] == (1280 if key == "efficientnet_hip" else 768) * len(p["resolved_layers"])
+                assert p["inferred_dim"] == (5120 if key == "efficientnet_hip" else 768) * len(p["resolved_layers"])
             # extract_embeddings of the mirror takes exactly these keywords
             sig = inspect.signature(registry.get_model_class(MIRROR[key]).extract_embeddings).parameters
             assert set(f["keywords"]) <= set(sig), key

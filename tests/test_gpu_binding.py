@@ -68,7 +68,7 @@ def test_reference_call_sequence_with_real_forwards(built_lib, contract, key):
             dummy = torch.randn(1, L, device="cuda")
             emb = m.extract_embeddings(dummy, **c["keywords"])
         n = len(p["resolved_layers"])
-        width = 1280 if key == "efficientnet_hip" else 768
+        width = 5120 if key == "efficientnet_hip" else 768      # (B, 1280, 4, 32) -> mean(-1) -> view(B, 5120) (efficientnet.py:297-311)
         if c["keywords"]["aggregation"] == "none":
             assert isinstance(emb, torch.Tensor) and emb.dim() == 3 and emb.shape[0] == 1 and emb.shape[2] == width
         else:
