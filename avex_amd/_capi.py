@@ -38,9 +38,10 @@ class GemmArgs(C.Structure):
                 ("resid_half", C.c_void_p), ("ldrh", C.c_int64), ("gelu", C.c_int32), ("out_f32", C.c_void_p), ("ldo", C.c_int64),
                 ("out_half", C.c_void_p), ("ldh", C.c_int64), ("out_raw", C.c_void_p), ("ldraw", C.c_int64),
                 ("variant", C.c_int32),
-                ("ln_stats", C.c_void_p), ("ln_nseg", C.c_int32), ("ln_eps", C.c_float), ("ln_s", C.c_void_p),
-                ("lnr_y", C.c_void_p), ("ldy", C.c_int64), ("lnr_stats", C.c_void_p), ("lnr_nseg", C.c_int32),
-                ("lnr_gamma", C.c_void_p), ("lnr_beta", C.c_void_p), ("stats_out", C.c_void_p)]
+                ("ln_rows", C.c_void_p), ("ln_s", C.c_void_p),
+                ("lnr_y", C.c_void_p), ("ldy", C.c_int64), ("lnr_rows", C.c_void_p),
+                ("lnr_gamma", C.c_void_p), ("lnr_beta", C.c_void_p), ("stats_out", C.c_void_p),
+                ("overflow_count", C.c_void_p)]
 
 
 class BeatsConfig(C.Structure):
@@ -96,6 +97,7 @@ SYMBOLS = {
     "avexhip_cast_f32_to_half": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_cast_half_to_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _P]),
+    "avexhip_ln_rowstats": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, _P, _P]),
     "avexhip_layernorm": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P,
                                     C.c_int64, C.c_int, _P]),
     "avexhip_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
@@ -111,6 +113,8 @@ SYMBOLS = {
                                         C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "avexhip_beats_forward_fbank": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint32, C.POINTER(_P), C.c_int,
                                               _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_beats_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
+    "avexhip_beats_overflow_reset": (C.c_int, [_P, _P]),
     "avexhip_beats_set_profiling": (C.c_int, [_P, C.c_int]),
     "avexhip_beats_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
                                              C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]),

@@ -137,11 +137,12 @@ class Model(ModelBase):
                  audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None, return_features_only: bool = False,
                  use_naturelm: bool = False, fine_tuned: bool = False, disable_layerdrop: bool = False,
                  init_config: Optional[Dict[str, Any]] = None, operand_dtype: Optional[str] = None,
-                 max_chunk_clips: int = 0, residual: Optional[str] = None) -> None:
+                 max_chunk_clips: int = 0, residual: Optional[str] = None, on_overflow: Optional[str] = None) -> None:
         super().__init__(device=device, audio_config=audio_config)
         if num_classes is None:
             return_features_only = True
         self.num_classes = num_classes
+        self.on_overflow = on_overflow                  # f16 range alarm policy: "warn" (default) / "raise" / "retry" / "ignore" (kernels.BeatsEncoder)
         self.disable_layerdrop = disable_layerdrop      # inference never drops layers; kept for API parity
         self.use_naturelm = bool(use_naturelm)
         self.fine_tuned = bool(fine_tuned)
@@ -196,9 +197,13 @@ class Model(ModelBase):
             with torch.cuda.device(p.device):
                 state = {k: v for k, v in self.state_dict().items() if k.startswith("backbone.")}
                 self._encoder = kernels.BeatsEncoder(self.beats_cfg, state, operand_dtype=self.operand_dtype,
-                                                     max_chunk_clips=self.max_chunk_clips, residual=self.residual)
+                                                     max_chunk_clips=self.max_chunk_clips, residual=self.residual, on_overflow=self.on_overflow)
             self._weights_dirty = False
         return self._encoder
+
+    def overflow_events(self) -> int:
+        """How many lanes have clipped a value to the f16 range in this model's forwards so far (0: none; see ``on_overflow``)."""
+        return 0 if self._encoder is None else self._encoder.overflow_events(sync=True)
 
     # ------------------------------------------------------------------ layers
     def _discover_embedding_layers(self) -> None:

@@ -47,9 +47,10 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     AVX_REQUIRE(a, "gemm: null args");
     avx::GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.ln_stats = a->ln_stats; g.ln_nseg = a->ln_nseg; g.ln_eps = a->ln_eps; g.ln_s = a->ln_s;
-    g.lnr_y = a->lnr_y; g.ldy = (int)a->ldy; g.lnr_stats = a->lnr_stats; g.lnr_nseg = a->lnr_nseg;
+    g.ln_rows = a->ln_rows; g.ln_s = a->ln_s;
+    g.lnr_y = a->lnr_y; g.ldy = (int)a->ldy; g.lnr_rows = a->lnr_rows;
     g.lnr_gamma = a->lnr_gamma; g.lnr_beta = a->lnr_beta; g.stats_out = a->stats_out;
+    g.ovf = a->overflow_count;
     g.A = a->A; g.lda = a->lda; g.W = a->W; g.ldw = a->ldw;
     g.M = a->M; g.N = a->N; g.K = a->K;
     g.bias = a->bias; g.resid = a->resid; g.ldr = a->ldr; g.alpha = a->alpha; g.gelu = a->gelu;
@@ -57,6 +58,9 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     g.out_f32 = a->out_f32; g.ldo = a->ldo; g.out_half = a->out_half; g.ldh = a->ldh;
     g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
     return avx::gemm(g, dtype, (hipStream_t)stream);
+}
+extern "C" int avexhip_ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, void* stream) {
+    return avx::ln_rowstats(stats, M, nseg, eps, rows, (hipStream_t)stream);
 }
 
 namespace avx {
@@ -159,6 +163,10 @@ struct Layer {
     // LayerNorm-folded copies (see GemmArgs): fc1 consumes LN1 of this layer, QKV consumes LN2 of the previous layer
     void* w_fc1_f = nullptr; float* b_fc1_f = nullptr; float* s_fc1 = nullptr;
     void* w_qkv_f = nullptr; float* b_qkv_f = nullptr; float* s_qkv = nullptr;
+    // residual-side folds (GemmArgs::lnr_prefolded): fc2 adds alpha * LN1(y1) of this layer, out_proj alpha * LN2(y2) of the previous layer;
+    // ga = alpha * gamma, bb = bias + alpha * beta
+    float* ga_fc2 = nullptr; float* bb_fc2 = nullptr;
+    float* ga_o = nullptr; float* bb_o = nullptr;
 };
 
 struct StageRec {
@@ -223,6 +231,10 @@ struct avexhip_beats {
     std::vector<float> rel_table;  // host [num_buckets, H]; empty if no relative position embedding
     std::map<int, float*> bias_tabs;
     std::vector<void*> allocs;
+    // range alarm of the f16 conversions (GemmArgs::ovf): device counter every GEMM of a forward adds to, mirrored to pinned host
+    // memory by an asynchronous copy at the end of each forward (read without a synchronisation by avexhip_beats_overflow_count)
+    unsigned int* d_ovf = nullptr;
+    unsigned int* h_ovf = nullptr;
     bool profiling = false;
     std::vector<StageRec> recs;
     std::vector<std::string> prof_names;
@@ -233,6 +245,8 @@ struct avexhip_beats {
     ~avexhip_beats() {
         for (void* p : allocs) (void)hipFree(p);
         for (auto& kv : bias_tabs) (void)hipFree(kv.second);
+        if (d_ovf) (void)hipFree(d_ovf);
+        if (h_ovf) (void)hipHostFree(h_ovf);
         if (fb) avexhip_fbank_plan_destroy(fb);
         for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (int i = 0; i < 3; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
@@ -459,6 +473,19 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
         RC(dev_f32(h, tb, p + "final_layer_norm.weight", E, &ly.ln2_w));
         RC(dev_f32(h, tb, p + "final_layer_norm.bias", E, &ly.ln2_b));
         if (h->ln_fold) {
+            auto two = [&](float** ga, float** bb) -> int {
+                AVX_HIP_CHECK(hipMalloc((void**)ga, sizeof(float) * 2 * (size_t)E));
+                h->allocs.push_back(*ga);
+                *bb = *ga + E;
+                return AVEXHIP_OK;
+            };
+            RC(two(&ly.ga_fc2, &ly.bb_fc2));
+            RC(avx::lnr_fold(ly.ln1_w, ly.ln1_b, ly.b_fc2, h->alpha, E, ly.ga_fc2, ly.bb_fc2, nullptr));
+            if (i > 0) {
+                const Layer& prev = h->layers[i - 1];
+                RC(two(&ly.ga_o, &ly.bb_o));
+                RC(avx::lnr_fold(prev.ln2_w, prev.ln2_b, ly.b_o, h->alpha, E, ly.ga_o, ly.bb_o, nullptr));
+            }
             std::vector<float> Wh, bh;
             RC(host_f32(tb, p + "fc1.weight", (int64_t)F * E, Wh));
             RC(host_f32(tb, p + "fc1.bias", F, bh));
@@ -514,6 +541,7 @@ int bias_tab_for(avexhip_beats* h, int T, float** out) {
 struct Ws {
     char* patches; float* f0; char* h0; float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
     float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
+    float* r1; float* r2;     // ... reduced to (rstd, -mu rstd) per row by avx::ln_rowstats
     size_t total;
 };
 
@@ -536,6 +564,8 @@ Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
     w.raw = (float*)take(M * h->E * 4);
     w.st1 = (float*)take(h->ln_fold ? M * (h->E / 64) * 8 : 256);
     w.st2 = (float*)take(h->ln_fold ? M * (h->E / 64) * 8 : 256);
+    w.r1 = (float*)take(h->ln_fold ? (M + 256) * 8 : 256);
+    w.r2 = (float*)take(h->ln_fold ? (M + 256) * 8 : 256);
     w.total = off;
     return w;
 }
@@ -663,7 +693,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         void* preh = fast ? w.preh : nullptr;
         const bool hook0 = (hook_mask & 1u) != 0;
         avx::GemmArgs g;
-        memset(&g, 0, sizeof(g));
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.patches; g.lda = P * P; g.W = h->w_patch; g.ldw = P * P; g.M = M; g.N = D; g.K = P * P;
         if (fast) { g.out_half = w.h0; g.ldh = D; } else { g.out_f32 = w.f0; g.ldo = D; }
         prof.begin("gemm.patch_embed", 2.0 * Md * D * P * P);
@@ -678,7 +708,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         }
         prof.end();
         if (h->w_post) {
-            memset(&g, 0, sizeof(g));
+            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.h0; g.lda = D; g.W = h->w_post; g.ldw = D; g.M = M; g.N = E; g.K = D; g.bias = h->b_post;
             g.out_half = w.xh; g.ldh = E; g.row_zero = pad;
             if (!fast || hook0) { g.out_f32 = x32; g.ldo = E; }
@@ -710,17 +740,17 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             const Layer& ly = h->layers[i];
             const bool raw_in = fold && i > 0;      // xh holds y2 of layer i-1 (raw) instead of its LayerNorm
             const Layer* pl = i > 0 ? &h->layers[i - 1] : nullptr;
-            memset(&g, 0, sizeof(g));
+            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
             g.out_half = w.qkv; g.ldh = 3 * E;
-            if (raw_in) { g.W = ly.w_qkv_f; g.bias = ly.b_qkv_f; g.ln_stats = w.st2; g.ln_nseg = nseg; g.ln_eps = 1e-5f; g.ln_s = ly.s_qkv; }
+            if (raw_in) { g.W = ly.w_qkv_f; g.bias = ly.b_qkv_f; g.ln_rows = w.r2; g.ln_s = ly.s_qkv; }
             prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
             RC(avx::gemm(g, dt, cs));
             prof.end();
             prof.begin("attention", 4.0 * Md * Tt * E + 2.0 * Md * 8 * (E / H) * H);
             RC(avx::attention(w.qkv, Bc, Tt, H, bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, pad, w.ah, dt, cs));
             prof.end();
-            memset(&g, 0, sizeof(g));
+            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = h->alpha;
             if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
             else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
@@ -728,33 +758,38 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
                 g.stats_out = w.st1;
                 if (raw_in) {
                     g.resid_half = nullptr; g.ldrh = 0;
-                    g.lnr_y = w.xh; g.ldy = E; g.lnr_stats = w.st2; g.lnr_nseg = nseg; g.lnr_gamma = pl->ln2_w; g.lnr_beta = pl->ln2_b; g.ln_eps = 1e-5f;
+                    g.lnr_y = w.xh; g.ldy = E; g.lnr_rows = w.r2; g.lnr_gamma = ly.ga_o; g.lnr_beta = ly.bb_o; g.lnr_prefolded = 1;
                 }
             }
             prof.begin("gemm.out_proj", 2.0 * Md * E * E);
             RC(avx::gemm(g, dt, cs));
             prof.end();
+            if (fold) {
+                prof.begin("ln_rowstats", 0.0);
+                RC(avx::ln_rowstats(w.st1, M, nseg, 1e-5f, w.r1, cs));
+                prof.end();
+            }
             if (!fold) {
                 prof.begin("layernorm", 0.0);
                 RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
                 prof.end();
             }
-            memset(&g, 0, sizeof(g));
+            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
             g.out_half = w.hh; g.ldh = F;
-            if (fold) { g.A = preh; g.W = ly.w_fc1_f; g.bias = ly.b_fc1_f; g.ln_stats = w.st1; g.ln_nseg = nseg; g.ln_eps = 1e-5f; g.ln_s = ly.s_fc1; }
+            if (fold) { g.A = preh; g.W = ly.w_fc1_f; g.bias = ly.b_fc1_f; g.ln_rows = w.r1; g.ln_s = ly.s_fc1; }
             prof.begin("gemm.fc1", 2.0 * Md * F * E);
             RC(avx::gemm(g, dt, cs));
             prof.end();
             const bool hooked = (hook_mask >> (i + 1)) & 1u;
-            memset(&g, 0, sizeof(g));
+            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = h->alpha;
             if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
             else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
             if (fold) {   // residual = LN1(y1) on the fly; y2 (raw) goes to xh, which nothing reads any more in this layer
                 g.resid_half = nullptr; g.ldrh = 0;
-                g.lnr_y = preh; g.ldy = E; g.lnr_stats = w.st1; g.lnr_nseg = nseg; g.lnr_gamma = ly.ln1_w; g.lnr_beta = ly.ln1_b; g.ln_eps = 1e-5f;
-                g.out_half = w.xh; g.stats_out = w.st2;
+                g.lnr_y = preh; g.ldy = E; g.lnr_rows = w.r1; g.lnr_gamma = ly.ga_fc2; g.lnr_beta = ly.bb_fc2; g.lnr_prefolded = 1;
+                g.out_half = w.xh; g.stats_out = (i + 1 < L) ? w.st2 : nullptr;      // the last layer's y2 goes to a LayerNorm kernel that takes its own statistics
             }
             if (hooked) {
                 g.out_raw = hook_pooled ? w.raw : hook_out[i + 1] + (size_t)c0 * Tt * E;
@@ -765,15 +800,20 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
             prof.end();
             if (hooked && hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, hook_out[i + 1] + (size_t)c0 * E, cs));
             const bool last = i == L - 1;
+            if (fold && !last) {
+                prof.begin("ln_rowstats", 0.0);
+                RC(avx::ln_rowstats(w.st2, M, nseg, 1e-5f, w.r2, cs));
+                prof.end();
+            }
             // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
             float* xo = nullptr;
             if (last) xo = features_out ? features_out + (size_t)c0 * Tt * E : ((pooled_out || !fast) ? x32 : nullptr);
             else if (!fast) xo = x32;
             // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
-            const bool fused_pool = last && pooled_out && !features_out && !fold && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
-            if (fused_pool) {
+            const bool fused_pool = last && pooled_out && !features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
+            if (fused_pool) {      // the pre-LayerNorm sums y2 sit in preh, with the fold in xh
                 prof.begin("layernorm+mean_pool", 0.0);
-                RC(avx::layernorm_pool(preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, Bc, Tt, E, pooled_out + (size_t)c0 * E, dt, cs));
+                RC(avx::layernorm_pool(fold ? w.xh : preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, Bc, Tt, E, pooled_out + (size_t)c0 * E, dt, cs));
                 prof.end();
             } else if (!fold) {
                 prof.begin("layernorm", 0.0);
@@ -809,6 +849,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     }
     }   // rounds
 #undef RC
+    if (h->d_ovf && h->h_ovf) AVX_HIP_CHECK(hipMemcpyAsync(h->h_ovf, h->d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     if (h->profiling) {
         AVX_HIP_CHECK(hipStreamSynchronize(s));
         std::map<std::string, std::pair<double, double>> agg;  // name -> (ms, flops)
@@ -900,6 +941,13 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
             return nullptr;
         }
     }
+    if (hipMalloc((void**)&h->d_ovf, sizeof(unsigned int)) != hipSuccess || hipMemset(h->d_ovf, 0, sizeof(unsigned int)) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_ovf, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
+        avexhip_set_error("beats_create: cannot allocate the range-alarm counter");
+        delete h;
+        return nullptr;
+    }
+    *h->h_ovf = 0;
     h->alpha = c.deep_norm ? powf(2.0f * (float)c.encoder_layers, 0.25f) : 1.0f;
     if (build(h, tensors, n_tensors) != AVEXHIP_OK) {
         delete h;
@@ -943,6 +991,20 @@ extern "C" int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank,
     AVX_REQUIRE(B > 0 && frames > 0, "beats_forward_fbank: empty input");
     return forward_impl(h, nullptr, fbank, B, 0, 0, frames, frame_pad, hook_mask, hook_out, hook_pooled, features_out, pooled_out,
                         workspace, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int avexhip_beats_overflow_count(avexhip_beats* h, uint32_t* events, void* sync_stream, int synchronize) {
+    AVX_REQUIRE(h && events, "overflow_count: null argument");
+    if (synchronize) AVX_HIP_CHECK(hipStreamSynchronize((hipStream_t)sync_stream));
+    *events = h->h_ovf ? *(volatile unsigned int*)h->h_ovf : 0u;
+    return AVEXHIP_OK;
+}
+
+extern "C" int avexhip_beats_overflow_reset(avexhip_beats* h, void* stream) {
+    AVX_REQUIRE(h, "overflow_reset: null handle");
+    AVX_HIP_CHECK(hipMemsetAsync(h->d_ovf, 0, sizeof(unsigned int), (hipStream_t)stream));
+    AVX_HIP_CHECK(hipMemcpyAsync(h->h_ovf, h->d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return AVEXHIP_OK;
 }
 
 extern "C" int avexhip_beats_set_profiling(avexhip_beats* h, int enabled) {

@@ -32,6 +32,28 @@ template <> struct Half<__bf16> {
     static __device__ __forceinline__ __bf16 from(float x) { return (__bf16)x; }
 };
 
+// Range alarm of the f16 outputs (Half<_Float16>::from saturates silently): a kernel keeps the running max of |value| over
+// everything a lane rounds to f16 (v_max3_f32 with |.| modifiers: half a VALU slot per element) and commits once at its end.
+template <typename T> static __device__ __forceinline__ void ovf_see(float& mx, float a, float b) {
+    if constexpr (sizeof(T) == 2 && __is_same(T, _Float16)) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a)), __builtin_fabsf(b));
+}
+template <typename T> static __device__ __forceinline__ void ovf_see4(float& mx, f32x4 v) {
+    ovf_see<T>(mx, v[0], v[1]);
+    ovf_see<T>(mx, v[2], v[3]);
+}
+// a wave's lanes whose running max left the f16 range, as a (wave-uniform) mask to OR into a scalar that lives across a kernel's main
+// loop in SGPRs (a VGPR kept alive through a 256-register MFMA loop would spill)
+template <typename T> static __device__ __forceinline__ unsigned long long ovf_mask(float mx) {
+    if constexpr (__is_same(T, _Float16)) return __ballot(mx > 65504.0f);
+    return 0ull;
+}
+template <typename T> static __device__ __forceinline__ void ovf_commit(unsigned int* ctr, unsigned long long mask) {
+    if constexpr (__is_same(T, _Float16)) {
+        if (ctr != nullptr && mask != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1) atomicAdd(ctr, (unsigned int)__popcll(mask));
+    }
+}
+template <typename T> static __device__ __forceinline__ void ovf_commit(unsigned int* ctr, float mx) { ovf_commit<T>(ctr, ovf_mask<T>(mx)); }
+
 static __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -214,30 +236,35 @@ struct GemmArgs {
     float* out_raw; int64_t ldraw;
     const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to every output
     int variant;
-    // ---- LayerNorm folded into the GEMMs around it (256-tile kernel, variant 2 only) ---------------------------------
-    // A tensor y that is only ever consumed through LayerNorm is kept RAW in the operand type together with per-row
-    // partial statistics [M][nseg][2] = (sum, sum of squares) of each 64-column segment (written by the GEMM that produced y).
+    // ---- LayerNorm folded into the GEMMs around it (256-tile streaming kernel) --------------------------------------
+    // A tensor y that is only ever consumed through LayerNorm is kept RAW in the operand type.  The GEMM that produces y writes
+    // per-row partial statistics [M][N/64][2] = (sum, sum of squares) of each 64-column segment (stats_out); avx::ln_rowstats
+    // reduces them, in a fixed order, to one (rstd, -mu * rstd) pair per row; the consumers take those pairs:
     //  * consumer of LN(y) as its A operand:  A = y, W = W * diag(gamma) (folded by the caller), ln_s[n] = sum_k W'[n][k],
-    //    bias = b + W beta;  the epilogue forms  rstd[m] * (acc - mu[m] * ln_s[n]) + bias[n]  before GELU / rounding;
-    //  * consumer of LN(y) as its residual:  out = alpha * ((y - mu) * rstd * gamma + beta) + acc + bias;
-    //  * producer: stats_out receives the partial statistics of the rows it writes (from the ROUNDED outputs).
-    const float* ln_stats;    // consumer-as-A: statistics of the A rows, or NULL
-    int ln_nseg;              // segments per row (row width = 64 * ln_nseg)
-    float ln_eps;
+    //    bias = b + W beta;  the epilogue forms  rstd[m] * acc + ((-mu rstd)[m] * ln_s[n] + bias[n])  before GELU / rounding;
+    //  * consumer of LN(y) as its residual:  out = alpha * ((y * rstd - mu rstd) * gamma + beta) + acc + bias;
+    //  * producer: stats_out receives the partial statistics of the rows it writes (from the fp32 values before rounding).
+    const float* ln_rows;     // consumer-as-A: [M rounded up to 256][2] (rstd, -mu * rstd) of the A rows, or NULL
     const float* ln_s;        // [N]
     const void* lnr_y;        // consumer-as-residual: raw residual rows (half), or NULL
     int ldy;
-    const float* lnr_stats;   // [M][lnr_nseg][2]
-    int lnr_nseg;
+    const float* lnr_rows;    // [M][2] (rstd, -mu * rstd) of the residual rows
     const float* lnr_gamma;   // [N]
     const float* lnr_beta;    // [N]
+    int lnr_prefolded;        // lnr_gamma holds alpha * gamma and lnr_beta holds alpha * beta + bias (what the kernel takes; avx::lnr_fold makes them).
+                              // avx::gemm folds per launch when the flag is clear; callers that launch the same fold repeatedly keep the vectors
     float* stats_out;         // [M][N/64][2] or NULL
-    int tile_order;           // 256-tile kernel: 0 = grouped walk (default), 1 = row-major (A/B experiments)
-    int stagger_ticks;        // variant 5: workgroups of odd slot start this many 10-ns ticks late (desynchronised epilogues)
-    int stagger_groups;       // variant 5: number of start phases (>= 1)
+    // sticky range alarm: the number of (lane, launch) pairs that rounded at least one |value| > 65504 to an f16 output is added
+    // here (one atomic per wave at most, at the end of the kernel); NULL = not counted.  bf16 outputs cannot overflow.
+    unsigned int* ovf;
+    int tile_order;           // 256-tile kernel: 0 = grouped walk where K < 2048 (default), 1 = row-major, >= 2 = grouped walk with that many row panels per group
     int nt;                   // set by the launcher: bit 0 non-temporal output stores (256-tile kernels)
 };
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
+// partial statistics [M][nseg][2] (GemmArgs::stats_out) -> [M][2] (rstd, -mu * rstd), summed in segment order (deterministic)
+int ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, hipStream_t s);
+// ga = alpha * gamma, bb = bias + alpha * beta: the column vectors a residual-side fold takes (GemmArgs::lnr_prefolded)
+int lnr_fold(const float* gamma, const float* beta, const float* bias, float alpha, int N, float* ga, float* bb, hipStream_t s);
 // exactly one of in / in_half is non-null
 int layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int M,
               int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s);

@@ -398,9 +398,49 @@ __global__ __launch_bounds__(256) void row_sum_half_kernel(const T* __restrict__
     if (lane == 0) out[row] = s;
 }
 
+// Folded LayerNorm (GemmArgs): per-row partial statistics [M][nseg][2] = (sum, sum of squares) of the 64-column segments of a raw
+// tensor y, written by the epilogue that produced y  ->  one (rstd, -mu * rstd) pair per row, LN(y) = y * rstd + (-mu rstd) (times
+// gamma, plus beta).  One thread per row, the segments added in order (bit-reproducible); 96 bytes read and 8 written per row.
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const float* __restrict__ stats, int M, int nseg, float eps, float* __restrict__ rows) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const f32x4* src = (const f32x4*)(stats + (int64_t)m * nseg * 2);      // nseg is even (launcher)
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < (nseg >> 1); ++q) { const f32x4 v = src[q]; s1 += v[0] + v[2]; s2 += v[1] + v[3]; }
+    const float inv = 1.0f / (float)(64 * nseg);
+    const float mu = s1 * inv;
+    const float var = fmaxf(__builtin_fmaf(-mu, mu, s2 * inv), 0.f);
+    const float rstd = __builtin_amdgcn_rsqf(var + eps);
+    ((float2*)rows)[m] = make_float2(rstd, -mu * rstd);
+}
+
+// column vectors of a residual-side LayerNorm fold: ga = alpha * gamma, bb = bias + alpha * beta (GemmArgs::lnr_prefolded)
+__global__ __launch_bounds__(256) void lnr_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias, float alpha,
+                                                        int N, float* __restrict__ ga, float* __restrict__ bb) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    ga[n] = gamma[n] * alpha;
+    bb[n] = __builtin_fmaf(alpha, beta[n], bias[n]);
+}
+
 }  // namespace
 
 namespace avx {
+
+int lnr_fold(const float* gamma, const float* beta, const float* bias, float alpha, int N, float* ga, float* bb, hipStream_t s) {
+    AVX_REQUIRE(gamma && beta && bias && ga && bb && N > 0, "lnr_fold: bad arguments");
+    hipLaunchKernelGGL(lnr_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, s, gamma, beta, bias, alpha, N, ga, bb);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, hipStream_t s) {
+    AVX_REQUIRE(stats && rows && M > 0, "ln_rowstats: bad arguments");
+    AVX_REQUIRE(nseg > 0 && nseg % 2 == 0, "ln_rowstats: nseg = %d (row width must be a multiple of 128)", nseg);
+    hipLaunchKernelGGL(ln_rowstats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, M, nseg, eps, rows);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
 
 int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t s) {
     AVX_REQUIRE(w && out && N > 0 && K > 0, "row_sum_half: bad arguments");

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 
     // ---- epilogue ---------------------------------------------------------------------------
     const float alpha = p.alpha;
+    float ovf_mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wc * 64 + j * 16 + (lane & 15);
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
             if (p.gelu) v = act4(v, p.gelu);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
+                ovf_see4<T>(ovf_mx, v);
                 v4 h;
                 h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]);
                 h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
@@ -169,11 +171,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
             }
         }
     }
+    ovf_commit<T>(p.ovf, ovf_mx);
 }
 
 
 // ---------------------------------------------------------------------------------------------
-// Variant 2: 256x256x64 tile, 8 waves (2 along n x 4 along m, 128x64 outputs per wave), 128 KiB LDS
+// The 256-tile pipeline (gemm256p_kernel below): 256x256x64 tile, 8 waves (2 along n x 4 along m, 128x64 outputs per wave), 128 KiB LDS
 // (2 stages), staged by LDS-DMA in HALF-tiles that follow the order in which the waves finish with
 // them, so three half-tiles are always in flight under the MFMAs (counted vmcnt, raw s_barrier).
 //
@@ -224,8 +227,6 @@ static __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int ti
 }
 
 constexpr int STAGE2 = 2 * T2 * BK * 2;   // 65536: W tile (32 KiB) + X tile (32 KiB)
-constexpr int LNS_OFF = 2 * STAGE2;        // (mu, rstd) of the tile's 256 rows: A-side statistics, then residual-side (2 x 2 KiB)
-constexpr int LDS2 = 2 * STAGE2 + 4096;
 
 #define AVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define AVX_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -282,10 +283,6 @@ static int gemm_nt_mode(const avx::GemmArgs& a) {
     __builtin_amdgcn_sched_barrier(0);
 
 
-// Branch-free epilogue for half-only outputs (bias, optional GELU): bias / GELU are applied in the accumulator
-// layout, the wave's private slab holds the converted f16 values (half the LDS traffic of the fp32 transpose:
-// ds_write_b64 of 4 halves, ds_read_b128 of 8 halves per lane), and the loops carry no uniform branches so the
-// scheduler interleaves the 16 independent GELU chains of a 64-column slice (latency, not issue, bound otherwise).
 // Sum over the 8 consecutive lanes that share (lane >> 3), valid in the lane with (lane & 7) == 0: three DPP steps
 // (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shl:4), no LDS traffic (a __shfl_xor becomes a ds_bpermute round trip).
 static __device__ __forceinline__ float seg8_sum(float v) {
@@ -295,429 +292,49 @@ static __device__ __forceinline__ float seg8_sum(float v) {
     return v;
 }
 
-template <typename T, int GELU, bool LNA>   // GELU: 0 none, 1 exact-erf GELU, 2 SiLU
-static __device__ __forceinline__ void epilogue_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid, int wm,
-                                                     int wn, int lane, int m0, int n0) {
-    typedef typename Half<T>::v8 v8;
-    typedef typename Half<T>::v4 v4;
-    constexpr int HP_LD = 72;   // halves per slab row (64 n + 8 pad = 144 B)
-    T* slab = (T*)(smem + wid * (64 * HP_LD * 2));
-    const int er = lane >> 3, ec = lane & 7;
-    const int lc = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-        f32x4 bv[4], sv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4*)(p.bias + n0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
-        if (LNA) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[i] = *(const f32x4*)(p.ln_s + n0 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // LayerNorm of the A rows folded in: rstd * (acc - mu * s[n]) + bias'  (mu, rstd of tile row 64 wn + 16 j + lc)
-            float2 st = make_float2(1.f, 0.f);
-            if (LNA) st = ((const float2*)(smem + LNS_OFF))[wn * 64 + 16 * j + lc];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 v;
-                if (LNA) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = __builtin_fmaf(st.x, acc[4 * ih + i][j][e], __builtin_fmaf(st.y, sv[i][e], bv[i][e]));
-                } else {
-                    v = acc[4 * ih + i][j] + bv[i];
-                }
-                if (GELU) v = (GELU == 2) ? silu4(v) : gelu_erf4(v);
-                v4 h;
-                h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
-                *(v4*)(slab + (16 * j + lc) * HP_LD + 16 * i + 4 * lg) = h;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int ml = 8 * ps + er;
-            const int m = m0 + wn * 64 + ml;
-            const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
-            if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
-        }
-        asm volatile("" ::: "memory");
-    }
-}
-
-// Branch-free epilogue for the residual GEMMs in operand-type residual mode (out_proj, fc2 without a hook tap):
-// out = half( resid_half * alpha + acc + bias ).  The sum is formed in fp32 AFTER the transpose (fp32 slab), so the
-// residual is read and the result written as row-contiguous 16-byte vectors and nothing is rounded twice.
-template <typename T, bool LNR, bool STATS>
-static __device__ __forceinline__ void epilogue_resid_half(const avx::GemmArgs& p, f32x4 (&acc)[8][4], char* smem, int wid,
-                                                           int wm, int wn, int lane, int m0, int n0) {
-    typedef typename Half<T>::v8 v8;
-    constexpr int EP_LD = 68;
-    float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
-    const int er = lane >> 3, ec = lane & 7;
-    const float alpha = p.alpha;
-    // LNR: the residual is LayerNorm(y) of raw rows y, applied on the fly from (mu, rstd) in LDS and gamma / beta
-    const T* __restrict__ resid = (const T*)(LNR ? p.lnr_y : p.resid_half);
-    const int ldres = LNR ? p.ldy : p.ldrh;
-    const float2* lnr = (const float2*)(smem + LNS_OFF + 2048);
-    const int nseg_out = p.N >> 6;
-    // All residual rows of the wave's 128 x 64 outputs up front (16 x 16 bytes per lane = 64 VGPRs, free now that the operand fragments
-    // are dead): issued per chunk they exposed the memory latency four times per tile (epilogue 8-10 us against 3.3 us for the plain one)
-    v8 rh[2][2][4];
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                int m = m0 + wn * 64 + 32 * jh + 8 * ps + er;
-                m = m < p.M ? m : p.M - 1;
-                rh[ih][jh][ps] = *(const v8*)(resid + (int64_t)m * ldres + n0 + wm * 128 + 64 * ih + 8 * ec);
-            }
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-        const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;
-        f32x4 b0 = *(const f32x4*)(p.bias + nb), b1 = *(const f32x4*)(p.bias + nb + 4);
-        f32x4 ga0, ga1;
-        if (LNR) {
-            // alpha * LN(y) + bias = y * (rstd * alpha gamma) + (alpha beta + bias - mu * rstd * alpha gamma)
-            ga0 = *(const f32x4*)(p.lnr_gamma + nb) * alpha; ga1 = *(const f32x4*)(p.lnr_gamma + nb + 4) * alpha;
-            const f32x4 be0 = *(const f32x4*)(p.lnr_beta + nb), be1 = *(const f32x4*)(p.lnr_beta + nb + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { b0[e] = __builtin_fmaf(alpha, be0[e], b0[e]); b1[e] = __builtin_fmaf(alpha, be1[e], b1[e]); }
-        }
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    *(f32x4*)(slab + (16 * j + (lane & 15)) * EP_LD + 16 * i + 4 * (lane >> 4)) = acc[4 * ih + i][2 * jh + j];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int ml = 8 * ps + er;
-                const int m = m0 + wn * 64 + 32 * jh + ml;
-                const f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
-                const f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
-                v8 h;
-                f32x4 o0, o1;
-                if (LNR) {
-                    const float2 st = lnr[wn * 64 + 32 * jh + ml];      // (rstd, -mu * rstd)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ih][jh][ps][e], st.x, st.y), ga0[e], b0[e]) + v0[e];
-                        o1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[ih][jh][ps][4 + e], st.x, st.y), ga1[e], b1[e]) + v1[e];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o0[e] = __builtin_fmaf((float)rh[ih][jh][ps][e], alpha, v0[e] + b0[e]);
-                        o1[e] = __builtin_fmaf((float)rh[ih][jh][ps][4 + e], alpha, v1[e] + b1[e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
-                if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
-                if (STATS) {
-                    // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
-                    // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
-                    const f32x4 q0 = o0 * o0, q1 = o1 * o1;
-                    float s1 = (o0[0] + o0[1]) + (o0[2] + o0[3]) + ((o1[0] + o1[1]) + (o1[2] + o1[3]));
-                    float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
-                    s1 = seg8_sum(s1); s2 = seg8_sum(s2);
-                    if (ec == 0 && m < p.M)
-                        *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((n0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(512) void gemm256_kernel(avx::GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename Half<T>::v8 v8;
-    typedef typename Half<T>::v4 v4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;   // wm also selects the stagger group (waves 4-7 lag)
-    const int tiles_n = p.N / T2;
-    const int tiles_m = (p.M + T2 - 1) / T2;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    // grouped walk where a group of 8 A panels fits the L2 (K < 2048: QKV, out_proj, fc1); measured inside one call against the
-    // row-major walk: fc1 +3 %, out_proj +3 %, QKV +-0, whole step +1.4 %; HBM fetch per fc1 launch 1.57 -> 0.97 GB
-    // (profiles/r01g_gemm_tile_order.txt).  At K = 3072 a group would be 12.6 MB: row-major there.
-    const bool grouped = p.tile_order >= 2 || (p.tile_order == 0 && p.K < 2048);
-    const int group_m = p.tile_order >= 2 ? p.tile_order : 8;
-    int tm, tn;
-    if (!grouped) { tm = tile / tiles_n; tn = tile - tm * tiles_n; } else tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
-    const int m0 = tm * T2, n0 = tn * T2;
-    const T* __restrict__ A = (const T*)p.A;
-    const T* __restrict__ W = (const T*)p.W;
-    const int nk = p.K / BK;
-    const bool stamp = AVX_STAMPS_ON && tid == 0 && blockIdx.x < 8192;
-    AVX_STAMP(if (stamp) g_gemm_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime(););
-
-    // ---- per-lane DMA source pointers: [half][q] for W and X ------------------------------------
-    // W half h = rows 128q + 64h + 8*wid + (lane>>3); X half h = rows 128q + 64*(wid>>2) + 32h + 8*(wid&3) + (lane>>3)
-    const T* wsrc[2][2];
-    const T* xsrc[2][2];
-    int wdst[2][2], xdst[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int wb = 128 * q + 64 * h + 8 * wid;
-            const int wr = wb + (lane >> 3);
-            wsrc[h][q] = W + (int64_t)(n0 + wr) * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3);
-            wdst[h][q] = wb * 128;
-            const int xb = 128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3);
-            const int xr = xb + (lane >> 3);
-            int arow = m0 + xr;
-            arow = arow < p.M ? arow : p.M - 1;
-            xsrc[h][q] = A + (int64_t)arow * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3);
-            xdst[h][q] = T2 * BK * 2 + xb * 128;
-        }
-    auto dma_w = [&](int h, int kt) __attribute__((always_inline)) {
-        char* base = smem + (kt & 1) * STAGE2;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, 0);
-    };
-    auto dma_x = [&](int h, int kt) __attribute__((always_inline)) {
-        char* base = smem + (kt & 1) * STAGE2;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, 0);
-    };
-
-    // ---- per-lane fragment read offsets (swizzle depends on lane only: rows start at multiples of 16)
-    const int sw = (lane >> 1) & 7;
-    const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);   // k-substep 0
-    const int foff1 = foff0 ^ 64;                                        // k-substep 1: chunk + 4
-    const int wfrag = (wm * 128) * 128;
-    const int xfrag = T2 * BK * 2 + (wn * 64) * 128;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    v8 wf[4][2], xf[4][2];
-
-    // ---- prologue: tile 0 complete, W0/X0/X1 of tile 1 in flight --------------------------------
-    dma_w(0, 0); dma_x(0, 0); dma_x(1, 0); dma_w(1, 0);
-    // folded LayerNorm: the producer's per-segment partial sums of this tile's 256 rows (threads 0-255: A side, 256-511:
-    // residual side) are loaded BETWEEN the two DMA groups, so the counted wait below covers them and nothing else changes
-    float ls1 = 0.f, ls2 = 0.f;
-    const bool ln_any = p.ln_stats != nullptr || p.lnr_stats != nullptr;
-    const float* lstp = tid >= 256 ? p.lnr_stats : p.ln_stats;
-    const int lnseg = tid >= 256 ? p.lnr_nseg : p.ln_nseg;
-    if (ln_any && lstp != nullptr) {
-        int row = m0 + (tid & 255);
-        row = row < p.M ? row : p.M - 1;
-        const f32x4* src = (const f32x4*)(lstp + (int64_t)row * lnseg * 2);     // 64 * nseg columns: nseg is even (N % 256 == 0 or K % 128 == 0)
-        for (int q = 0; q < (lnseg >> 1); ++q) { const f32x4 v = src[q]; ls1 += v[0] + v[2]; ls2 += v[1] + v[3]; }
-    }
-    if (nk > 1) {
-        dma_w(0, 1); dma_x(0, 1); dma_x(1, 1);
-        AVX_VMCNT(6);
-    } else {
-        AVX_VMCNT(0);
-    }
-    if (ln_any && lstp != nullptr) {
-        const float inv = 1.0f / (float)(64 * lnseg);
-        const float mu = ls1 * inv;
-        const float var = fmaxf(__builtin_fmaf(-mu, mu, ls2 * inv), 0.f);
-        const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
-        ((float2*)(smem + LNS_OFF))[tid] = make_float2(rstd, -mu * rstd);       // LN(y) = y * rstd + (-mu * rstd), times gamma, plus beta
-    }
-    AVX_BAR();
-    AVX_STAMP(if (stamp) g_gemm_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(););
-    if (wm == 1) { AVX_BAR(); }   // stagger: waves 4-7 run one barrier behind
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        // A: W0 x (X0, X1); refill W1 of tile kt+1 (other stage, last read in B of tile kt-1)
-        AVX_READ_X(st);
-        AVX_READ_W(0, st);
-        if (kt + 1 < nk) dma_w(1, kt + 1);
-        AVX_LGKM0();
-        AVX_BAR();
-        AVX_HALF(0);
-        AVX_BAR();
-        // B: W1 x (X0, X1); refill W0, X0, X1 with tile kt+2; make tile kt+1 visible
-        AVX_READ_W(1, st);
-        if (kt + 2 < nk) {
-            dma_w(0, kt + 2); dma_x(0, kt + 2); dma_x(1, kt + 2);
-            AVX_VMCNT(6);
-        } else {
-            AVX_VMCNT(0);
-        }
-        AVX_LGKM0();
-        AVX_BAR();
-        AVX_HALF(1);
-        AVX_BAR();
-    }
-    if (wm == 0) { AVX_BAR(); }   // re-align the two groups
-    AVX_STAMP(if (stamp) g_gemm_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(););
-
-    // ---- epilogue -------------------------------------------------------------------------------
-    // Each wave transposes its 128(n) x 64(m) accumulators through a private LDS slab (the stage
-    // buffers are free: every wave is past the last barrier) in four 64(n) x 32(m) chunks, so that
-    // global traffic is row-contiguous: a lane owns 8 consecutive n of one row (16-byte f16 / 2x16-byte
-    // fp32 vectors), 8 lanes cover a 128-byte line, a wave instruction writes 8 full lines.  The
-    // direct-from-accumulator form (8-byte stores, 32 B per row per instruction) ran the store path at
-    // ~2 TB/s and cost 16 us per tile; bias / residual / GELU / masking happen after the transpose.
-    if (p.out_half && p.bias && !p.out_f32 && !p.out_raw && !p.resid && !p.resid_half && !p.lnr_y && !p.stats_out && !p.row_zero) {
-        // Half-only outputs with bias and no residual (QKV, fc1 = 3/4 of the K = 768 work).
-        if (p.ln_stats) {
-            if (p.gelu == 1) epilogue_half<T, 1, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else if (p.gelu == 2) epilogue_half<T, 2, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else epilogue_half<T, 0, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-        } else {
-            if (p.gelu == 1) epilogue_half<T, 1, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else if (p.gelu == 2) epilogue_half<T, 2, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else epilogue_half<T, 0, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-        }
-    } else if (p.out_half && p.bias && (p.resid_half || p.lnr_y) && !p.ln_stats && !p.gelu && !p.out_f32 && !p.out_raw && !p.resid && !p.row_zero) {
-        if (p.lnr_y) {
-            if (p.stats_out) epilogue_resid_half<T, true, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else epilogue_resid_half<T, true, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-        } else {
-            if (p.stats_out) epilogue_resid_half<T, false, true>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-            else epilogue_resid_half<T, false, false>(p, acc, smem, wid, wm, wn, lane, m0, n0);
-        }
-    } else {
-        constexpr int EP_LD = 68;   // floats per slab row (64 n + 4 pad: conflict-free 16-byte writes)
-        float* slab = (float*)(smem + wid * (32 * EP_LD * 4));
-        const int er = lane >> 3, ec = lane & 7;
-        const float alpha = p.alpha;
-#pragma unroll
-        for (int ih = 0; ih < 2; ++ih) {
-            const int nb = n0 + wm * 128 + 64 * ih + 8 * ec;   // this lane's 8 consecutive columns
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
-            f32x4 ls0 = b0, ls1 = b0, lg0 = b0, lg1 = b0, lb0 = b0, lb1 = b0;     // folded-LayerNorm column vectors (see GemmArgs)
-            if (p.ln_stats) { ls0 = *(const f32x4*)(p.ln_s + nb); ls1 = *(const f32x4*)(p.ln_s + nb + 4); }
-            if (p.lnr_y) {
-                lg0 = *(const f32x4*)(p.lnr_gamma + nb) * alpha; lg1 = *(const f32x4*)(p.lnr_gamma + nb + 4) * alpha;
-                lb0 = *(const f32x4*)(p.lnr_beta + nb); lb1 = *(const f32x4*)(p.lnr_beta + nb + 4);
-            }
-#pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        *(f32x4*)(slab + (16 * j + (lane & 15)) * EP_LD + 16 * i + 4 * (lane >> 4)) = acc[4 * ih + i][2 * jh + j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my wave's slab writes are done (LDS is in-order per wave)
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int ml = 8 * ps + er;
-                    const int m = m0 + wn * 64 + 32 * jh + ml;
-                    f32x4 v0 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec);
-                    f32x4 v1 = *(const f32x4*)(slab + ml * EP_LD + 8 * ec + 4);
-                    if (m >= p.M) continue;
-                    const f32x4 a0 = v0, a1 = v1;      // accumulators before the bias (the folded-LayerNorm residual adds them last)
-                    if (p.ln_stats) {
-                        const float2 st = ((const float2*)(smem + LNS_OFF))[wn * 64 + 32 * jh + ml];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v0[e] = __builtin_fmaf(st.x, v0[e], __builtin_fmaf(st.y, ls0[e], b0[e]));
-                            v1[e] = __builtin_fmaf(st.x, v1[e], __builtin_fmaf(st.y, ls1[e], b1[e]));
-                        }
-                    } else {
-                        v0 += b0; v1 += b1;
-                    }
-                    if (p.row_zero != nullptr && p.row_zero[m] != 0) {
-                        v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
-                    }
-                    if (p.out_raw) {
-                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0, p.nt);
-                        st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1, p.nt);
-                    }
-                    if (p.resid) {
-                        const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
-                        const f32x4 r1 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf(r0[e], alpha, v0[e]); v1[e] = __builtin_fmaf(r1[e], alpha, v1[e]); }
-                    } else if (p.resid_half) {
-                        const v8 rh = *(const v8*)((const T*)p.resid_half + (int64_t)m * p.ldrh + nb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rh[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rh[4 + e], alpha, v1[e]); }
-                    } else if (p.lnr_y) {
-                        const v8 rh = *(const v8*)((const T*)p.lnr_y + (int64_t)m * p.ldy + nb);
-                        const float2 st = ((const float2*)(smem + LNS_OFF + 2048))[wn * 64 + 32 * jh + ml];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // the same operations in the same order as epilogue_resid_half<T, true, *>: bit-identical rows
-                            v0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[e], st.x, st.y), lg0[e], __builtin_fmaf(alpha, lb0[e], b0[e])) + a0[e];
-                            v1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[4 + e], st.x, st.y), lg1[e], __builtin_fmaf(alpha, lb1[e], b1[e])) + a1[e];
-                        }
-                    }
-                    if (p.gelu) { v0 = act4(v0, p.gelu); v1 = act4(v1, p.gelu); }
-                    if (p.out_f32) {
-                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0, p.nt);
-                        st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1, p.nt);
-                    }
-                    if (p.out_half) {
-                        v8 h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
-                        st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
-                    }
-                    if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
-                        const f32x4 q0 = v0 * v0, q1 = v1 * v1;     // same order as the branch-free epilogue
-                        float s1 = (v0[0] + v0[1]) + (v0[2] + v0[3]) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-                        float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
-                        s1 = seg8_sum(s1); s2 = seg8_sum(s2);
-                        if (ec == 0)
-                            *(float2*)(p.stats_out + ((int64_t)m * (p.N >> 6) + ((n0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
-    }
-    AVX_STAMP(if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_gemm_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); });
-}
-
-
-
 // ---------------------------------------------------------------------------------------------
-// Variant 5: the variant-2 pipeline as ONE CONTINUOUS K STREAM over a persistent workgroup's tiles (one workgroup per CU).
-// The in-kernel stamps of variant 2 at K = 768 read: DMA prologue 3.0 us + K loop 17.8 us + epilogue 4.4 us + 1.9 us
-// until the next workgroup starts.  Here the last iterations of a tile issue the DMA for the next tile's first K-tiles
-// as if they were K-tiles nk, nk + 1 of the same product (pointers switch in the middle of iteration nk - 2), the epilogue's
-// transpose slabs live in the 32 KiB of LDS above the two stages, the bias row arrives by LDS-DMA one tile ahead, and the
-// wave stagger is never re-aligned: no prologue, no turnaround, no barrier between tiles.
-// MEASURED: bit-identical to variant 2, and NOT faster (0 +- 2 % on every shape): prologue and turnaround vanish from the
-// stamps, but the K loop of a K = 768 tile stretches from 17.8 to 22.4 us (1.87 instead of 1.48 us per K-tile).  The
-// per-tile cost is not a pipeline-drain cost; kept as a diagnostic vehicle (scripts/gemm_stamps5.py), variant 2 stays default.
+// The 256-tile kernel: the half-tile pipeline above as ONE CONTINUOUS K STREAM over a persistent workgroup's tiles (one
+// workgroup per CU).  The last iterations of a tile issue the DMA for the next tile's first K-tiles as if they were K-tiles
+// nk, nk + 1 of the same product (the source pointers switch in the middle of iteration nk - 2), the epilogue's transpose slabs
+// live in the 32 KiB of LDS above the two stages, per-tile row / column vectors (bias, folded-LayerNorm vectors) arrive by
+// LDS-DMA one tile ahead, the two wave groups are re-aligned around the epilogue and the next tile's first counted wait skips
+// the epilogue's stores.  (History: the tile-per-workgroup form of this pipeline, gemm256_kernel, was the default until round 1's
+// last day and the home of the folded-LayerNorm epilogues until round 3; profiles/r01h_gemm_stream.txt has the comparison.)
+//
+// Epilogues (template EPI, flags LN):
+//   EPI 1  half output = act(acc + bias)                      LN bit 0: the A rows are raw y, LayerNorm folded in (GemmArgs::ln_rows)
+//   EPI 2  half output = resid * alpha + acc + bias           LN bit 0: resid = LayerNorm(lnr_y) on the fly; bit 1: stats_out
+//   EPI 0  everything avexhip_gemm can ask for (fp32 / raw outputs, fp32 residual, masked rows, missing bias ...), same arithmetic
+//          and operation order as the two fast forms where they overlap (bit-identical rows), conservative waits.
 // ---------------------------------------------------------------------------------------------
 constexpr int LDS5 = 2 * STAGE2 + 32768;
+constexpr int L5_BIAS = 8 * 2304;            // EPI 1: [2][256] floats, bias of the current / next tile
+constexpr int L5_LNS = L5_BIAS + 2048;       // EPI 1 + LN: [2][256] floats, ln_s of the current / next tile's columns
+constexpr int L5_ROWS = L5_LNS + 2048;       // EPI 1 + LN: [2][256] float2, (rstd, -mu rstd) of the current / next tile's rows
+static_assert(L5_ROWS + 4096 <= 32768, "EPI 1 scratch above the stages");
 #ifndef GEMM_NOSTORE
-#define GEMM_NOSTORE 0   // diagnostic builds: 1 drops the half-only epilogue's global stores of variant 5 (is the tile start waiting for them?)
+#define GEMM_NOSTORE 0   // diagnostic builds: 1 drops the half-only epilogue's global stores (is the tile start waiting for them?)
+#endif
+#ifndef GEMM_XCD_WALK
+#define GEMM_XCD_WALK 0
 #endif
 
-template <typename T, int EPI>   // EPI: 0 generic epilogue, 1 half + bias (+GELU), 2 half + bias + half residual
+template <typename T, int EPI, int LN>
 __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
+    static_assert(EPI >= 0 && EPI <= 2 && LN >= 0 && LN <= 3 && (EPI != 1 || LN <= 1) && (EPI != 0 || LN == 0), "epilogue selector");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
+    const int wm = wid >> 2, wn = wid & 3;      // wm also selects the stagger group (waves 4-7 lag one barrier)
     const int tiles_n = p.N / T2;
     const int tiles_m = (p.M + T2 - 1) / T2;
     const int ntiles = tiles_m * tiles_n;
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
     const int nk = p.K / BK;   // >= 2 (launcher)
-    // blocks sharing blockIdx % 8 share an XCD: in round `it` they take 32 consecutive tiles (n fastest)
+    // blocks sharing blockIdx % 8 share an XCD: in round `it` they take 32 consecutive tiles
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7) >> 3;
     int m0 = 0, n0 = 0;
 
@@ -731,8 +348,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             wdst[h][q] = (128 * q + 64 * h + 8 * wid) * 128;
             xdst[h][q] = T2 * BK * 2 + (128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3)) * 128;
         }
-    const bool grouped = p.K < 2048;      // as in gemm256_kernel
-    const int group_m = 8;
+    // grouped walk where a group of 8 A panels fits the L2 (K < 2048: QKV, out_proj, fc1); measured against the row-major walk: fc1 +3 %,
+    // out_proj +3 %, QKV +-0, whole step +1.4 %; HBM fetch per fc1 launch 1.57 -> 0.97 GB (profiles/r01g_gemm_tile_order.txt).
+    // At K = 3072 a group would be 12.6 MB: row-major there.
+    const bool grouped = p.tile_order >= 2 || (p.tile_order == 0 && p.K < 2048);
+    const int group_m = p.tile_order >= 2 ? p.tile_order : 8;
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
         int tm, tn;
         if (grouped) tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
@@ -760,25 +380,39 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, 0);
     };
-    static_assert(EPI == 1 || EPI == 2, "the streaming kernel has the two branch-free epilogues only");
     constexpr bool fast_half = EPI == 1, fast_resid = EPI == 2;
-    float* ldsbias = (float*)(smem + 2 * STAGE2 + 8 * 2304);      // EPI 1: [2][256] bias of the current / next tile, filled by LDS-DMA
-    auto dma_bias = [&](int n0b, int par) __attribute__((always_inline)) {   // 256 floats = one LDS-DMA wave instruction (wave 0)
-        if (fast_half && wid == 0)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(p.bias + n0b + lane * 4), (lptr_t*)(ldsbias + par * 256), 16, 0, 0);
+    constexpr bool LNA = EPI == 1 && (LN & 1), LNR = EPI == 2 && (LN & 1), STATS = EPI == 2 && (LN & 2);
+    float* ldsbias = (float*)(smem + 2 * STAGE2 + L5_BIAS);
+    float* ldslns = (float*)(smem + 2 * STAGE2 + L5_LNS);
+    float* ldsrows = (float*)(smem + 2 * STAGE2 + L5_ROWS);
+    // EPI 1: the tile's bias row (wave 0), with the fold its ln_s row (wave 1) and the (rstd, -mu rstd) pairs of its 256 rows (waves 2, 3)
+    // go to LDS by LDS-DMA, at most one wave instruction (1 KiB) per wave, one tile ahead: a global load in the epilogue could only be
+    // waited for together with the next tile's DMAs that are in flight by then
+    auto dma_aux = [&](int n0b, int m0b, int par) __attribute__((always_inline)) {
+        if (fast_half) {
+            if (wid == 0) __builtin_amdgcn_global_load_lds((gptr_t*)(p.bias + n0b + lane * 4), (lptr_t*)(ldsbias + par * 256), 16, 0, 0);
+            if (LNA && wid == 1) __builtin_amdgcn_global_load_lds((gptr_t*)(p.ln_s + n0b + lane * 4), (lptr_t*)(ldslns + par * 256), 16, 0, 0);
+            if (LNA && (wid == 2 || wid == 3)) {
+                int r = m0b + 128 * (wid - 2) + 2 * lane;                 // two rows (16 bytes) per lane
+                const int last = (p.M - 2) & ~1;                           // rows past M are never stored: any valid, aligned address will do
+                r = r < last ? r : last;
+                __builtin_amdgcn_global_load_lds((gptr_t*)(p.ln_rows + 2 * (int64_t)r), (lptr_t*)(ldsrows + par * 512 + (wid - 2) * 256), 16, 0, 0);
+            }
+        }
     };
     auto tile_prologue = [&]() __attribute__((always_inline)) {   // 14 DMA instructions
         dma_w(0, 0, 0); dma_x(0, 0, 0); dma_x(1, 0, 0); dma_w(1, 0, 0);
         dma_w(0, 1, 1); dma_x(0, 1, 1); dma_x(1, 1, 1);
     };
     const int sw = (lane >> 1) & 7;
-    const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);
-    const int foff1 = foff0 ^ 64;
+    const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4);   // k-substep 0 (swizzle depends on the lane only: rows start at multiples of 16)
+    const int foff1 = foff0 ^ 64;                                        // k-substep 1: chunk + 4
     const int wfrag = (wm * 128) * 128;
     const int xfrag = T2 * BK * 2 + (wn * 64) * 128;
 
     f32x4 acc[8][4];
     v8 wf[4][2], xf[4][2];
+    unsigned long long ovf_lanes = 0ull;      // range alarm: lanes that clipped a value in any tile so far (scalar registers)
 
     // GEMM_XCD_WALK 1 (A/B builds): each XCD owns a CONTIGUOUS eighth of the logical tile ids and walks it 32 ids per round, so that a
     // group's A panels could stay in that XCD's L2 from one round to the next.  MEASURED: no change in time (+-0.1 % on the step) and
@@ -786,15 +420,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     // touch at least 11.3 operand panels of 393 KB (K = 768) per round, 4.4 MB against 4 MB of L2, so under LRU nothing survives from
     // one round to the next whichever XCD runs it; the fetch counter sits at rounds x that footprint (the floor of this tiling), and
     // what it counts is L2 <-> fabric traffic, of which the 256 MB Infinity Cache absorbs the A re-reads (A is 195 MB).
-#ifndef GEMM_XCD_WALK
-#define GEMM_XCD_WALK 0
-#endif
     const int t_lo = GEMM_XCD_WALK ? (int)(((int64_t)ntiles * xcd) >> 3) : 0;
     const int t_hi = GEMM_XCD_WALK ? (int)(((int64_t)ntiles * (xcd + 1)) >> 3) : ntiles;
     int tile = GEMM_XCD_WALK ? t_lo + slot : (0 * 8 + xcd) * per_xcd + slot;
     if (tile >= t_hi) return;
     set_tile(tile);
-    dma_bias(n0, 0);
+    dma_aux(n0, m0, 0);
     tile_prologue();
     const bool stamp_on = AVX_STAMPS_ON && tid == 0;
     AVX_VMCNT(6);
@@ -822,19 +453,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         for (int kt = 0; kt < nk; ++kt) {
             const int st = (g0 + kt) & 1;
             AVX_STAMP(if (stamp && it == 2 && kt < 63 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + kt] = __builtin_amdgcn_s_memtime(););
+            // A: W0 x (X0, X1); refill W1 of K-tile kt+1 (other stage, last read in B of K-tile kt-1)
             AVX_READ_X(st);
             AVX_READ_W(0, st);
             if (kt + 1 < nk) { if (!(early_w1 && kt == 0 && it > 0)) dma_w(1, kt + 1, st ^ 1); }   // (issued before the epilogue, see below)
             else if (has_next) dma_w(1, 0, st ^ 1);                  // pointers already switched (below, one iteration ago)
             if (kt == nk - 2 && has_next) set_tile(next_tile);       // last use of this tile's pointers was the line above
-            // next tile's bias row: in the LAST K-tile, i.e. at least four barriers into this tile, when the lagging wave group
-            // has left the previous tile's epilogue (which read the slot this overwrites); it is older than the six DMAs of the
-            // B phase below, so wave 0's vmcnt(6) there and the two barriers that follow publish it before the epilogue
-            if (kt == nk - 1 && has_next) dma_bias(n0, (it + 1) & 1);
+            // next tile's row / column vectors: in the LAST K-tile, i.e. at least four barriers into this tile, when the lagging wave group
+            // has left the previous tile's epilogue (which read the slot this overwrites); they are older than the six DMAs of the
+            // B phase below, so each issuing wave's vmcnt(6) there and the two barriers that follow publish them before the epilogue
+            if (kt == nk - 1 && has_next) dma_aux(n0, m0, (it + 1) & 1);
             AVX_LGKM0();
             AVX_BAR();
             AVX_HALF(0);
             AVX_BAR();
+            // B: W1 x (X0, X1); refill W0, X0, X1 with K-tile kt+2; make K-tile kt+1 visible
             AVX_READ_W(1, st);
             if (kt + 2 < nk) {
                 dma_w(0, kt + 2, st); dma_x(0, kt + 2, st); dma_x(1, kt + 2, st);
@@ -854,8 +487,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_BAR();
         }
         AVX_STAMP(if (stamp && it == 2 && nk < 64 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + nk] = __builtin_amdgcn_s_memtime(););
-        // Re-align the two wave groups for the epilogue (as the tile-per-workgroup kernel does): left staggered, the lagging group cannot
-        // pass its last loop barrier before the leading group reaches the next tile's first one, i.e. the two epilogues run one after the other.
+        // Re-align the two wave groups for the epilogue: left staggered, the lagging group cannot pass its last loop barrier before the
+        // leading group reaches the next tile's first one, i.e. the two epilogues would run one after the other.
         if (wm == 0) { AVX_BAR(); }
         // every wave is past the loop now: the W1 half of the stage K-tile 1 of the next tile goes to is free.  Issued here, ahead of the
         // epilogue's stores, the first K-tile's counted wait does not have to wait for those stores.
@@ -863,30 +496,55 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         g0 += nk;
         AVX_STAMP(if (stamp) { g_gemm_stamps[4 * tile + 2] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile + 1] = __builtin_amdgcn_s_memtime(); });
 
-        const int er = lane >> 3, ec = lane & 7, lc = lane & 15, lg = lane >> 4;
+        // ---- epilogue ---------------------------------------------------------------------------
+        // Each wave transposes its 128(n) x 64(m) accumulators through a private LDS slab in 16-row chunks, so that global traffic is
+        // row-contiguous: a lane owns 8 consecutive n of one row (16-byte f16 / 2 x 16-byte fp32 vectors), 8 lanes cover a 128-byte
+        // line, a wave instruction writes 8 full lines.  (The direct-from-accumulator form, 8-byte stores, ran the store path at ~2 TB/s.)
+        // the epilogue's lane constants (slab addresses, row / column offsets) are derived from an opaque copy of the lane id: computed from
+        // `lane` itself they are loop-invariant, get hoisted above the tile loop, and then live -- spilled -- through the K loop
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int er = le >> 3, ec = le & 7, lc = le & 15, lg = le >> 4;
+        float ovf_mx = 0.f;
 
         if constexpr (fast_half) {
-            // bias from LDS (placed there by LDS-DMA one tile ahead): a global load here could only be waited for together with the
-            // six DMAs of the next tile that are in flight
-            f32x4 bvv[2][4];
+            // bias / GELU (/ the folded LayerNorm of the A rows) in the accumulator layout; the slab holds the converted halves
+            // (ds_write_b64 of 4 halves, ds_read_b128 of 8); no uniform branches inside, so the scheduler interleaves the
+            // independent GELU chains of a 64-column slice
+            const float* lb = ldsbias + (it & 1) * 256 + wm * 128;
+            const float* lsv = ldslns + (it & 1) * 256 + wm * 128;
+            float2 rst[4];
+            if (LNA) {
 #pragma unroll
-            for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bvv[ih][i] = *(const f32x4*)(ldsbias + (it & 1) * 256 + wm * 128 + 64 * ih + 16 * i + 4 * lg);
-            constexpr int HP_LD = 72;
+                for (int j = 0; j < 4; ++j) rst[j] = ((const float2*)(ldsrows + (it & 1) * 512))[wn * 64 + 16 * j + lc];      // (rstd, -mu rstd) of tile row 64 wn + 16 j + lc
+            }
+            constexpr int HP_LD = 72;     // halves per slab row (64 n + 8 pad = 144 B)
             T* slab = (T*)(smem + 2 * STAGE2 + wid * (16 * HP_LD * 2));
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
-                f32x4 bv[4];
+                f32x4 bv[4], sv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv[i] = bvv[ih][i];
+                for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4*)(lb + 64 * ih + 16 * i + 4 * lg);
+                if (LNA) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sv[i] = *(const f32x4*)(lsv + 64 * ih + 16 * i + 4 * lg);
+                }
                 const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        f32x4 v = acc[4 * ih + i][j] + bv[i];
+                        f32x4 v;
+                        if (LNA) {
+                            // LayerNorm of the A rows folded in: rstd * acc + ((-mu rstd) * s[n] + bias'[n])
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = __builtin_fmaf(rst[j].x, acc[4 * ih + i][j][e], __builtin_fmaf(rst[j].y, sv[i][e], bv[i][e]));
+                        } else {
+                            v = acc[4 * ih + i][j] + bv[i];
+                        }
                         if (p.gelu) v = act4(v, p.gelu);
+                        ovf_see4<T>(ovf_mx, v);
                         v4 h;
                         h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
                         *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;
@@ -903,38 +561,119 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 }
             }
         } else if constexpr (fast_resid) {
-            // the first half's residual vectors are loaded before the DMAs (so waiting for them does not wait for the
-            // DMAs); the second half's are issued two chunks later, when the DMAs have long landed
-            const T* __restrict__ resid = (const T*)p.resid_half;
-            v8 rh[2][4][2];
-            auto load_resid = [&](int ih) __attribute__((always_inline)) {
+            // out = half( resid * alpha + acc + bias ), the sum formed in fp32 AFTER the transpose (fp32 slab), so the residual is read and the
+            // result written as row-contiguous 16-byte vectors and nothing is rounded twice.  LNR: resid = LayerNorm(lnr_y) applied on the
+            // fly, alpha * LN(y) + bias = (y * rstd - mu rstd) * (alpha gamma) + (alpha beta + bias); the launcher hands over alpha gamma
+            // and alpha beta + bias ready-made (GemmArgs::lnr_prefolded: lnr_gamma, lnr_beta).
+            // The epilogue walks 8 chunks of 16 rows x 64 columns (c = 4 ih + j).  A chunk's residual vectors (and row statistics) are
+            // requested three chunks ahead: all of a half up front cost 64 registers this kernel does not have once the fold's vectors are
+            // there (it spilled 60), none ahead exposed the memory latency eight times per tile (8-10 us against 3.3 us).
+            const T* __restrict__ resid = (const T*)(LNR ? p.lnr_y : p.resid_half);
+            const int ldres = LNR ? p.ldy : (int)p.ldrh;
+            constexpr int AHEAD = 3;
+            v8 rh[8][2];
+            auto request = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
-                        int m = em0 + wn * 64 + 16 * j + 8 * ps + er;
-                        m = m < p.M ? m : p.M - 1;
-                        rh[ih][j][ps] = *(const v8*)(resid + (int64_t)m * p.ldrh + en0 + wm * 128 + 64 * ih + 8 * ec);
-                    }
+                for (int ps = 0; ps < 2; ++ps) {
+                    int m = em0 + wn * 64 + 16 * (c & 3) + 8 * ps + er;
+                    m = m < p.M ? m : p.M - 1;
+                    rh[c][ps] = *(const v8*)(resid + (int64_t)m * ldres + en0 + wm * 128 + 64 * (c >> 2) + 8 * ec);
+                }
             };
-            f32x4 bb[2][2];
-#pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                bb[ih][0] = *(const f32x4*)(p.bias + en0 + wm * 128 + 64 * ih + 8 * ec);
-                bb[ih][1] = *(const f32x4*)(p.bias + en0 + wm * 128 + 64 * ih + 8 * ec + 4);
+            // LNR: lane L keeps the (rstd, -mu rstd) pair of row L of the wave's 64 rows (one coalesced 512-byte read, two registers);
+            // the lane that stores row r of a chunk fetches the pair from lane r with ds_bpermute (no LDS memory involved)
+            float2 rsl = make_float2(0.f, 0.f);
+            if (LNR) {
+                int m = em0 + wn * 64 + le;
+                m = m < p.M ? m : p.M - 1;
+                rsl = ((const float2*)p.lnr_rows)[m];
             }
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // bias landed (older than the 8 residual loads)
-            load_resid(0);
+            f32x4 bb[2][2], ga[2][2];
+            auto columns = [&](int ih) __attribute__((always_inline)) {
+                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
+                const float* bsrc = LNR ? p.lnr_beta : p.bias;      // LNR: alpha * beta + bias, ready-made
+                bb[ih][0] = *(const f32x4*)(bsrc + nb);
+                bb[ih][1] = *(const f32x4*)(bsrc + nb + 4);
+                if (LNR) { ga[ih][0] = *(const f32x4*)(p.lnr_gamma + nb); ga[ih][1] = *(const f32x4*)(p.lnr_gamma + nb + 4); }
+            };
+            columns(0);
+#pragma unroll
+            for (int c = 0; c < AHEAD; ++c) request(c);
             asm volatile("" ::: "memory");
             float* slab = (float*)(smem + 2 * STAGE2 + wid * 4096);   // 16 rows x 64 floats, 16-byte chunk c of row r at slot c ^ r
             const float alpha = p.alpha;
+            const int nseg_out = p.N >> 6;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ih = c >> 2, j = c & 3;
+                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
+                if (c + AHEAD < 8) request(c + AHEAD);
+                if (c == 2) columns(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(f32x4*)((char*)slab + lc * 256 + (((4 * i + lg) ^ lc) << 4)) = acc[4 * ih + i][j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int ml = 8 * ps + er;
+                    const int m = em0 + wn * 64 + 16 * j + ml;
+                    const f32x4 v0 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec) ^ ml) << 4));
+                    const f32x4 v1 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec + 1) ^ ml) << 4));
+                    f32x4 o0, o1;
+                    if (LNR) {
+                        float2 st;
+                        st.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * j + ml), __builtin_bit_cast(int, rsl.x)));
+                        st.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * j + ml), __builtin_bit_cast(int, rsl.y)));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[c][ps][e], st.x, st.y), ga[ih][0][e], bb[ih][0][e]) + v0[e];
+                            o1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[c][ps][4 + e], st.x, st.y), ga[ih][1][e], bb[ih][1][e]) + v1[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o0[e] = __builtin_fmaf((float)rh[c][ps][e], alpha, v0[e] + bb[ih][0][e]);
+                            o1[e] = __builtin_fmaf((float)rh[c][ps][4 + e], alpha, v1[e] + bb[ih][1][e]);
+                        }
+                    }
+                    ovf_see4<T>(ovf_mx, o0); ovf_see4<T>(ovf_mx, o1);
+                    v8 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
+                    if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
+                    if (STATS) {
+                        // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
+                        // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
+                        const f32x4 q0 = o0 * o0, q1 = o1 * o1;
+                        float s1 = (o0[0] + o0[1]) + (o0[2] + o0[3]) + ((o1[0] + o1[1]) + (o1[2] + o1[3]));
+                        float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+                        s1 = seg8_sum(s1); s2 = seg8_sum(s2);
+                        if (ec == 0 && m < p.M)
+                            *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((en0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            // EPI 0: every option of GemmArgs, in the fast forms' operation order where they overlap (so a row comes out bit-identical
+            // whichever epilogue wrote it); plain loads and the compiler's own waits (this is the path of hook taps, fp32 residual streams
+            // and the first / last products of a forward, not of the layer loop)
+            float* slab = (float*)(smem + 2 * STAGE2 + wid * 4096);
+            const float alpha = p.alpha;
+            const int nseg_out = p.N >> 6;
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
-                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
-                const f32x4 b0 = bb[ih][0], b1 = bb[ih][1];
+                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;   // this lane's 8 consecutive columns
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
+                f32x4 ls0 = b0, ls1 = b0, lg0 = b0, lg1 = b0, lb0 = b0, lb1 = b0;     // folded-LayerNorm column vectors (see GemmArgs)
+                if (p.ln_rows) { ls0 = *(const f32x4*)(p.ln_s + nb); ls1 = *(const f32x4*)(p.ln_s + nb + 4); }
+                if (p.lnr_y) {      // (the launcher has folded alpha into gamma and alpha * beta into the bias: GemmArgs::lnr_prefolded)
+                    lg0 = *(const f32x4*)(p.lnr_gamma + nb); lg1 = *(const f32x4*)(p.lnr_gamma + nb + 4);
+                    lb0 = *(const f32x4*)(p.lnr_beta + nb); lb1 = *(const f32x4*)(p.lnr_beta + nb + 4);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (ih == 0 && j == 2) load_resid(1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         *(f32x4*)((char*)slab + lc * 256 + (((4 * i + lg) ^ lc) << 4)) = acc[4 * ih + i][j];
@@ -943,81 +682,136 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     for (int ps = 0; ps < 2; ++ps) {
                         const int ml = 8 * ps + er;
                         const int m = em0 + wn * 64 + 16 * j + ml;
-                        const f32x4 v0 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec) ^ ml) << 4)) + b0;
-                        const f32x4 v1 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec + 1) ^ ml) << 4)) + b1;
-                        v8 h;
+                        f32x4 v0 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec) ^ ml) << 4));
+                        f32x4 v1 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec + 1) ^ ml) << 4));
+                        if (m < p.M) {
+                            const f32x4 a0 = v0, a1 = v1;      // accumulators before the bias (the folded-LayerNorm residual adds them last)
+                            if (p.ln_rows) {
+                                const float2 st = ((const float2*)p.ln_rows)[m];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            h[e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][e], alpha, v0[e]));
-                            h[4 + e] = Half<T>::from(__builtin_fmaf((float)rh[ih][j][ps][4 + e], alpha, v1[e]));
+                                for (int e = 0; e < 4; ++e) {
+                                    v0[e] = __builtin_fmaf(st.x, v0[e], __builtin_fmaf(st.y, ls0[e], b0[e]));
+                                    v1[e] = __builtin_fmaf(st.x, v1[e], __builtin_fmaf(st.y, ls1[e], b1[e]));
+                                }
+                            } else {
+                                v0 += b0; v1 += b1;
+                            }
+                            if (p.row_zero != nullptr && p.row_zero[m] != 0) {
+                                v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
+                            }
+                            if (p.out_raw) {
+                                st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0, p.nt);
+                                st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1, p.nt);
+                            }
+                            if (p.resid) {
+                                const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
+                                const f32x4 r1 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf(r0[e], alpha, v0[e]); v1[e] = __builtin_fmaf(r1[e], alpha, v1[e]); }
+                            } else if (p.resid_half) {
+                                const v8 rh = *(const v8*)((const T*)p.resid_half + (int64_t)m * p.ldrh + nb);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v0[e] = __builtin_fmaf((float)rh[e], alpha, v0[e]); v1[e] = __builtin_fmaf((float)rh[4 + e], alpha, v1[e]); }
+                            } else if (p.lnr_y) {
+                                const v8 rh = *(const v8*)((const T*)p.lnr_y + (int64_t)m * p.ldy + nb);
+                                const float2 st = ((const float2*)p.lnr_rows)[m];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {     // the same operations in the same order as EPI 2 with LN bit 0: bit-identical rows
+                                    v0[e] = __builtin_fmaf(__builtin_fmaf((float)rh[e], st.x, st.y), lg0[e], lb0[e]) + a0[e];
+                                    v1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[4 + e], st.x, st.y), lg1[e], lb1[e]) + a1[e];
+                                }
+                            }
+                            if (p.gelu) { v0 = act4(v0, p.gelu); v1 = act4(v1, p.gelu); }
+                            if (p.out_f32) {
+                                st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0, p.nt);
+                                st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1, p.nt);
+                            }
+                            if (p.out_half) {
+                                ovf_see4<T>(ovf_mx, v0); ovf_see4<T>(ovf_mx, v1);
+                                v8 h;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
+                                st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
+                            }
+                            if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
+                                const f32x4 q0 = v0 * v0, q1 = v1 * v1;     // same order as EPI 2
+                                float s1 = (v0[0] + v0[1]) + (v0[2] + v0[3]) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                                float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+                                s1 = seg8_sum(s1); s2 = seg8_sum(s2);
+                                if (ec == 0)
+                                    *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((en0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
+                            }
                         }
-                        if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
         }
+        ovf_lanes |= ovf_mask<T>(ovf_mx);
         AVX_STAMP(if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime(););
         if (!has_next) break;
         prev_full = em0 + T2 <= p.M;
+        {   // the next tile's 8 source pointers (16 registers) are computed a second time here instead of being carried through the
+            // epilogue, which needs every register it can get (the barrier on the tile id keeps the two computations apart)
+            int t2 = next_tile;
+            asm volatile("" : "+s"(t2));
+            set_tile(t2);
+        }
         if (wm == 1) { AVX_BAR(); }      // stagger again for the next tile's loop
         tile = next_tile;
     }
+    ovf_commit<T>(p.ovf, ovf_lanes);
+}
+
+template <typename T, int EPI, int LN>
+static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
+    AVX_ENSURE_LDS((gemm256p_kernel<T, EPI, LN>), LDS5);
+    hipLaunchKernelGGL((gemm256p_kernel<T, EPI, LN>), dim3(grid), dim3(512), LDS5, s, a5);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
 }
 
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
-    // variant: 0 = auto, 1 = 128-tile register staging, 2 = 256-tile half-tile pipeline, 3 = 128-tile LDS-DMA,
-    // 5 = variant 2 persistent (next tile's DMA prologue issued before the epilogue)
+    // variant: 0 = auto, 1 = 128-tile register staging, 3 = 128-tile LDS-DMA, 5 (or 2, its tile-per-workgroup ancestor's number) =
+    // the 256-tile streaming kernel
     int variant = a.variant;
-    const bool ln_fold = a.ln_stats || a.lnr_y || a.stats_out;
+    const bool ln_fold = a.ln_rows || a.lnr_y || a.stats_out;
     if (ln_fold) {
         // folded LayerNorm exists in the 256-tile kernel only
-        AVX_REQUIRE(a.N % T2 == 0 && (!a.out_half || a.ldh % 8 == 0), "gemm: folded LayerNorm needs N %% 256 == 0 (N=%d)", a.N);
-        AVX_REQUIRE(!a.ln_stats || (a.ln_s && a.bias && a.ln_nseg > 0 && a.ln_nseg % 2 == 0 && 64 * a.ln_nseg == a.K), "gemm: ln_stats needs ln_s, bias and 64*ln_nseg == K (K %% 128 == 0)");
-        AVX_REQUIRE(!a.lnr_y || (a.lnr_stats && a.lnr_gamma && a.lnr_beta && a.lnr_nseg > 0 && 64 * a.lnr_nseg == a.N && a.ldy % 8 == 0 && !a.resid && !a.resid_half),
-                    "gemm: lnr_y needs lnr_stats/gamma/beta, 64*lnr_nseg == N and no other residual");
-        AVX_REQUIRE(a.variant == 0 || a.variant == 2, "gemm: folded LayerNorm is built for variant 2 only");
-        variant = 2;
+        AVX_REQUIRE(a.N % T2 == 0 && a.K >= 2 * BK && (!a.out_half || a.ldh % 8 == 0), "gemm: folded LayerNorm needs N %% 256 == 0 and K >= 128 (N=%d K=%d)", a.N, a.K);
+        AVX_REQUIRE(!a.ln_rows || (a.ln_s && a.bias && a.M >= 2), "gemm: ln_rows needs ln_s and bias");
+        AVX_REQUIRE(!a.lnr_y || (a.lnr_rows && a.lnr_gamma && a.lnr_beta && a.bias && a.lnr_prefolded && a.ldy % 8 == 0 && !a.resid && !a.resid_half),
+                    "gemm: lnr_y needs lnr_rows / gamma / beta / bias and no other residual");
+        AVX_REQUIRE(a.variant == 0 || a.variant == 2 || a.variant == 5, "gemm: folded LayerNorm is built for the 256-tile kernel only");
+        variant = 5;
     }
     if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
-    if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? (ln_fold ? 2 : 5) : 3;   // 5 falls back to 2 for epilogues it does not have
-    if (variant == 5 && a.K < 2 * BK) variant = 2;
-    if ((variant == 2 || variant == 5) && (a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
+    if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 5 : 3;
+    if (variant == 2) variant = 5;
+    if (variant == 5 && (a.K < 2 * BK || a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
     if (variant == 5) {
-        // the streaming kernel has the two branch-free epilogues only; everything else runs the tile-per-workgroup kernel
-        const bool fast_half = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.resid_half && !a.row_zero && !ln_fold;
-        const bool fast_resid = a.out_half && a.bias && a.resid_half && !a.gelu && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero && !ln_fold;
-        if (!fast_half && !fast_resid) variant = 2;
-    }
-    if (variant == 5) {
-        AVX_ENSURE_LDS((gemm256p_kernel<T, 1>), LDS5);
-        AVX_ENSURE_LDS((gemm256p_kernel<T, 2>), LDS5);
         int n_cu = 256;
         { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
         avx::GemmArgs a5 = a;
-        a5.stagger_ticks = 0; a5.stagger_groups = 1;
+        static const int order = getenv("AVEX_AMD_GEMM_TILE_ORDER") ? atoi(getenv("AVEX_AMD_GEMM_TILE_ORDER")) : 0;
+        a5.tile_order = order;
         a5.nt = gemm_nt_mode(a);
         int grid = tiles < n_cu ? ((tiles + 7) / 8) * 8 : (n_cu / 8) * 8;
         if (grid < 8) grid = 8;
         if (const char* fg = getenv("AVEX_AMD_GEMM_GRID")) { const int g = atoi(fg); if (g >= 8) grid = (g / 8) * 8; }   // tests: force many tiles per workgroup
-        const bool fast_half = !a.resid_half;
-        if (fast_half) hipLaunchKernelGGL((gemm256p_kernel<T, 1>), dim3(grid), dim3(512), LDS5, s, a5);
-        else hipLaunchKernelGGL((gemm256p_kernel<T, 2>), dim3(grid), dim3(512), LDS5, s, a5);
-        AVX_LAUNCH_CHECK();
-        return AVEXHIP_OK;
-    }
-    if (variant == 2) {
-        AVX_ENSURE_LDS(gemm256_kernel<T>, LDS2);
-        const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
-        static const int order = getenv("AVEX_AMD_GEMM_TILE_ORDER") ? atoi(getenv("AVEX_AMD_GEMM_TILE_ORDER")) : 0;
-        avx::GemmArgs a2 = a;
-        a2.tile_order = order;
-        a2.nt = gemm_nt_mode(a);
-        hipLaunchKernelGGL((gemm256_kernel<T>), dim3(tiles), dim3(512), LDS2, s, a2);
-        AVX_LAUNCH_CHECK();
-        return AVEXHIP_OK;
+        const char* fgen = getenv("AVEX_AMD_GEMM_GENERIC");
+        const bool force_generic = fgen && atoi(fgen) != 0;     // tests: cross-check of the fast epilogues
+        const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero && !force_generic;
+        const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out;
+        const bool fast_resid = plain_out && (a.resid_half || a.lnr_y) && !a.gelu && !a.ln_rows;
+        if (fast_half) return a.ln_rows ? launch256<T, 1, 1>(a5, grid, s) : launch256<T, 1, 0>(a5, grid, s);
+        if (fast_resid) {
+            if (a.lnr_y) return a.stats_out ? launch256<T, 2, 3>(a5, grid, s) : launch256<T, 2, 1>(a5, grid, s);
+            return a.stats_out ? launch256<T, 2, 2>(a5, grid, s) : launch256<T, 2, 0>(a5, grid, s);
+        }
+        return launch256<T, 0, 0>(a5, grid, s);
     }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     static const char* pad_env = getenv("AVEX_AMD_DEBUG_LDS_PAD");
@@ -1048,10 +842,26 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
                     (!a.out_raw || a.ldraw % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&
                     (!a.resid_half || a.ldrh % 4 == 0),
                 "gemm: output/residual leading dims must be multiples of 4 elements");
-    if (dtype == AVEXHIP_F16) return launch<_Float16>(a, s);
-    if (dtype == AVEXHIP_BF16) return launch<__bf16>(a, s);
-    avexhip_set_error("gemm: unknown dtype %d", dtype);
-    return AVEXHIP_ERR_INVALID;
+    if (dtype != AVEXHIP_F16 && dtype != AVEXHIP_BF16) {
+        avexhip_set_error("gemm: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    if (a.lnr_y && !a.lnr_prefolded) {
+        // the kernel takes alpha * gamma and bias + alpha * beta: callers that launch the same fold repeatedly keep those vectors
+        // (lnr_prefolded); for the others they are made here, in stream-ordered scratch
+        AVX_REQUIRE(a.lnr_gamma && a.lnr_beta && a.bias, "gemm: lnr_y needs lnr_gamma, lnr_beta and bias");
+        float* tmp = nullptr;
+        AVX_HIP_CHECK(hipMallocAsync((void**)&tmp, sizeof(float) * 2 * (size_t)a.N, s));
+        GemmArgs b = a;
+        int rc = lnr_fold(a.lnr_gamma, a.lnr_beta, a.bias, a.alpha, a.N, tmp, tmp + a.N, s);
+        if (rc == AVEXHIP_OK) {
+            b.lnr_gamma = tmp; b.lnr_beta = tmp + a.N; b.lnr_prefolded = 1;
+            rc = dtype == AVEXHIP_F16 ? launch<_Float16>(b, s) : launch<__bf16>(b, s);
+        }
+        (void)hipFreeAsync(tmp, s);
+        return rc;
+    }
+    return dtype == AVEXHIP_F16 ? launch<_Float16>(a, s) : launch<__bf16>(a, s);
 }
 
 }  // namespace avx

@@ -6,7 +6,10 @@ libavexhip.so.  Every function raises ``AvexHipError`` if the library or a GPU i
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import math
+import os
+import warnings
 from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -14,6 +17,8 @@ import torch
 
 from . import _capi
 from ._capi import AvexHipError, BeatsConfig, FbankConfig, GemmArgs, MelspecConfig, Tensor, check, dtype_code, lib
+
+logger = logging.getLogger(__name__)
 
 F32_EPS = 1.1920929e-07
 
@@ -374,14 +379,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
          resid: Optional[torch.Tensor] = None, resid_half: Optional[torch.Tensor] = None, alpha: float = 1.0,
          gelu: bool = False, silu: bool = False,
          out_f32: bool = True, out_half: bool = False, out_raw: bool = False, variant: int = 0,
-         ln_stats: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-         lnr_y: Optional[torch.Tensor] = None, lnr_stats: Optional[torch.Tensor] = None,
+         ln_rows: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None,
+         lnr_y: Optional[torch.Tensor] = None, lnr_rows: Optional[torch.Tensor] = None,
          lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False,
-         lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0
-         ) -> Dict[str, torch.Tensor]:
-    """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_stats``/``ln_s`` fold a
-    LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual, ``stats_out`` returns the
-    per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"`` (include/avexhip.h)."""
+         lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0,
+         overflow: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_rows``/``ln_s`` fold a
+    LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual (the ``*_rows`` tensors come from
+    :func:`ln_rowstats`), ``stats_out`` returns the per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"``;
+    ``overflow`` is an optional ``uint32``/``int32`` device scalar the f16 range alarm adds to (include/avexhip.h)."""
     _need_cuda(a, w)
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise ValueError("a and w must both be float16 or bfloat16")
@@ -418,18 +424,42 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     if out_raw:
         res["raw"] = torch.empty((M, N), dtype=torch.float32, device=a.device)
         args.out_raw, args.ldraw = _ptr(res["raw"]), N
-    if ln_stats is not None:
-        ln_stats = ln_stats.contiguous()
-        args.ln_stats, args.ln_nseg, args.ln_eps, args.ln_s = _ptr(ln_stats), ln_stats.shape[1], ln_eps, _ptr(ln_s)
+    if ln_rows is not None:
+        ln_rows = _padded_rows(ln_rows, M)
+        args.ln_rows, args.ln_s = _ptr(ln_rows), _ptr(ln_s)
     if lnr_y is not None:
-        lnr_y, lnr_stats = lnr_y.contiguous(), lnr_stats.contiguous()
-        args.lnr_y, args.ldy, args.lnr_stats, args.lnr_nseg = _ptr(lnr_y), N, _ptr(lnr_stats), lnr_stats.shape[1]
-        args.lnr_gamma, args.lnr_beta, args.ln_eps = _ptr(lnr_gamma), _ptr(lnr_beta), ln_eps
+        lnr_y, lnr_rows = lnr_y.contiguous(), lnr_rows.contiguous()
+        args.lnr_y, args.ldy, args.lnr_rows = _ptr(lnr_y), N, _ptr(lnr_rows)
+        args.lnr_gamma, args.lnr_beta = _ptr(lnr_gamma), _ptr(lnr_beta)
+    if overflow is not None:
+        if overflow.numel() != 1 or overflow.element_size() != 4 or not overflow.is_cuda:
+            raise ValueError("overflow must be a 4-byte device scalar")
+        args.overflow_count = _ptr(overflow)
     if stats_out:
         res["stats"] = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=a.device)
         args.stats_out = _ptr(res["stats"])
     check(lib().avexhip_gemm(C.byref(args), code, _stream()), "gemm")
     return res
+
+
+def _padded_rows(rows: torch.Tensor, M: int) -> torch.Tensor:
+    """(rstd, shift) pairs readable up to an even number of rows (the kernel fetches them two rows at a time)."""
+    rows = rows.contiguous()
+    if rows.shape[0] >= M + (M & 1):
+        return rows
+    out = torch.zeros((M + (M & 1), 2), dtype=torch.float32, device=rows.device)
+    out[:rows.shape[0]] = rows
+    return out
+
+
+def ln_rowstats(stats: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """Partial statistics ``[M, nseg, 2]`` (``gemm(..., stats_out=True)["stats"]``) -> ``[M (+1 if odd), 2]`` = (rstd, -mean * rstd)."""
+    _need_cuda(stats)
+    stats = stats.contiguous()
+    M, nseg, _ = stats.shape
+    rows = torch.zeros((M + (M & 1), 2), dtype=torch.float32, device=stats.device)
+    check(lib().avexhip_ln_rowstats(_ptr(stats), M, nseg, eps, _ptr(rows), _stream()), "ln_rowstats")
+    return rows
 
 
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, half_dtype="f16",
@@ -559,9 +589,21 @@ class BeatsEncoder:
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype="f16",
-                 max_chunk_clips: int = 0, residual="half") -> None:
+                 max_chunk_clips: int = 0, residual="half", on_overflow: Optional[str] = None) -> None:
+        """``on_overflow``: what to do when an f16 conversion inside the forward clipped a value to +-65504 (the handle's sticky range
+        alarm, ``avexhip_beats_overflow_count``; the reference computes in fp32 and has no such limit, backbone.py:350-375):
+        ``"warn"`` (default; checked without synchronising, so the warning may come one call late), ``"raise"``, ``"retry"`` (the
+        batch is run again with bf16 operands and an fp32 residual stream -- fp32's exponent range, 2e-3 instead of 3e-4 of the
+        reference -- and that result is returned; both synchronise after every forward) or ``"ignore"``.  Environment default:
+        ``AVEX_AMD_ON_OVERFLOW``."""
         _capi.require_gpu()
         self.cfg = dict(cfg)
+        self.on_overflow = (on_overflow or os.environ.get("AVEX_AMD_ON_OVERFLOW") or "warn").lower()
+        if self.on_overflow not in ("warn", "raise", "retry", "ignore"):
+            raise ValueError(f"on_overflow must be 'warn', 'raise', 'retry' or 'ignore', got {self.on_overflow!r}")
+        self._overflow_seen = 0
+        self._fallback: Optional["BeatsEncoder"] = None
+        self._fallback_args = (dict(cfg), state, max_chunk_clips) if self.on_overflow == "retry" and dtype_code(operand_dtype) == _capi.F16 else None
         self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual)
         self.E = int(cfg["encoder_embed_dim"])
         self.L = int(cfg["encoder_layers"])
@@ -633,7 +675,39 @@ class BeatsEncoder:
         check(lib().avexhip_beats_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(pad), mask, ptrs,
                                           int(hook_pooled), _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
               "beats_forward")
+        if self.on_overflow != "ignore":
+            new = self._new_overflow(sync=self.on_overflow in ("raise", "retry"))
+            if new:
+                msg = (f"avex_amd: {new} lane(s) clipped a value to the f16 range (+-65504) inside the BEATs forward: the result is not the "
+                       "reference's.  Use operand_dtype='bf16' with residual='f32' (fp32's exponent range), or on_overflow='retry'.")
+                if self.on_overflow == "raise":
+                    raise AvexHipError(msg)
+                if self.on_overflow == "retry" and self._fallback_args is not None:
+                    if self._fallback is None:
+                        fcfg, fstate, fchunk = self._fallback_args
+                        self._fallback = BeatsEncoder(fcfg, fstate, operand_dtype="bf16", max_chunk_clips=fchunk, residual="f32", on_overflow="ignore")
+                    logger.warning(msg + "  Re-running the batch with bf16 operands and an fp32 residual stream.")
+                    return self._fallback.forward(wav, hook_layers=hook_layers, hook_pooled=hook_pooled, want_features=want_features,
+                                                  want_pooled=want_pooled, frame_pad=frame_pad)
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
         return {"features": feats, "pooled": pooled, "hooks": hooks, "tokens": Tt}
+
+    def overflow_events(self, sync: bool = True) -> int:
+        """The handle's sticky range-alarm count (0 = no f16 conversion ever clipped); ``sync`` waits for the current stream first."""
+        n = C.c_uint32(0)
+        check(lib().avexhip_beats_overflow_count(self._h, C.byref(n), _stream(), int(bool(sync))), "beats_overflow_count")
+        return int(n.value)
+
+    def reset_overflow(self) -> None:
+        check(lib().avexhip_beats_overflow_reset(self._h, _stream()), "beats_overflow_reset")
+        torch.cuda.current_stream().synchronize()
+        self._overflow_seen = 0
+
+    def _new_overflow(self, sync: bool) -> int:
+        n = self.overflow_events(sync=sync)
+        new = n - self._overflow_seen
+        self._overflow_seen = n
+        return max(new, 0)
 
     def set_profiling(self, enabled: bool) -> None:
         check(lib().avexhip_beats_set_profiling(self._h, int(enabled)), "set_profiling")
@@ -647,6 +721,9 @@ class BeatsEncoder:
         return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
 
     def close(self) -> None:
+        if getattr(self, "_fallback", None) is not None:
+            self._fallback.close()
+            self._fallback = None
         if getattr(self, "_h", None):
             lib().avexhip_beats_destroy(self._h)
             self._h = None

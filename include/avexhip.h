@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 4
+#define AVEXHIP_ABI_VERSION 5
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -207,23 +207,32 @@ typedef struct {
     float* out_f32;  int64_t ldo;
     void*  out_half; int64_t ldh;
     float* out_raw;  int64_t ldraw;
-    int32_t variant;                   /* 0 = auto; 1 = 128-tile, register staging; 2 = 256-tile half-tile
-                                          LDS-DMA pipeline (needs N % 256 == 0); 3 = 128-tile LDS-DMA;
-                                          5 = variant 2 with persistent workgroups */
-    /* LayerNorm folded into the GEMMs around it (all NULL/0 = off; variant 2 only, N % 256 == 0).
+    int32_t variant;                   /* 0 = auto; 1 = 128-tile, register staging; 3 = 128-tile LDS-DMA;
+                                          5 (or 2) = 256-tile half-tile LDS-DMA pipeline, persistent workgroups
+                                          (needs N % 256 == 0, K >= 128) */
+    /* LayerNorm folded into the GEMMs around it (all NULL/0 = off; the 256-tile kernel only: N % 256 == 0, K >= 128).
      * A tensor y that is only consumed through LayerNorm (backbone.py:363,374: x = LN(residual * alpha + sublayer))
-     * stays raw in the operand type with per-row partial statistics [M][width/64][2] = (sum, sum of squares)
-     * of its 64-column segments, written by the GEMM that produced it (stats_out, from the rounded outputs).
+     * stays raw in the operand type.  The GEMM that produces it writes per-row partial statistics
+     * [M][N/64][2] = (sum, sum of squares) of its 64-column segments (stats_out, from the fp32 values);
+     * avexhip_ln_rowstats turns them into one (rstd, -mean * rstd) pair per row; the consumers take those pairs:
      *  - A operand = LN(y):  pass A = y, W = W * diag(gamma), bias = b + W beta, ln_s[n] = sum_k W'[n][k],
-     *    ln_stats = y's statistics (64 * ln_nseg == K); the epilogue forms rstd * (acc - mu * ln_s) + bias.
-     *  - residual = LN(y):   pass lnr_y = y (ld ldy), its statistics (64 * lnr_nseg == N), gamma, beta:
-     *    out = alpha * ((y - mu) * rstd * gamma + beta) + acc + bias.  */
-    const float* ln_stats; int32_t ln_nseg; float ln_eps; const float* ln_s;
-    const void*  lnr_y; int64_t ldy; const float* lnr_stats; int32_t lnr_nseg;
+     *    ln_rows = y's pairs; the epilogue forms rstd * acc + (-mean rstd) * ln_s + bias.
+     *  - residual = LN(y):   pass lnr_y = y (ld ldy), lnr_rows = its pairs, gamma, beta:
+     *    out = alpha * ((y * rstd - mean rstd) * gamma + beta) + acc + bias.  */
+    const float* ln_rows; const float* ln_s;
+    const void*  lnr_y; int64_t ldy; const float* lnr_rows;
     const float* lnr_gamma; const float* lnr_beta;
     float* stats_out;
+    /* Range alarm of f16 outputs (conversions saturate at +-65504 silently): when non-NULL, the kernel adds to this device
+     * counter the number of lanes that rounded at least one |value| > 65504 to an f16 output (a lower bound of the number of
+     * clipped elements; 0 = nothing clipped).  bf16 outputs cannot overflow and never count. */
+    uint32_t* overflow_count;
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
+/* stats [M][nseg][2] as written through avexhip_gemm_args.stats_out (nseg = row width / 64, even) -> rows [M][2] =
+ * (rstd, -mean * rstd) with rstd = 1 / sqrt(var + eps); segments are added in order (bit-reproducible).  `rows` must be
+ * readable up to M rounded up to an even number of rows. */
+int avexhip_ln_rowstats(const float* stats_dev, int M, int nseg, float eps, float* rows_dev, void* stream);
 
 /* torch.nn.LayerNorm over the last dim C (C % 4 == 0, C <= 1024), eps inside sqrt; writes fp32
  * and/or half copies; the input is fp32 (in_dev) or the operand type (in_half_dev), exactly one
@@ -353,6 +362,16 @@ int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank_dev, int B,
 /* Per-stage timing of the most recent forward on this handle is available when the handle was put
  * in profiling mode (HIP events on the launch stream; forces a stream sync at the end of forward).
  * names/ms arrays are library-owned and valid until the next forward. */
+/* Range alarm.  The residual stream and every GEMM output of the default mode are f16; conversions saturate at +-65504 instead of
+ * producing inf, silently.  Each handle keeps a sticky count of the lanes that clipped at least one value (see
+ * avexhip_gemm_args.overflow_count); every forward ends with an asynchronous copy of it to pinned host memory.
+ * overflow_count returns that host copy: with synchronize = 0 whatever has arrived (never blocks: a forward still in flight is
+ * not included), with synchronize != 0 after hipStreamSynchronize(sync_stream).  0 = nothing was ever clipped; > 0 = results
+ * since the last reset may be wrong: rerun with operand_dtype bf16 (fp32's exponent range) and residual_dtype 0 (fp32 stream).
+ * bf16 handles never count.  The reference computes in fp32 throughout (backbone.py:350-375). */
+int avexhip_beats_overflow_count(avexhip_beats* h, uint32_t* events, void* sync_stream, int synchronize);
+int avexhip_beats_overflow_reset(avexhip_beats* h, void* stream);
+
 int avexhip_beats_set_profiling(avexhip_beats* h, int enabled);
 int avexhip_beats_last_profile(const avexhip_beats* h, const char* const** names, const float** ms,
                                const double** flops, int* count);

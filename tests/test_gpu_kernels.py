@@ -100,11 +100,12 @@ def test_gemm_epilogues(built_lib, dtype, variant, shape):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2500, 768, 256), (3000, 512, 128), (1100, 3072, 192)])
-def test_gemm_persistent_matches_tiled(built_lib, dtype, shape, monkeypatch):
-    """Variant 5 (persistent workgroups) walks several tiles per workgroup when the grid is forced to 8:
-    every epilogue must reproduce variant 2 bit for bit (same K order, same epilogue arithmetic)."""
+def test_gemm_persistent_walk_and_epilogues_agree(built_lib, dtype, shape, monkeypatch):
+    """The 256-tile kernel is persistent: with the grid forced to 8 every workgroup walks many tiles (the continuous K stream across
+    tile boundaries, the one-tile-ahead LDS-DMA of the bias row, the counted waits around the epilogue).  Every epilogue must give
+    the same bits (i) whatever the grid, (ii) through its fast form and through the generic one (AVEX_AMD_GEMM_GENERIC=1), and
+    (iii) for the plain / bias / GELU epilogues, as the 128-tile kernel (same K order, same arithmetic)."""
     from avex_amd import kernels as K
-    monkeypatch.setenv("AVEX_AMD_GEMM_GRID", "8")
     M, N, Kd = shape
     a = _dev(round_half(synth.normal(f"pA{shape}", (M, Kd), 1.0), dtype), _tdt(dtype))
     w = _dev(round_half(synth.normal(f"pW{shape}", (N, Kd), 0.05), dtype), _tdt(dtype))
@@ -113,15 +114,27 @@ def test_gemm_persistent_matches_tiled(built_lib, dtype, shape, monkeypatch):
     resid = _dev(synth.normal("presid32", (M, N), 1.0))
     cases = [dict(out_f32=False, out_half=True), dict(out_f32=False, out_half=True, gelu=True),
              dict(out_f32=False, out_half=True, resid_half=rh, alpha=2.2133638),
+             dict(out_f32=False, out_half=True, resid_half=rh, alpha=2.2133638, stats_out=True),
              dict(out_f32=True, out_half=True, out_raw=True, resid=resid, alpha=2.2133638),
              dict(out_f32=True, resid_half=rh, alpha=0.5, gelu=True)]
-    for kw in cases:
+    for ci, kw in enumerate(cases):
+        monkeypatch.delenv("AVEX_AMD_GEMM_GRID", raising=False)
+        monkeypatch.delenv("AVEX_AMD_GEMM_GENERIC", raising=False)
+        ref = K.gemm(a, w, bias=bias, variant=5, **kw)
+        monkeypatch.setenv("AVEX_AMD_GEMM_GRID", "8")
         for _ in range(2):          # twice: a stale prologue from the previous launch must not matter
-            r5 = K.gemm(a, w, bias=bias, variant=5, **kw)
-            r2 = K.gemm(a, w, bias=bias, variant=2, **kw)
-            for key in r2:
-                if r2[key] is not None:
-                    assert torch.equal(r5[key], r2[key]), (kw.keys(), key)
+            r8 = K.gemm(a, w, bias=bias, variant=5, **kw)
+            for key in ref:
+                assert torch.equal(r8[key], ref[key]), (ci, key, "grid 8")
+        monkeypatch.setenv("AVEX_AMD_GEMM_GENERIC", "1")
+        rg = K.gemm(a, w, bias=bias, variant=5, **kw)
+        for key in ref:
+            assert torch.equal(rg[key], ref[key]), (ci, key, "generic epilogue")
+        monkeypatch.delenv("AVEX_AMD_GEMM_GRID", raising=False)
+        monkeypatch.delenv("AVEX_AMD_GEMM_GENERIC", raising=False)
+        if ci < 2:
+            r3 = K.gemm(a, w, bias=bias, variant=3, **kw)
+            assert torch.equal(r3["half"], ref["half"]), (ci, "128-tile kernel")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -149,13 +162,17 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
     # (sums are taken from the fp32 values before the row is rounded to the operand type)
     assert np.allclose(st[..., 0], seg.sum(-1), rtol=1e-3, atol=0.05 if dtype == "f16" else 0.4) and np.allclose(st[..., 1], (seg ** 2).sum(-1), rtol=2e-3 if dtype == "f16" else 1e-2, atol=0.3)
     ln = O.layer_norm(y.astype(np.float32), gamma.astype(np.float32), beta.astype(np.float32)).astype(np.float64)   # LN of the ROUNDED rows
+    rows = K.ln_rowstats(r["stats"])             # (rstd, -mean rstd) per row, from the producer's partial sums
+    yd = y.astype(np.float64)
+    assert np.allclose(rows[:M, 0].cpu().numpy(), 1.0 / np.sqrt(yd.var(1) + 1e-5), rtol=2e-4)
+    assert np.allclose(rows[:M, 1].cpu().numpy(), -yd.mean(1) / np.sqrt(yd.var(1) + 1e-5), rtol=2e-3, atol=2e-4)
     # consumer A: gelu(LN(y) @ w1.T + b1) through folded weights
     w1 = synth.normal("lnW1", (F, E), 0.05); b1 = synth.normal("lnb1", (F,), 0.1)
     w1f = rnd((w1 * gamma[None, :]).astype(np.float32))
     s1 = w1f.astype(np.float64).sum(1).astype(np.float32)
     b1f = (b1 + w1.astype(np.float64) @ beta).astype(np.float32)
     for gelu in (False, True):
-        r1 = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), gelu=gelu, out_f32=False, out_half=True, ln_stats=r["stats"], ln_s=_dev(s1))
+        r1 = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), gelu=gelu, out_f32=False, out_half=True, ln_rows=rows, ln_s=_dev(s1))
         # exact model of the fold: LN(y) (gamma folded and ROUNDED into w1f) @ ...
         mu = y.astype(np.float64).mean(1, keepdims=True); rstd = 1.0 / np.sqrt(y.astype(np.float64).var(1, keepdims=True) + 1e-5)
         ref1 = ((y - mu) * rstd) @ w1f.astype(np.float64).T + b1f
@@ -168,14 +185,14 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
             ref_unf = O.gelu_erf(ref_unf.astype(np.float32))
         assert rel_l2(r1["half"].float().cpu().numpy(), ref_unf) < (1.2e-3 if dtype == "f16" else 8e-3)
     # generic epilogue with the fold (fp32 output)
-    r1g = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), ln_stats=r["stats"], ln_s=_dev(s1))
+    r1g = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), ln_rows=rows, ln_s=_dev(s1))
     # (the statistics come from the fp32 rows before rounding: mu differs from the rounded rows' mean by ~1e-5 sigma)
     assert rel_l2(r1g["f32"].cpu().numpy(), ((y - mu) * rstd) @ w1f.astype(np.float64).T + b1f) < (1e-4 if dtype == "f16" else 1e-3)
     # consumer R: out = alpha * LN(y) + a2 @ w2.T + b2, fast path (+ statistics), and generic path with a raw tap
     a2 = rnd(synth.normal("lnA2", (M, 512), 1.0)); w2 = rnd(synth.normal("lnW2", (E, 512), 0.05)); b2 = synth.normal("lnb2", (E,), 0.1)
     raw_ref = a2.astype(np.float64) @ w2.astype(np.float64).T + b2
     ref2 = alpha * ln + raw_ref
-    kw = dict(bias=_dev(b2), alpha=alpha, lnr_y=r["half"], lnr_stats=r["stats"], lnr_gamma=_dev(gamma.astype(np.float32)), lnr_beta=_dev(beta.astype(np.float32)))
+    kw = dict(bias=_dev(b2), alpha=alpha, lnr_y=r["half"], lnr_rows=rows, lnr_gamma=_dev(gamma.astype(np.float32)), lnr_beta=_dev(beta.astype(np.float32)))
     r2 = K.gemm(_dev(a2, td), _dev(w2, td), out_f32=False, out_half=True, stats_out=True, **kw)
     out2 = r2["half"].float().cpu().numpy()
     assert rel_l2(out2, ref2) < (6e-4 if dtype == "f16" else 5e-3)

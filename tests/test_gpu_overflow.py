@@ -1,0 +1,180 @@
+"""The f16 range alarm (`-m gpu`).  The default mode keeps the residual stream and every GEMM output in f16; conversions saturate at
++-65504 silently (csrc/common.h Half<_Float16>::from), while the reference computes in fp32 throughout (backbone.py:350-375).  Every
+GEMM epilogue therefore tracks the largest magnitude it rounds and the handle keeps a sticky count (avexhip_beats_overflow_count).
+These tests drive heavy-tailed synthetic checkpoints -- the published goldens all have O(1) activations -- and check that (i) the
+alarm fires exactly when a value left the f16 range, (ii) the wide modes (fp32 residual stream; bf16 operands) stay finite and inside
+their tolerance of the CPU oracle on the same weights, (iii) the policies warn / raise / retry do what they say.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from _util import rel_l2, round_half
+from avex_amd import synth
+from oracle import beats_oracle as O
+
+pytestmark = pytest.mark.gpu
+CFG = synth.BEATS_BASE_CFG
+
+
+def _dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dt is None else t.to(dt)
+
+
+# ------------------------------------------------------------------ kernel level
+@pytest.mark.parametrize("M", [300, 2048])          # 128-tile kernel / 256-tile streaming kernel
+def test_gemm_range_alarm_counts_only_what_leaves_the_f16_range(built_lib, M):
+    from avex_amd import kernels as K
+    N, Kd = 512, 256
+    a = round_half(synth.normal("ovA", (M, Kd), 1.0), "f16")
+    w = round_half(synth.normal("ovW", (N, Kd), 0.05), "f16")
+    bias = synth.normal("ovb", (N,), 0.1).astype(np.float32)
+    big = bias.copy(); big[37] = 7.0e4; big[300] = -9.0e4           # two columns leave the range in every row
+    rh = round_half(synth.normal("ovr", (M, N), 1.0), "f16")
+    for dt, td in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ad, wd = _dev(a, td), _dev(w, td)
+        K.gemm(ad, wd, bias=_dev(bias), out_f32=False, out_half=True, overflow=ctr)                           # EPI 1
+        K.gemm(ad, wd, bias=_dev(bias), gelu=True, out_f32=False, out_half=True, overflow=ctr)
+        K.gemm(ad, wd, bias=_dev(bias), resid_half=_dev(rh, td), alpha=2.2, out_f32=False, out_half=True, overflow=ctr)        # EPI 2
+        K.gemm(ad, wd, bias=_dev(bias), resid_half=_dev(rh, td), alpha=2.2, out_f32=True, out_half=True, overflow=ctr)         # generic
+        assert int(ctr.item()) == 0, "in-range values must not count"
+        r = K.gemm(ad, wd, bias=_dev(big), out_f32=False, out_half=True, overflow=ctr)
+        n1 = int(ctr.item())
+        out = r["half"].float()
+        assert bool(torch.isfinite(out).all())
+        if dt == "f16":
+            assert n1 > 0 and float(out[:, 37].min()) == 65504.0 and float(out[:, 300].max()) == -65504.0      # saturated, and said so
+        else:
+            assert n1 == 0 and abs(float(out[0, 37]) - 7.0e4) < 600                                           # bf16: fp32's exponent range
+        K.gemm(ad, wd, bias=_dev(big), resid_half=_dev(rh, td), alpha=2.2, out_f32=False, out_half=True, overflow=ctr)
+        K.gemm(ad, wd, bias=_dev(big), resid_half=_dev(rh, td), alpha=2.2, out_f32=True, out_half=True, overflow=ctr)
+        n3 = int(ctr.item())
+        assert (n3 > 2 * n1 > 0) if dt == "f16" else n3 == 0
+        # fp32-only outputs round nothing to f16
+        ctr.zero_()
+        K.gemm(ad, wd, bias=_dev(big), out_f32=True, overflow=ctr)
+        assert int(ctr.item()) == 0
+
+
+# ------------------------------------------------------------------ end to end
+def _heavy_checkpoint(kind: str):
+    """Synthetic BEATs-base weights with outliers: LayerNorm gains x50 on a few channels, input at 8x full scale, and
+    kind "residual": three fc2 rows x 1e6 in layer 5 -> |x * alpha + fc2(h)| reaches ~8e4 on a few (token, channel) pairs;
+    kind "hidden":   two fc1 rows x 3e6 in layer 7 -> the GELU hidden activations themselves pass 65504."""
+    sd = dict(synth.beats_state_dict(CFG, seed=0))
+    k = "backbone.encoder.layers.3.final_layer_norm.weight"
+    w = sd[k].copy(); w[[5, 77, 300, 511]] *= 50.0; sd[k] = w
+    k = "backbone.encoder.layers.8.self_attn_layer_norm.weight"
+    w = sd[k].copy(); w[[11, 400]] *= 50.0; sd[k] = w
+    if kind == "residual":
+        k = "backbone.encoder.layers.5.fc2.weight"
+        w = sd[k].copy(); w[[9, 130, 640]] *= 1.0e6; sd[k] = w
+    else:
+        k = "backbone.encoder.layers.7.fc1.weight"
+        w = sd[k].copy(); w[[21, 2000]] *= 3.0e6; sd[k] = w
+    return sd
+
+
+@pytest.fixture(scope="module")
+def clips():
+    return synth.noise_clips(2, 32000, seed=3) * 8.0
+
+
+def _run(sd, x, **kw):
+    from avex_amd import kernels as K
+    enc = K.BeatsEncoder(CFG, sd, **kw)
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            r = enc.forward(torch.from_numpy(x).cuda(), want_features=True, want_pooled=True)
+            torch.cuda.synchronize()
+        return r["features"].cpu().numpy(), r["pooled"].cpu().numpy(), enc.overflow_events(), [str(c.message) for c in caught]
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("kind", ["residual", "hidden"])
+def test_heavy_tailed_checkpoint(built_lib, clips, kind):
+    sd = _heavy_checkpoint(kind)
+    f_ref, taps = O.beats_forward(clips, sd, CFG)
+    p_ref = f_ref.mean(1)
+    assert np.isfinite(f_ref).all()
+    if kind == "residual":          # the oracle (fp32, like the reference) sees the out-of-range sums
+        assert np.abs(taps["backbone.encoder.layers.5.fc2"]).max() > 65504.0
+    # (i) default mode: the alarm fires (whatever the output looks like)
+    _, _, n, msgs = _run(sd, clips, operand_dtype="f16", residual="half", on_overflow="warn")
+    assert n > 0
+    # (ii) bf16 operands with an fp32 residual stream: fp32's exponent range everywhere, nothing to count, inside the bf16 tolerance
+    f, p, n_bf, _ = _run(sd, clips, operand_dtype="bf16", residual="f32")
+    assert n_bf == 0 and np.isfinite(f).all()
+    e_bf = rel_l2(p, p_ref)
+    print(f"[{kind}] bf16 / f32 residual: pooled rel-L2 {e_bf:.2e}, frame-level {rel_l2(f, f_ref):.2e}")
+    assert e_bf < 8e-3
+    f, p, n_bfh, _ = _run(sd, clips, operand_dtype="bf16", residual="half")
+    assert n_bfh == 0 and np.isfinite(f).all()
+    print(f"[{kind}] bf16 / bf16 residual: pooled rel-L2 {rel_l2(p, p_ref):.2e}")
+    assert rel_l2(p, p_ref) < 2e-2
+    # f16 operands with an fp32 residual stream: the pre-LayerNorm sums never pass through f16, so the "residual" outliers are harmless;
+    # the "hidden" ones clip in fc1's own f16 output and the alarm must say so
+    f, p, n_32, _ = _run(sd, clips, operand_dtype="f16", residual="f32", on_overflow="ignore")
+    assert np.isfinite(f).all()
+    if kind == "residual":
+        e_32 = rel_l2(p, p_ref)
+        print(f"[{kind}] f16 / f32 residual: pooled rel-L2 {e_32:.2e}, frame-level {rel_l2(f, f_ref):.2e}")
+        assert n_32 == 0 and e_32 < 3e-3
+    else:
+        assert n_32 > 0
+
+
+def test_overflow_policies(built_lib, clips):
+    from avex_amd import kernels as K
+    from avex_amd._capi import AvexHipError
+    sd = _heavy_checkpoint("residual")
+    x = torch.from_numpy(clips).cuda()
+    # warn: a RuntimeWarning, at the latest on the call after the one that clipped (the check does not synchronise)
+    enc = K.BeatsEncoder(CFG, sd, on_overflow="warn")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        enc.forward(x, want_features=False, want_pooled=True)
+        torch.cuda.synchronize()
+        enc.forward(x, want_features=False, want_pooled=True)
+    assert any("f16 range" in str(c.message) for c in caught)
+    n = enc.overflow_events()
+    assert n > 0
+    enc.reset_overflow()
+    assert enc.overflow_events() == 0
+    enc.close()
+    # raise
+    enc = K.BeatsEncoder(CFG, sd, on_overflow="raise")
+    with pytest.raises(AvexHipError, match="f16 range"):
+        enc.forward(x, want_features=False, want_pooled=True)
+    enc.close()
+    # retry: the result IS the wide mode's result
+    enc = K.BeatsEncoder(CFG, sd, on_overflow="retry")
+    got = enc.forward(x, want_features=False, want_pooled=True)["pooled"]
+    enc.close()
+    wide = K.BeatsEncoder(CFG, sd, operand_dtype="bf16", residual="f32", on_overflow="ignore")
+    want = wide.forward(x, want_features=False, want_pooled=True)["pooled"]
+    wide.close()
+    assert torch.equal(got, want)
+    # a clean checkpoint never alarms, in any mode
+    clean = synth.beats_state_dict(CFG, seed=0)
+    enc = K.BeatsEncoder(CFG, clean, on_overflow="raise")
+    enc.forward(torch.from_numpy(synth.noise_clips(2, 32000, seed=3)).cuda(), want_features=False, want_pooled=True)
+    assert enc.overflow_events() == 0
+    enc.close()
+
+
+def test_model_class_exposes_the_alarm(built_lib, clips):
+    import avex_amd
+    spec = avex_amd.get_model_spec("esp_aves2_sl_beats_all").model_copy(deep=True)
+    m = avex_amd.build_model_from_spec(spec, "cuda", return_features_only=True, on_overflow="ignore")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _heavy_checkpoint("residual").items()}, strict=False)
+    m.eval()
+    assert m.overflow_events() == 0
+    m(torch.from_numpy(clips).cuda())
+    assert m.overflow_events() > 0
