@@ -915,9 +915,10 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->fast = c.residual_dtype != 0;
     {
         const char* e = getenv("AVEX_AMD_LN_FOLD");
-        // AVEX_AMD_LN_FOLD=1 folds the encoder's LayerNorms into the GEMM epilogues (tile-per-workgroup kernel).  Off by default since the
-        // streaming GEMM (which has the plain epilogues only) overtook it: 9 132-9 157 vs 9 035-9 048 clips/s (profiles/r01h_gemm_stream.txt)
-        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && (e && atoi(e) != 0);
+        // The encoder's LayerNorms are folded into the GEMM epilogues around them (GemmArgs) unless AVEX_AMD_LN_FOLD=0: 24 LayerNorm
+        // launches and 9 GB of traffic per 256-clip step disappear, +2.7 % (9 367 -> 9 623 clips/s alternating inside one process,
+        // profiles/r03a_ln_fold.txt) and one rounding of the residual stream less per sublayer.
+        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && !(e && atoi(e) == 0);
     }
     {
         // Independent chunks of a batch can overlap on several HIP streams: one chunk's HBM-bound kernels

@@ -306,15 +306,16 @@ def main():
         enc.forward(wav, want_features=False, want_pooled=True)
         prof = enc.last_profile()
         enc.set_profiling(False)
-        # the dominant kernel: the four GEMMs of every encoder layer (QKV, out_proj, fc1, fc2).  With the defaults they run in the streaming
-        # 256-tile kernel gemm256p_kernel; with AVEX_AMD_LN_FOLD=1 or an fp32 residual stream in the tile-per-workgroup gemm256_kernel.
+        # the dominant kernel: the four GEMMs of every encoder layer (QKV, out_proj, fc1, fc2), all in the streaming 256-tile kernel
+        # gemm256p_kernel (with the default fold its instantiations <T, 1, 1> / <T, 2, 3> carry the encoder's LayerNorms too)
         layer_gemms = ("gemm.qkv", "gemm.out_proj", "gemm.fc1", "gemm.fc2")
         gemm_ms = sum(ms for n, ms, fl in prof if n in layer_gemms)
         gemm_fl = sum(fl for n, ms, fl in prof if n in layer_gemms)
         n_streams = max(1, min(4, int(os.environ.get("AVEX_AMD_STREAMS", "1") or 1)))       # (a knob, default 1: api.cpp plan_chunks)
         eff_chunk = args.chunk if n_streams == 1 or B < 2 else min(args.chunk, (B + n_streams - 1) // n_streams)
         n_gemm_launch = 4 * int(cfg["encoder_layers"]) * ((B + eff_chunk - 1) // eff_chunk)
-        kernel_name = "gemm256_kernel" if (os.environ.get("AVEX_AMD_LN_FOLD", "0") not in ("", "0") or args.residual != "half") else "gemm256p_kernel"
+        kernel_name = "gemm256p_kernel"
+        ln_fold = args.residual == "half" and os.environ.get("AVEX_AMD_LN_FOLD", "1") not in ("0",)
         total_ms = sum(ms for _, ms, _ in prof)
         stages = {n: {"ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1) if ms > 0 and fl > 0 else None} for n, ms, fl in prof}
         # the other kernels of the step against their own bounds (same serialised HIP-event times; algorithmic bytes / flops of DESIGN.md section 4)
@@ -329,10 +330,13 @@ def main():
             others["posconv_kernel"] = {"bound": "mfma", "achieved": round(sf["posconv"] / sm["posconv"] / 1e9, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(sf["posconv"] / sm["posconv"] / 1e9 / PEAK_TFLOPS, 4), "ms_per_step": round(sm["posconv"], 3)}
         if sm.get("layernorm") and args.residual == "half":
-            ln_bytes = (2 * L) * B * T_ * E_ * 2 * 2 + B * T_ * (512 * 4 + 512 * 2) + B * T_ * E_ * (4 + 2 + 4)       # 24 half -> half, patch LN (f32 -> f16), encoder LN
+            # patch LayerNorm (half -> half, 512 wide) and encoder LayerNorm (half -> half, 768 wide); without the fold also 2 per layer
+            ln_bytes = B * T_ * 512 * 2 * 2 + B * T_ * E_ * 2 * 2 + (0 if ln_fold else (2 * L - 1) * B * T_ * E_ * 2 * 2)
             others["layernorm_half_kernel"] = {"bound": "hbm", "achieved": round(ln_bytes / sm["layernorm"] / 1e9, 2), "peak": 8.0, "unit": "TB/s",
                                                "frac": round(ln_bytes / sm["layernorm"] / 1e9 / 8.0, 4), "ms_per_step": round(sm["layernorm"], 3),
-                                               "note": "read + write mix; torch's device-to-device copy reaches 5.3 TB/s on this board (scripts/hbm_bw.py)"}
+                                               "launches_per_step": 2 if ln_fold else 2 * L + 1,
+                                               "note": "read + write mix; torch's device-to-device copy reaches 5.3 TB/s on this board (scripts/hbm_bw.py)"
+                                                       + ("; the encoder's 24 LayerNorms are folded into the GEMM epilogues" if ln_fold else "")}
         if sm.get("fbank"):
             fb_bytes = B * (SAMPLES * 4 + 992 * 128 * 2)
             others["fbank_kernel"] = {"bound": "hbm", "achieved": round(fb_bytes / sm["fbank"] / 1e9, 2), "peak": 8.0, "unit": "TB/s",
@@ -377,6 +381,7 @@ def main():
                        "backend": (dist.get_backend() if world > 1 else None), "gathered_rows_in_clip_order": gather_check,
                        "inputs": "avex_amd.synth.noise_clips(seed=0), keyed by global clip index",
                        "chunk_clips": args.chunk, "streams": max(1, min(4, int(os.environ.get("AVEX_AMD_STREAMS", "1") or 1))), "residual_stream": args.residual,
+                       "layernorm_fold": bool(args.residual == "half" and os.environ.get("AVEX_AMD_LN_FOLD", "1") != "0"),
                        "dtype_note": DTYPE_NOTE,
                        "model_tflops_per_s": round(value * FLOP_PER_CLIP / 1e12, 1),
                        "model_frac_of_mfma_peak": round(value * FLOP_PER_CLIP / 1e12 / (PEAK_TFLOPS * world), 4)},

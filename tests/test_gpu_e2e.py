@@ -22,16 +22,18 @@ def base_sd():
     return synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0)
 
 
-@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres", "f16-halfres-fold", "bf16-halfres-fold"])
+@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres", "f16-halfres-nofold", "bf16-halfres-nofold"])
 def encoder(request, built_lib, base_sd):
-    """f32 residual stream (generic GEMM epilogues), half residual stream (default: streaming GEMM + LayerNorm kernels) and half
-    residual stream with the LayerNorms folded into the GEMM epilogues (AVEX_AMD_LN_FOLD=1, read when the handle is created)."""
+    """f32 residual stream (generic GEMM epilogues), half residual stream (default: the LayerNorms folded into the streaming GEMM's
+    epilogues) and half residual stream with LayerNorm kernels (AVEX_AMD_LN_FOLD=0, read when the handle is created)."""
     import os
     from avex_amd import kernels as K
     dt = request.param.split("-")[0]
     old = os.environ.get("AVEX_AMD_LN_FOLD")
-    if request.param.endswith("fold"):
-        os.environ["AVEX_AMD_LN_FOLD"] = "1"
+    if request.param.endswith("nofold"):
+        os.environ["AVEX_AMD_LN_FOLD"] = "0"
+    else:
+        os.environ.pop("AVEX_AMD_LN_FOLD", None)
     try:
         enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype=dt, max_chunk_clips=3,
                              residual="half" if "halfres" in request.param else "f32")

@@ -164,8 +164,9 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
     ln = O.layer_norm(y.astype(np.float32), gamma.astype(np.float32), beta.astype(np.float32)).astype(np.float64)   # LN of the ROUNDED rows
     rows = K.ln_rowstats(r["stats"])             # (rstd, -mean rstd) per row, from the producer's partial sums
     yd = y.astype(np.float64)
-    assert np.allclose(rows[:M, 0].cpu().numpy(), 1.0 / np.sqrt(yd.var(1) + 1e-5), rtol=2e-4)
-    assert np.allclose(rows[:M, 1].cpu().numpy(), -yd.mean(1) / np.sqrt(yd.var(1) + 1e-5), rtol=2e-3, atol=2e-4)
+    # (the sums are of the fp32 values; yd is what was stored, one rounding to the operand type later)
+    assert np.allclose(rows[:M, 0].cpu().numpy(), 1.0 / np.sqrt(yd.var(1) + 1e-5), rtol=2e-4 if dtype == "f16" else 2e-3)
+    assert np.allclose(rows[:M, 1].cpu().numpy(), -yd.mean(1) / np.sqrt(yd.var(1) + 1e-5), rtol=2e-3, atol=2e-4 if dtype == "f16" else 2e-3)
     # consumer A: gelu(LN(y) @ w1.T + b1) through folded weights
     w1 = synth.normal("lnW1", (F, E), 0.05); b1 = synth.normal("lnb1", (F,), 0.1)
     w1f = rnd((w1 * gamma[None, :]).astype(np.float32))
