@@ -347,14 +347,22 @@ def main():
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_traffic.json")))      # the latest round's PMC summary
         traffic_src = None
+        traffic_by_shape = None
         if tfiles and B == 256 and args.dtype == "f16":
             try:
-                traffic = round(json.load(open(tfiles[-1]))[kernel_name]["hbm_bytes_per_launch"])
+                tj = json.load(open(tfiles[-1]))
+                loop = tj.get("gemm256p_kernel_layer_loop")       # the 48 layer GEMMs only (scripts/parse_traffic.py labels launches by position)
+                traffic = round((loop or tj[kernel_name])["hbm_bytes_per_launch"])
                 traffic_src = "profiles/" + os.path.basename(tfiles[-1])
+                alg = {"qkv": B * T_ * (E_ + 3 * E_) * 2 + 3 * E_ * E_ * 2, "out_proj": B * T_ * (E_ + 2 * E_) * 2 + E_ * E_ * 2,
+                       "fc1": B * T_ * (E_ + 4 * E_) * 2 + 4 * E_ * E_ * 2, "fc2": B * T_ * (4 * E_ + 2 * E_) * 2 + 4 * E_ * E_ * 2}
+                if tj.get("gemm256p_kernel_by_shape"):
+                    traffic_by_shape = {k: {"counted": round(v["hbm_bytes_per_launch"]), "algorithmic": alg.get(k)}
+                                        for k, v in tj["gemm256p_kernel_by_shape"].items() if k in alg}
             except Exception:  # noqa: BLE001
                 traffic = None
         roof = {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_by_shape": traffic_by_shape,
                 "algorithmic_tflop_per_launch": round(gemm_fl / n_gemm_launch / 1e12, 4),
                 "launches_per_step": n_gemm_launch, "avg_launch_ms": round(gemm_ms / n_gemm_launch, 4),
                 "gemm_share_of_step": round(gemm_ms / total_ms, 3),

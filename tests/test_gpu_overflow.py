@@ -117,7 +117,7 @@ def test_heavy_tailed_checkpoint(built_lib, clips, kind):
     f, p, n_bfh, _ = _run(sd, clips, operand_dtype="bf16", residual="half")
     assert n_bfh == 0 and np.isfinite(f).all()
     print(f"[{kind}] bf16 / bf16 residual: pooled rel-L2 {rel_l2(p, p_ref):.2e}")
-    assert rel_l2(p, p_ref) < 2e-2
+    assert rel_l2(p, p_ref) < 6e-3              # measured 2.3e-3 / 2.6e-3 (the bf16 bar of tests/test_gpu_e2e.py)
     # f16 operands with an fp32 residual stream: the pre-LayerNorm sums never pass through f16, so the "residual" outliers are harmless;
     # the "hidden" ones clip in fc1's own f16 output and the alarm must say so
     f, p, n_32, _ = _run(sd, clips, operand_dtype="f16", residual="f32", on_overflow="ignore")
@@ -125,7 +125,7 @@ def test_heavy_tailed_checkpoint(built_lib, clips, kind):
     if kind == "residual":
         e_32 = rel_l2(p, p_ref)
         print(f"[{kind}] f16 / f32 residual: pooled rel-L2 {e_32:.2e}, frame-level {rel_l2(f, f_ref):.2e}")
-        assert n_32 == 0 and e_32 < 3e-3
+        assert n_32 == 0 and e_32 < 1e-3           # measured 3.7e-4 (north_star's own bar for the default mode)
     else:
         assert n_32 > 0
 
