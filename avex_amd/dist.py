@@ -9,7 +9,7 @@ every rank.
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional, Tuple
+from typing import Any, Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -59,6 +59,76 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     buf = torch.empty((world * width, D), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, padded, group=group)
     return torch.cat([buf[r * width: r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+class PipelinedGather:
+    """The all-gather of batch n overlapped with the forward of batch n + 1.
+
+    ``push(local, n_total)`` starts a NON-BLOCKING ``all_gather_into_tensor`` of this rank's ``[n_local, ...]`` rows into one of
+    two alternating buffers and hands back the finished matrix of the PREVIOUS push (``None`` the first time); ``flush()`` returns
+    the last one.  On RCCL the collective runs on the communicator's own stream: it starts when the rows are ready and the
+    compute stream only waits for it (``work.wait()``, a stream dependency, not a host block) one step later, so the 786 KB
+    exchange and its launch latency hide under the next batch's kernels.  Rows keep rank order = clip order; ragged splits
+    (``shard_bounds``) are padded to the widest shard and trimmed on the way out.  With one process nothing is exchanged and
+    ``push`` returns the previous input.  The result tensors alias the two buffers: consume (or copy) one before the push after
+    next overwrites it.
+    """
+
+    def __init__(self, group=None) -> None:
+        self.group = group
+        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self._bufs: List[Optional[torch.Tensor]] = [None, None]
+        self._slot = 0
+        self._pending: Optional[Tuple[Any, torch.Tensor, torch.Tensor, int, tuple]] = None      # (work, buffer, kept input, n_total, tail shape)
+
+    def _buffer(self, slot: int, rows: int, width: int, like: torch.Tensor) -> torch.Tensor:
+        b = self._bufs[slot]
+        if b is None or b.shape != (rows, width) or b.dtype != like.dtype or b.device != like.device:
+            b = torch.empty((rows, width), dtype=like.dtype, device=like.device)
+            self._bufs[slot] = b
+        return b
+
+    def _finish(self) -> Optional[torch.Tensor]:
+        if self._pending is None:
+            return None
+        work, buf, _kept, n_total, tail = self._pending
+        self._pending = None
+        if work is None:                       # single process: the "buffer" is the input itself
+            return buf
+        work.wait()
+        sizes = [shard_bounds(n_total, r, self.world) for r in range(self.world)]
+        width = max(hi - lo for lo, hi in sizes)
+        if all(hi - lo == width for lo, hi in sizes):
+            out = buf
+        else:
+            out = torch.cat([buf[r * width: r * width + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+        return out.reshape((n_total,) + tail)
+
+    def push(self, local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
+        done = self._finish()
+        if not self.active:
+            self._pending = (None, local, local, n_total, tuple(local.shape[1:]))
+            return done
+        tail = tuple(local.shape[1:])
+        ncol = 1
+        for d in tail:
+            ncol *= int(d)
+        flat = local.reshape(local.shape[0], ncol).contiguous()          # (an empty shard has no -1 to infer)
+        sizes = [shard_bounds(n_total, r, self.world) for r in range(self.world)]
+        width = max(hi - lo for lo, hi in sizes)
+        if flat.shape[0] != width:             # ragged: pad to the widest shard
+            padded = torch.zeros((width, flat.shape[1]), dtype=flat.dtype, device=flat.device)
+            padded[: flat.shape[0]] = flat
+            flat = padded
+        buf = self._buffer(self._slot, self.world * width, flat.shape[1], flat)
+        self._slot ^= 1
+        work = dist.all_gather_into_tensor(buf, flat, group=self.group, async_op=True)
+        self._pending = (work, buf, flat, n_total, tail)       # `flat` is kept alive until the collective has read it
+        return done
+
+    def flush(self) -> Optional[torch.Tensor]:
+        return self._finish()
 
 
 def extract_embeddings_sharded(embed_fn: Callable[[torch.Tensor], torch.Tensor], wav: torch.Tensor,

@@ -22,9 +22,13 @@ logger = logging.getLogger(__name__)
 __all__ = ["extract_embeddings_in_memory", "extract_embeddings_streaming", "write_embedding_metadata"]
 
 
-def _stage(batch: Dict[str, Any], device: torch.device, stream: Optional["torch.cuda.Stream"]):
-    """Host -> device copy of one Collater batch (on ``stream`` when given: pinned source, non-blocking)."""
+def _stage(batch: Dict[str, Any], device: torch.device, stream: Optional["torch.cuda.Stream"], rows: Optional[Tuple[int, int]] = None):
+    """Host -> device copy of one Collater batch (on ``stream`` when given: pinned source, non-blocking); ``rows`` = this rank's
+    slice of the batch in a sharded run (only those clips cross PCIe)."""
     wav, mask = batch["raw_wav"], batch.get("padding_mask")
+    if rows is not None:
+        wav = wav[rows[0]:rows[1]]
+        mask = mask[rows[0]:rows[1]] if mask is not None else None
     if stream is None:
         return wav.to(device), (mask.to(device) if mask is not None else None), None
     with torch.cuda.stream(stream):
@@ -39,10 +43,21 @@ def _stage(batch: Dict[str, Any], device: torch.device, stream: Optional["torch.
 
 def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]], target_layers: List[Any],
                                  device: Any, aggregation: str = "mean", disable_tqdm: bool = True,
-                                 disable_layerdrop: Optional[bool] = None, prefetch: Optional[bool] = None
+                                 disable_layerdrop: Optional[bool] = None, prefetch: Optional[bool] = None,
+                                 sharded: Optional[bool] = None, group: Any = None
                                  ) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, List[tuple]]:
     """Run ``model.extract_embeddings`` over every batch of ``dataloader`` and stack the results on the CPU
-    (reference: embedding_utils.py:26-144; ``disable_tqdm`` is accepted for signature compatibility, no progress bar here)."""
+    (reference: embedding_utils.py:26-144; ``disable_tqdm`` is accepted for signature compatibility, no progress bar here).
+
+    ``sharded`` (default: on when ``torch.distributed`` is initialised with more than one rank): every rank iterates the SAME
+    batches, embeds clips ``dist.shard_bounds(B, rank, world)`` of each and the embeddings are all-gathered in clip order
+    (``dist.PipelinedGather``: batch n's exchange under batch n + 1's forward), so every rank returns what a single device would
+    (the reference's loop is single-device, run_evaluate.py:1053)."""
+    from . import dist as adist
+    import torch.distributed as tdist
+    world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
+    rank = tdist.get_rank(group) if world > 1 else 0
+    sharded = world > 1 if sharded is None else (bool(sharded) and world > 1)
     device = torch.device(device)
     if prefetch is None:
         prefetch = device.type == "cuda"
@@ -70,7 +85,25 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
             resolved_layers = model.register_hooks_for_layers(target_layers)         # outside the loop, like the reference
             it = iter(dataloader)
             nxt = next(it, None)
-            staged = _stage(nxt, device, copy_stream) if nxt is not None else None
+            gathers: Dict[int, Any] = {}                        # position in the output list -> PipelinedGather
+
+            def my_rows(b: Dict[str, Any]) -> Optional[Tuple[int, int]]:
+                return adist.shard_bounds(int(b["raw_wav"].shape[0]), rank, world) if sharded else None
+
+            def exchange(parts: List[Tuple[str, torch.Tensor]], n_total: int) -> List[Tuple[str, torch.Tensor]]:
+                """Sharded run: start this batch's all-gathers, hand back the PREVIOUS batch's finished ones (clip order)."""
+                done = []
+                for i, (name, t) in enumerate(parts):
+                    if i not in gathers:
+                        gathers[i] = [adist.PipelinedGather(group), None]
+                    pg = gathers[i]
+                    prev = pg[0].push(t, n_total)
+                    if prev is not None:       # (a host tensor aliases the gather's buffer, which the push after next overwrites)
+                        done.append((pg[1], prev if prev.is_cuda else prev.clone()))
+                    pg[1] = name
+                return done
+
+            staged = _stage(nxt, device, copy_stream, my_rows(nxt)) if nxt is not None else None
             while nxt is not None:
                 batch, (wav, mask, ready) = nxt, staged
                 nxt = next(it, None)
@@ -84,20 +117,31 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
                     if mask is not None:
                         mask.record_stream(cur)
                 if nxt is not None:
-                    staged = _stage(nxt, device, copy_stream)                        # overlaps the forward below
-                if mask is None:
-                    emb = model.extract_embeddings(wav, aggregation=aggregation)
+                    staged = _stage(nxt, device, copy_stream, my_rows(nxt))          # overlaps the forward below
+                empty_shard = sharded and wav.shape[0] == 0                          # fewer clips than ranks: embed one clip for the shapes, keep no row
+                if empty_shard:
+                    wav_in = batch["raw_wav"][:1].to(device)
+                    mask_in = batch["padding_mask"][:1].to(device) if batch.get("padding_mask") is not None else None
                 else:
-                    emb = model.extract_embeddings({"raw_wav": wav, "padding_mask": mask}, aggregation=aggregation)
-                outs: List[Tuple[str, torch.Tensor]] = []
+                    wav_in, mask_in = wav, mask
+                if mask_in is None:
+                    emb = model.extract_embeddings(wav_in, aggregation=aggregation)
+                else:
+                    emb = model.extract_embeddings({"raw_wav": wav_in, "padding_mask": mask_in}, aggregation=aggregation)
+                parts: List[Tuple[str, torch.Tensor]] = []
                 if isinstance(emb, list):                                            # embedding_utils.py:98-104
-                    for i, layer_emb in enumerate(emb):
-                        to_host(resolved_layers[i] if i < len(resolved_layers) else f"layer_{i}", layer_emb, outs)
+                    parts = [(resolved_layers[i] if i < len(resolved_layers) else f"layer_{i}", e) for i, e in enumerate(emb)]
                 elif isinstance(emb, dict):
-                    for layer_name, layer_emb in emb.items():
-                        to_host(layer_name, layer_emb, outs)
+                    parts = list(emb.items())
                 else:
-                    to_host(resolved_layers[0] if resolved_layers else "embeddings", emb, outs)
+                    parts = [(resolved_layers[0] if resolved_layers else "embeddings", emb)]
+                if empty_shard:
+                    parts = [(n, t[:0]) for n, t in parts]
+                if sharded:
+                    parts = exchange(parts, int(batch["raw_wav"].shape[0]))          # the previous batch's rows, gathered
+                outs: List[Tuple[str, torch.Tensor]] = []
+                for name, t in parts:
+                    to_host(name, t, outs)
                 if copy_stream is not None:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(device))
@@ -106,6 +150,20 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
                     for name, t in outs:
                         layer_embeds.setdefault(name, []).append(t)
                 labels.append(batch["label"].cpu())
+            if sharded:                                                              # the last batch's exchange
+                outs = []
+                for i in sorted(gathers):
+                    pg, name = gathers[i]
+                    last = pg.flush()
+                    if last is not None:
+                        to_host(name, last if last.is_cuda else last.clone(), outs)
+                if copy_stream is not None and outs:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(device))
+                    pending.append((ev, outs))
+                else:
+                    for name, t in outs:
+                        layer_embeds.setdefault(name, []).append(t)
             for ev, outs in pending:
                 ev.synchronize()
                 for name, t in outs:
@@ -212,7 +270,25 @@ def extract_embeddings_streaming(model: Any, dataloader: Any, target_layers: Lis
 
             it = iter(dataloader)
             nxt = next(it, None)
-            staged = _stage(nxt, device, copy_stream) if nxt is not None else None
+            gathers: Dict[int, Any] = {}                        # position in the output list -> PipelinedGather
+
+            def my_rows(b: Dict[str, Any]) -> Optional[Tuple[int, int]]:
+                return adist.shard_bounds(int(b["raw_wav"].shape[0]), rank, world) if sharded else None
+
+            def exchange(parts: List[Tuple[str, torch.Tensor]], n_total: int) -> List[Tuple[str, torch.Tensor]]:
+                """Sharded run: start this batch's all-gathers, hand back the PREVIOUS batch's finished ones (clip order)."""
+                done = []
+                for i, (name, t) in enumerate(parts):
+                    if i not in gathers:
+                        gathers[i] = [adist.PipelinedGather(group), None]
+                    pg = gathers[i]
+                    prev = pg[0].push(t, n_total)
+                    if prev is not None:       # (a host tensor aliases the gather's buffer, which the push after next overwrites)
+                        done.append((pg[1], prev if prev.is_cuda else prev.clone()))
+                    pg[1] = name
+                return done
+
+            staged = _stage(nxt, device, copy_stream, my_rows(nxt)) if nxt is not None else None
             while nxt is not None:
                 batch, (wav, mask, ready) = nxt, staged
                 nxt = next(it, None)

@@ -253,22 +253,30 @@ def main():
     # 0.1 * N(0,1) clips from the build's own counter-based PRNG, so any sharding of the job embeds the same clips
     wav = torch.from_numpy(synth.noise_clips(B, SAMPLES, seed=0, first_clip=rank * B)).to(dev)
     gathered = torch.empty((world * B, 768), dtype=torch.float32, device=dev) if world > 1 else None
+    # N > 1: the step's all-gather is NON-BLOCKING (avex_amd.dist.PipelinedGather): the gather of step n runs on the communicator's
+    # stream under the kernels of step n + 1 and is waited for one step later; the last one is flushed inside the timed region, so
+    # K steps are K forwards + K completed gathers ("overlap gather(n) with compute(n+1)")
+    from avex_amd.dist import PipelinedGather
+    pipe = PipelinedGather() if world > 1 else None
 
     def step():
         r = enc.forward(wav, want_features=False, want_pooled=True)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, r["pooled"])
-            return gathered
+        if pipe is not None:
+            return pipe.push(r["pooled"], world * B)        # the PREVIOUS step's gathered matrix (None at the first step)
         return r["pooled"]
 
+    out = None
     for _ in range(args.warmup):
         out = step()
-    if world > 1:
+    if pipe is not None:
+        out = pipe.flush()
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if pipe is not None:
+        out = pipe.flush()
     sync()
     if world > 1:
         dist.barrier()
@@ -282,14 +290,31 @@ def main():
 
     # ---- after the timed region: the gathered matrix is in clip order on every rank ----
     gather_check = None
+    all_gather_ms = None
     if world > 1:
         local = enc.forward(wav, want_features=False, want_pooled=True)["pooled"]
         dist.all_gather_into_tensor(gathered, local)
+        piped_ok = torch.equal(out, gathered)                                      # what the timed loop's last (pipelined) gather delivered
+        # the exchange alone, blocking form, event-timed on the compute stream (rank 0's view; 10 repetitions)
+        sync()
+        if dry:
+            tg = time.perf_counter()
+            for _ in range(10):
+                dist.all_gather_into_tensor(gathered, local)
+            all_gather_ms = (time.perf_counter() - tg) * 1e3 / 10
+        else:
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(10):
+                dist.all_gather_into_tensor(gathered, local)
+            g1.record()
+            sync()
+            all_gather_ms = g0.elapsed_time(g1) / 10
         ok_own = torch.equal(gathered[rank * B:(rank + 1) * B], local)            # my rows sit at my clip indices, bit for bit
         sums = torch.empty((world * B,), dtype=torch.float64, device=dev)          # a checksum of checksums: every rank's
         dist.all_gather_into_tensor(sums, local.double().sum(1).contiguous())      # per-clip sums, gathered separately,
         ok_all = torch.equal(sums, gathered.double().sum(1))                       # must match the gathered rows
-        flag = torch.tensor([1 if (ok_own and ok_all) else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if (ok_own and ok_all and piped_ok) else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_check = bool(flag.item())
         if dry:     # the stub is a closed form of the clip, so the whole matrix can be checked against the generator
@@ -387,6 +412,8 @@ def main():
                        "global_batch": world * B, "samples_per_clip": SAMPLES, "tokens_per_clip": 496,
                        "parallelism": f"dp{world}", "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else None), "gathered_rows_in_clip_order": gather_check,
+                       "all_gather": (None if world == 1 else {"form": "non-blocking, overlapped with the next step's kernels, last one flushed inside the timed region",
+                                                               "blocking_ms": round(all_gather_ms, 4), "bytes_per_rank": B * 768 * 4}),
                        "inputs": "avex_amd.synth.noise_clips(seed=0), keyed by global clip index",
                        "chunk_clips": args.chunk, "streams": max(1, min(4, int(os.environ.get("AVEX_AMD_STREAMS", "1") or 1))), "residual_stream": args.residual,
                        "layernorm_fold": bool(args.residual == "half" and os.environ.get("AVEX_AMD_LN_FOLD", "1") != "0"),

@@ -101,3 +101,110 @@ def test_bench_refuses_mismatched_world(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu-dry-run"], capture_output=True, text=True,
                        timeout=300, cwd=str(tmp_path), env=env)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+# ------------------------------------------------------------------ pipelined (non-blocking) gather and the sharded harness loop
+class _StubModel:
+    """Enough of the model contract for the extraction loop: hooks bookkeeping + a per-clip extract_embeddings."""
+    disable_layerdrop = False
+
+    def __init__(self, list_output: bool) -> None:
+        self.list_output = list_output
+        self.calls = []
+
+    def register_hooks_for_layers(self, layers):
+        return ["layer.a", "layer.b"] if self.list_output else ["layer.a"]
+
+    def deregister_all_hooks(self):
+        pass
+
+    def extract_embeddings(self, x, aggregation="mean"):
+        wav = x["raw_wav"] if isinstance(x, dict) else x
+        self.calls.append(int(wav.shape[0]))
+        e = _embed(wav)
+        if self.list_output:
+            return [e.unsqueeze(1).repeat(1, 3, 1), (2.0 * e).unsqueeze(1).repeat(1, 3, 1)]       # (B, T', D) per layer, aggregation "none"
+        return e
+
+
+def _batches(n_batches, sizes):
+    g = torch.Generator().manual_seed(1)
+    out = []
+    for i in range(n_batches):
+        b = sizes[i % len(sizes)]
+        out.append({"raw_wav": torch.randn(b, 2000, generator=g), "padding_mask": torch.zeros(b, 2000, dtype=torch.bool),
+                    "label": torch.arange(b) + 100 * i})
+    return out
+
+
+def _pipe_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_distributed(backend="gloo")
+    from avex_amd.extraction import extract_embeddings_in_memory
+    # (a) PipelinedGather against the blocking gather, equal and ragged splits, results one step late
+    g = torch.Generator().manual_seed(5)
+    pg = adist.PipelinedGather()
+    got, want = [], []
+    for n_total in (8, 7, 8, 3, 1, 6):
+        full = torch.randn(n_total, 5, generator=g)
+        lo, hi = adist.shard_bounds(n_total, rank, world)
+        want.append(full)
+        prev = pg.push(full[lo:hi].clone(), n_total)
+        if prev is not None:
+            got.append(prev.clone())
+    got.append(pg.flush().clone())
+    assert pg.flush() is None
+    ok_a = len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    # (b) the harness loop, sharded: every rank iterates the same batches and returns the single-device result
+    res = {}
+    for list_output in (False, True):
+        model = _StubModel(list_output)
+        emb, labels, dims = extract_embeddings_in_memory(model, _batches(5, (6, 5, 1)), ["last_layer"], "cpu",
+                                                         aggregation="none" if list_output else "mean")
+        res[list_output] = ({k: v.numpy() for k, v in emb.items()}, labels.numpy(), dims, model.calls)
+    np.save(os.path.join(out_dir, f"pipe_ok_r{rank}.npy"), np.array([int(ok_a)]))
+    import pickle
+    with open(os.path.join(out_dir, f"loop_r{rank}.pkl"), "wb") as f:
+        pickle.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_and_sharded_extraction_loop(tmp_path):
+    import pickle
+    from avex_amd.extraction import extract_embeddings_in_memory
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref = {}
+    for list_output in (False, True):          # the single-process loop is the reference
+        emb, labels, dims = extract_embeddings_in_memory(_StubModel(list_output), _batches(5, (6, 5, 1)), ["last_layer"], "cpu",
+                                                         aggregation="none" if list_output else "mean")
+        ref[list_output] = ({k: v.numpy() for k, v in emb.items()}, labels.numpy(), dims)
+    for r in range(2):
+        assert np.load(tmp_path / f"pipe_ok_r{r}.npy")[0] == 1
+        with open(tmp_path / f"loop_r{r}.pkl", "rb") as f:
+            res = pickle.load(f)
+        for list_output in (False, True):
+            emb, labels, dims, calls = res[list_output]
+            remb, rlabels, rdims = ref[list_output]
+            assert sorted(emb) == sorted(remb) and dims == rdims and np.array_equal(labels, rlabels)
+            for k in remb:
+                assert np.array_equal(emb[k], remb[k]), (r, list_output, k)              # every rank: every row, in clip order
+            # each rank embedded only its share of every batch (a one-clip batch still costs the idle rank one probe clip)
+            assert calls == ([3, 3, 1, 3, 3] if r == 0 else [3, 2, 1, 3, 2]), calls
+
+
+def test_bench_control_flow_at_eight_ranks(tmp_path):
+    """BASELINE config C4's process layout (8 ranks) on the CPU with gloo and the stub encoder: rendezvous, pipelined gather, the
+    clip-order check over all 8 shards, one JSON line."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "2", "--cpu-dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8" and d["config"]["world_size"] == 8
+    assert d["config"]["gathered_rows_in_clip_order"] is True
+    assert d["config"]["all_gather"]["blocking_ms"] > 0 and d["config"]["all_gather"]["bytes_per_rank"] == 2 * 768 * 4
