@@ -229,7 +229,8 @@ struct avexhip_beats {
     float* lnE_w = nullptr; float* lnE_b = nullptr;
     std::vector<Layer> layers;
     std::vector<float> rel_table;  // host [num_buckets, H]; empty if no relative position embedding
-    std::map<int, float*> bias_tabs;
+    std::map<int, float*> bias_tabs;       // per token count T: [H, 2T-1] Toeplitz rows; at most BIAS_TAB_CACHE entries, least recently used evicted
+    std::vector<int> bias_tab_lru;         // token counts, most recent last
     std::vector<void*> allocs;
     // range alarm of the f16 conversions (GemmArgs::ovf): device counter every GEMM of a forward adds to, mirrored to pinned host
     // memory by an asynchronous copy at the end of each forward (read without a synchronisation by avexhip_beats_overflow_count)
@@ -522,8 +523,23 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
 int bias_tab_for(avexhip_beats* h, int T, float** out) {
     *out = nullptr;
     if (h->rel_table.empty()) return AVEXHIP_OK;
+    auto touch = [&](int t) {
+        auto& v = h->bias_tab_lru;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == t) { v.erase(v.begin() + (long)i); break; }
+        v.push_back(t);
+    };
     auto it = h->bias_tabs.find(T);
-    if (it != h->bias_tabs.end()) { *out = it->second; return AVEXHIP_OK; }
+    if (it != h->bias_tabs.end()) { touch(T); *out = it->second; return AVEXHIP_OK; }
+    // variable-length inference meets a new T per clip length: the cache is bounded (3 MB per entry near T = 32768).  hipFree waits for
+    // the device, so a table still read by a kernel in flight is never pulled from under it.
+    constexpr size_t BIAS_TAB_CACHE = 16;
+    while (h->bias_tabs.size() >= BIAS_TAB_CACHE && !h->bias_tab_lru.empty()) {
+        const int victim = h->bias_tab_lru.front();
+        h->bias_tab_lru.erase(h->bias_tab_lru.begin());
+        auto vit = h->bias_tabs.find(victim);
+        if (vit != h->bias_tabs.end()) { (void)hipFree(vit->second); h->bias_tabs.erase(vit); }
+    }
     const int H = h->H, W = 2 * T - 1;
     std::vector<float> host((size_t)H * W);
     for (int r = 0; r < W; ++r) {
@@ -534,6 +550,7 @@ int bias_tab_for(avexhip_beats* h, int T, float** out) {
     AVX_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * host.size()));
     AVX_HIP_CHECK(hipMemcpy(d, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
     h->bias_tabs[T] = d;
+    touch(T);
     *out = d;
     return AVEXHIP_OK;
 }

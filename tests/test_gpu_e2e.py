@@ -259,3 +259,19 @@ def test_config_c5_full_size_efficientnet(built_lib):
         # not bit-identical: the squeeze-excitation pool is accumulated with fp32 atomics (order varies with the grid), and a flipped
         # f16 rounding of an activation carries the difference to ~4e-5
         assert rel_l2(one.cpu().numpy(), full[r:r + 1].cpu().numpy()) < 2e-4
+
+
+def test_bias_table_cache_is_bounded_and_eviction_is_invisible(built_lib, base_sd):
+    """Variable-length inference: each token count needs its own Toeplitz bias table (api.cpp bias_tab_for); the cache holds 16 of them,
+    least recently used out.  40 different lengths, then the first one again: same bits as its first run."""
+    from avex_amd import kernels as K
+    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd)
+    x0 = torch.from_numpy(synth.noise_clips(1, 16000, seed=21)).cuda()
+    first = enc.forward(x0, want_features=False, want_pooled=True)["pooled"].clone()
+    for i in range(40):
+        T = 16000 + 2560 * (i + 1)                                   # 16 more frames = 8 more tokens each
+        r = enc.forward(torch.from_numpy(synth.noise_clips(1, T, seed=22 + i)).cuda(), want_features=False, want_pooled=True)
+        assert bool(torch.isfinite(r["pooled"]).all())
+    again = enc.forward(x0, want_features=False, want_pooled=True)["pooled"]
+    assert torch.equal(first, again)
+    enc.close()
