@@ -1,0 +1,114 @@
+// The attention kernel's key-tile loop with its LDS traffic, in the two shapes that were on the table (round 3):
+//   A  8 waves x TWO 32-query tiles per wave (attention2_kernel): per key tile a wave reads 4 K fragments (ds_read_b128), 8 V
+//      fragments (ds_read_b64_tr_b16) -- shared by its two query tiles -- and 2 x 4 bias vectors (ds_read_b128), issues 16 MFMAs
+//      (32x32x16) and the vector segment of 32 scores per lane;
+//   B  16 waves x ONE query tile per wave (the variant round 2 priced at -21 % of the tile loop with a register-only
+//      microbenchmark, scripts/micro/seg_cost.hip): per key tile a wave reads 4 + 8 + 4 fragments, issues 8 MFMAs and half the
+//      vector segment.  Same work per SIMD per iteration; B moves 192 KB through the LDS per key tile and workgroup, A 128 KB.
+// Cycles per iteration (one key tile of a 512-query block), free running, with and without the LDS reads.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/att_lds16.hip -o scripts/micro/bin/att_lds16
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int NQ, int NT, bool LDS>
+__global__ __launch_bounds__(NT) void tile_loop(int iters, unsigned long long* __restrict__ cyc, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];            // 64 KiB K/V half-buffer + 8 KiB of bias rows
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < (72 * 1024) / 4; i += NT) ((float*)smem)[i] = 0.001f * (float)(i & 1023);
+    __syncthreads();
+    f32x16 sq[NQ], o0[NQ], o1[NQ];
+    for (int u = 0; u < NQ; ++u) for (int r = 0; r < 16; ++r) { sq[u][r] = 0.f; o0[u][r] = 0.f; o1[u][r] = 0.f; }
+    h8 qf[NQ][4];
+    for (int u = 0; u < NQ; ++u) for (int s = 0; s < 4; ++s) for (int e = 0; e < 8; ++e) qf[u][s][e] = (_Float16)(0.01f * (lane + e + s + u));
+    f32x2 sum[NQ];
+    for (int u = 0; u < NQ; ++u) sum[u] = (f32x2){0.f, 0.f};
+    const char* kbase = smem + (lane & 31) * 128 + ((lane >> 5) << 4);
+    const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(smem + 32768 + lane * 8);
+    const float* tbase = (const float*)(smem + 65536) + 4 * (lane & 15);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const int kt = it & 7;
+        h8 kf[4], vf[2][2];
+        if (LDS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = *(const h8*)(kbase + kt * 4096 + s * 32);
+            i32x2 vt[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[i]) : "v"(vaddr + kt * 4096), "n"(512 * i));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0]), "+v"(vt[1]), "+v"(vt[2]), "+v"(vt[3]), "+v"(vt[4]), "+v"(vt[5]), "+v"(vt[6]), "+v"(vt[7]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const h4 lo = __builtin_bit_cast(h4, vt[2 * i]), hi = __builtin_bit_cast(h4, vt[2 * i + 1]);
+                vf[i >> 1][i & 1] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = qf[0][s];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vf[i >> 1][i & 1] = qf[0][i];
+        }
+        h8 pf[NQ][2];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            // accumulator start: gate * bias - m (4 x 16-byte bias reads, 8 packed FMAs)
+            const f32x2 g = {1.0001f, 1.0001f}, m = {-0.001f, -0.001f};
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 t4 = {0.1f, 0.2f, 0.3f, 0.4f};
+                if (LDS) t4 = *(const f32x4*)(tbase + u * 1024 + kt * 32 + 8 * g4);
+                const f32x2 a = __builtin_elementwise_fma(g, (f32x2){t4[0], t4[1]}, m), b = __builtin_elementwise_fma(g, (f32x2){t4[2], t4[3]}, m);
+                sq[u][4 * g4] = a[0]; sq[u][4 * g4 + 1] = a[1]; sq[u][4 * g4 + 2] = b[0]; sq[u][4 * g4 + 3] = b[1];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sq[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[u][s], sq[u], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 p = {__builtin_amdgcn_exp2f(sq[u][r]), __builtin_amdgcn_exp2f(sq[u][r + 1])};
+                sum[u] += p;
+                pf[u][r >> 3][r & 7] = (_Float16)p[0];
+                pf[u][r >> 3][(r & 7) + 1] = (_Float16)p[1];
+            }
+            o0[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][0], pf[u][0], o0[u], 0, 0, 0);
+            o1[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][1], pf[u][0], o1[u], 0, 0, 0);
+            o0[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][0], pf[u][1], o0[u], 0, 0, 0);
+            o1[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][1], pf[u][1], o1[u], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+    for (int u = 0; u < NQ; ++u) r += sum[u][0] + sum[u][1] + o0[u][3] + o1[u][7] + sq[u][1];
+    if (r == 1234.5f) sink[0] = r;
+    if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
+
+template <int NQ, int NT, bool LDS>
+static void run(const char* name) {
+    unsigned long long* cyc; float* sink;
+    CK(hipMalloc(&cyc, 256)); CK(hipMalloc(&sink, 64));
+    const int iters = 4000;
+    CK(hipFuncSetAttribute((const void*)tile_loop<NQ, NT, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL((tile_loop<NQ, NT, LDS>), dim3(256), dim3(NT), 72 * 1024, 0, iters, cyc, sink); CK(hipDeviceSynchronize()); }
+    unsigned long long h[16];
+    CK(hipMemcpy(h, cyc, 128, hipMemcpyDeviceToHost));
+    double mx = 0;
+    for (int w = 0; w < NT / 64; ++w) mx = h[w] > mx ? (double)h[w] : mx;
+    printf("%-64s: %6.0f cycles per key tile (slowest wave), wave0 %6.0f\n", name, mx / iters, (double)h[0] / iters);
+    CK(hipFree(cyc)); CK(hipFree(sink));
+}
+
+int main() {
+    run<2, 512, false>("A  8 waves x 2 query tiles, registers only");
+    run<2, 512, true>("A  8 waves x 2 query tiles, with the LDS reads (128 KB / key tile)");
+    run<1, 1024, false>("B 16 waves x 1 query tile,  registers only");
+    run<1, 1024, true>("B 16 waves x 1 query tile,  with the LDS reads (192 KB / key tile)");
+    return 0;
+}
