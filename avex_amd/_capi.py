@@ -55,6 +55,19 @@ class BeatsConfig(C.Structure):
                 ("residual_dtype", C.c_int32)]
 
 
+class EatConfig(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("num_heads", C.c_int32), ("depth", C.c_int32), ("ffn_dim", C.c_int32), ("patch_size", C.c_int32),
+                ("target_length", C.c_int32), ("n_mels", C.c_int32), ("norm_eps", C.c_float), ("norm_mean", C.c_float), ("norm_std", C.c_float),
+                ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32), ("residual_dtype", C.c_int32)]
+
+
+class AvesConfig(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("ffn_dim", C.c_int32),
+                ("pos_conv_kernel", C.c_int32), ("pos_conv_groups", C.c_int32), ("n_conv_layers", C.c_int32),
+                ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8),
+                ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32), ("residual_dtype", C.c_int32)]
+
+
 class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
@@ -118,6 +131,24 @@ SYMBOLS = {
     "avexhip_beats_set_profiling": (C.c_int, [_P, C.c_int]),
     "avexhip_beats_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
                                              C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]),
+    "avexhip_eat_create": (_P, [C.POINTER(EatConfig), C.POINTER(Tensor), C.c_int]),
+    "avexhip_eat_destroy": (None, [_P]),
+    "avexhip_eat_num_tokens": (C.c_int, [_P]),
+    "avexhip_eat_workspace_bytes": (C.c_size_t, [_P, C.c_int]),
+    "avexhip_eat_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_uint32, C.POINTER(_P), C.c_int, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "avexhip_eat_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
+    "avexhip_eat_set_profiling": (C.c_int, [_P, C.c_int]),
+    "avexhip_eat_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_double)),
+                                           C.POINTER(C.c_int)]),
+    "avexhip_aves_create": (_P, [C.POINTER(AvesConfig), C.POINTER(Tensor), C.c_int]),
+    "avexhip_aves_destroy": (None, [_P]),
+    "avexhip_aves_num_tokens": (C.c_int, [_P, C.c_int64]),
+    "avexhip_aves_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int64]),
+    "avexhip_aves_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_uint32, C.POINTER(_P), C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_aves_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
+    "avexhip_aves_set_profiling": (C.c_int, [_P, C.c_int]),
+    "avexhip_aves_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_double)),
+                                            C.POINTER(C.c_int)]),
 }
 
 # exported by the diagnostic build only (-DAVEX_DIAG; AVEX_AMD_DIAG=1 python -m avex_amd.build, then AVEX_AMD_LIB=.../libavexhip_diag.so)

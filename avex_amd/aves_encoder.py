@@ -18,6 +18,7 @@ behind a URL; the checker is ``oracle/aves_oracle.py`` on
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, Iterable, List, Mapping, Optional, Sequence
 
 import numpy as np
@@ -50,101 +51,131 @@ def conv_frame_plan(T: int, convs: Sequence[Sequence[int]]):
 
 
 class AvesEncoder:
-    """``[B, T]`` fp32 waveforms on the GPU -> last-layer features ``[B, T', 768]`` / hook taps / pooled embeddings."""
+    """``[B, T]`` fp32 waveforms on the GPU -> last-layer features ``[B, T', 768]`` / hook taps / pooled embeddings.
+    A thin wrapper over the ``avexhip_aves`` handle (csrc/encoders.cpp): the library owns the weights, this class the output tensors
+    and the workspace."""
 
-    def __init__(self, cfg: Mapping[str, object], state: Mapping[str, np.ndarray], operand_dtype: str = "f16", prefix: str = "model.") -> None:
+    def __init__(self, cfg: Mapping[str, object], state: Mapping[str, np.ndarray], operand_dtype: str = "f16", prefix: str = "model.",
+                 max_chunk_clips: int = 0, residual: str = "half") -> None:
         _capi.require_gpu()
         self.cfg = dict(cfg)
         self.dtype = operand_dtype
         self.convs = [tuple(int(v) for v in c) for c in cfg["extractor_conv_layer_config"]]
-        if self.convs[0] != (512, 10, 5) or any(c[0] != 512 for c in self.convs):
+        if self.convs[0] != (512, 10, 5) or any(c[0] != 512 for c in self.convs) or len(self.convs) > 8:
             raise K.AvexHipError("AVES feature extractor: only the wav2vec2-base layout (512 channels, first layer k=10 s=5) is built")
         if bool(cfg.get("encoder_layer_norm_first", False)):
             raise K.AvexHipError("AVES: encoder_layer_norm_first=True (pre-LN) is not built")
         self.E = int(cfg["encoder_embed_dim"]); self.H = int(cfg["encoder_num_heads"]); self.L = int(cfg["encoder_num_layers"])
         self.G = int(cfg["encoder_pos_conv_groups"]); self.KP = int(cfg["encoder_pos_conv_kernel"])
-        if self.E != 64 * self.H:
-            raise K.AvexHipError("AVES: head_dim must be 64")
-        dev = torch.device("cuda", torch.cuda.current_device())
-        f32 = lambda name: torch.from_numpy(np.ascontiguousarray(np.asarray(state[prefix + name], np.float32))).to(dev)
-        half = lambda t: K.to_half(t.contiguous(), operand_dtype)
-        fe = "feature_extractor.conv_layers."
-        self.w0 = f32(fe + "0.conv.weight").reshape(512, 10)
-        self.gn_w, self.gn_b = f32(fe + "0.layer_norm.weight"), f32(fe + "0.layer_norm.bias")
-        # conv weights [out, in, k] -> [out, k, in]: the K order of a strided activation row is (frame, channel)
-        self.wc = [half(f32(fe + f"{i}.conv.weight").permute(0, 2, 1).reshape(512, -1)) for i in range(1, len(self.convs))]
-        self.zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
-        e = "encoder."
-        self.fp_ln = (f32(e + "feature_projection.layer_norm.weight"), f32(e + "feature_projection.layer_norm.bias"))
-        self.fp_w, self.fp_b = half(f32(e + "feature_projection.projection.weight")), f32(e + "feature_projection.projection.bias")
-        t = e + "transformer."
-        g = state.get(prefix + t + "pos_conv_embed.conv.parametrizations.weight.original0", state.get(prefix + t + "pos_conv_embed.conv.weight_g"))
-        v = state.get(prefix + t + "pos_conv_embed.conv.parametrizations.weight.original1", state.get(prefix + t + "pos_conv_embed.conv.weight_v"))
-        if g is None or v is None:
-            raise K.AvexHipError("AVES: positional conv weight-norm parameters missing from the state dict")
-        tg = torch.from_numpy(np.ascontiguousarray(np.asarray(g, np.float32))).to(dev)
-        tv = torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32))).to(dev)
-        self.pc_w = K.posconv_pack(tg, tv, self.G, operand_dtype)
-        self.pc_b = f32(t + "pos_conv_embed.conv.bias")
-        self.enc_ln = (f32(t + "layer_norm.weight"), f32(t + "layer_norm.bias"))
-        self.layers = []
-        for i in range(self.L):
-            p = t + f"layers.{i}."
-            wq, wk, wv = (f32(p + f"attention.{n}.weight") for n in ("q_proj", "k_proj", "v_proj"))
-            bq, bk, bv = (f32(p + f"attention.{n}.bias") for n in ("q_proj", "k_proj", "v_proj"))
-            self.layers.append(dict(
-                w_qkv=half(torch.cat([wq, wk, wv], 0)), b_qkv=torch.cat([bq, bk, bv], 0).contiguous(),
-                w_o=half(f32(p + "attention.out_proj.weight")), b_o=f32(p + "attention.out_proj.bias"),
-                ln1=(f32(p + "layer_norm.weight"), f32(p + "layer_norm.bias")),
-                w1=half(f32(p + "feed_forward.intermediate_dense.weight")), b1=f32(p + "feed_forward.intermediate_dense.bias"),
-                w2=half(f32(p + "feed_forward.output_dense.weight")), b2=f32(p + "feed_forward.output_dense.bias"),
-                ln2=(f32(p + "final_layer_norm.weight"), f32(p + "final_layer_norm.bias"))))
+        c = _capi.AvesConfig()
+        c.embed_dim, c.num_heads, c.num_layers = self.E, self.H, self.L
+        c.ffn_dim = int(cfg.get("encoder_ff_interm_features", 4 * self.E))
+        c.pos_conv_kernel, c.pos_conv_groups, c.n_conv_layers = self.KP, self.G, len(self.convs)
+        for i, (_c, k, st) in enumerate(self.convs):
+            c.conv_kernel[i], c.conv_stride[i] = k, st
+        c.operand_dtype = _capi.dtype_code(operand_dtype)
+        c.max_chunk_clips = int(max_chunk_clips)
+        c.residual_dtype = K.RESIDUAL_CODES[str(residual).lower()]
+        sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
+        arr, n, keep = K.tensor_table(sub)
+        self._h = _capi.lib().avexhip_aves_create(C.byref(c), arr, n)
+        del keep
+        if not self._h:
+            raise K.AvexHipError(f"aves_create failed: {_capi.last_error()}")
+        self._ws: Optional[torch.Tensor] = None
+        self._state, self._prefix = state, prefix
+        self._conv_weights = None
 
     def num_tokens(self, T: int) -> int:
         return conv_frame_plan(T, self.convs)[0][-1]
 
     def extract_conv_features(self, wav: torch.Tensor) -> torch.Tensor:
-        """``[B, T]`` -> half ``[B, frames, 512]`` (output of the 7-layer feature extractor)."""
+        """``[B, T]`` -> half ``[B, frames, 512]``: the 7-layer feature extractor alone, composed from the exported kernels (layer 0 =
+        ``avexhip_wavconv0``, layers 1-6 = strided-row ``avexhip_gemm``) -- what the handle runs as its first stage, kept for tests."""
+        if self._conv_weights is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            def f32(name):
+                v = self._state[self._prefix + name]
+                if isinstance(v, torch.Tensor):
+                    return v.detach().to(device=dev, dtype=torch.float32).contiguous()
+                return torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32))).to(dev)
+            fe = "feature_extractor.conv_layers."
+            self._conv_weights = dict(
+                w0=f32(fe + "0.conv.weight").reshape(512, 10), gn_w=f32(fe + "0.layer_norm.weight"), gn_b=f32(fe + "0.layer_norm.bias"),
+                # conv weights [out, in, k] -> [out, k, in]: the K order of a strided activation row is (frame, channel)
+                wc=[K.to_half(f32(fe + f"{i}.conv.weight").permute(0, 2, 1).reshape(512, -1).contiguous(), self.dtype) for i in range(1, len(self.convs))],
+                zero_bias=torch.zeros(512, dtype=torch.float32, device=dev))
+        cw = self._conv_weights
         B, T = wav.shape
         F, P = conv_frame_plan(T, self.convs)
-        x = K.wavconv0(wav, self.w0, self.gn_w, self.gn_b, P[0], slack_rows=8, dtype=self.dtype)
+        x = K.wavconv0(wav, cw["w0"], cw["gn_w"], cw["gn_b"], P[0], slack_rows=8, dtype=self.dtype)
         for l in range(1, len(self.convs)):
             _c, k, s = self.convs[l]
             rows = B * P[l]
-            x = K.gemm(x, self.wc[l - 1], bias=self.zero_bias, gelu=True, out_f32=False, out_half=True, lda=s * 512, rows=rows, kdim=k * 512,
+            x = K.gemm(x, cw["wc"][l - 1], bias=cw["zero_bias"], gelu=True, out_f32=False, out_half=True, lda=s * 512, rows=rows, kdim=k * 512,
                        slack_rows=8)["half"]      # slack: the next layer's rows of the last clip read a little past it
         return x[:B * P[-1]].view(B, P[-1], 512)[:, :F[-1]].contiguous()
 
     @torch.no_grad()
-    def forward(self, wav: torch.Tensor, hook_layers: Iterable[int] = (), want_features: bool = True, want_pooled: bool = False
-                ) -> Dict[str, object]:
+    def forward(self, wav: torch.Tensor, hook_layers: Iterable[int] = (), want_features: bool = True, want_pooled: bool = False,
+                frame_pad: Optional[torch.Tensor] = None, hook_pooled: bool = False) -> Dict[str, object]:
         """``hook_layers``: transformer layer indices whose ``feed_forward.output_dense`` output is returned (fp32 ``[B, T', 768]``)."""
         if wav.dim() != 2 or wav.dtype != torch.float32 or not wav.is_cuda:
             raise ValueError("wav must be a [B, T] float32 CUDA tensor")
-        B = wav.shape[0]
-        hooks = set(int(i) for i in hook_layers)
-        feats = self.extract_conv_features(wav)
-        Tt = feats.shape[1]
-        M, E = B * Tt, self.E
-        _, h = K.layernorm(feats.view(M, 512), *self.fp_ln, want_f32=False)
-        x = K.gemm(h, self.fp_w, bias=self.fp_b, out_f32=False, out_half=True)["half"]
-        pre = K.posconv(x.view(B, Tt, E), None, self.pc_w, self.pc_b, self.G, self.KP, half_out=True).view(M, E)
-        _, x = K.layernorm(pre, *self.enc_ln, want_f32=False)
-        out: Dict[str, object] = {"hooks": {}}
-        x32 = None
-        for i, ly in enumerate(self.layers):
-            qkv = K.gemm(x, ly["w_qkv"], bias=ly["b_qkv"], out_f32=False, out_half=True)["half"]
-            a = K.attention(qkv, B, Tt, self.H, None, None, None, None)
-            pre = K.gemm(a, ly["w_o"], bias=ly["b_o"], resid_half=x, alpha=1.0, out_f32=False, out_half=True)["half"]
-            _, x = K.layernorm(pre, *ly["ln1"], want_f32=False)
-            hdn = K.gemm(x, ly["w1"], bias=ly["b1"], gelu=True, out_f32=False, out_half=True)["half"]
-            r = K.gemm(hdn, ly["w2"], bias=ly["b2"], resid_half=x, alpha=1.0, out_f32=False, out_half=True, out_raw=i in hooks)
-            if i in hooks:
-                out["hooks"][i] = r["raw"].view(B, Tt, E)
-            last = i == self.L - 1
-            x32, x = K.layernorm(r["half"], *ly["ln2"], want_f32=last and (want_features or want_pooled), want_half=not last)
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, T = wav.shape
+        dev = wav.device
+        Tt = self.num_tokens(T)
+        E = self.E
+        need = int(_capi.lib().avexhip_aves_workspace_bytes(self._h, B, T))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        hooks: Dict[int, torch.Tensor] = {}
+        ptrs = (C.c_void_p * max(self.L, 1))()
+        mask = 0
+        for i in sorted(set(int(x) for x in hook_layers)):
+            if not 0 <= i < self.L:
+                raise ValueError(f"hook layer {i} out of range 0..{self.L - 1}")
+            hooks[i] = torch.empty((B, E) if hook_pooled else (B, Tt, E), dtype=torch.float32, device=dev)
+            ptrs[i] = int(hooks[i].data_ptr())
+            mask |= 1 << i
+        feats = torch.empty((B, Tt, E), dtype=torch.float32, device=dev) if want_features else None
+        pooled = torch.empty((B, E), dtype=torch.float32, device=dev) if want_pooled else None
+        pad = None
+        if frame_pad is not None:
+            pad = frame_pad.to(device=dev, dtype=torch.uint8).contiguous()
+            if pad.shape != (B, Tt):
+                raise ValueError(f"frame_pad must be [B={B}, T'={Tt}], got {tuple(pad.shape)}")
+        _capi.check(_capi.lib().avexhip_aves_forward(self._h, K._ptr(wav), B, T, wav.stride(0), K._ptr(pad), mask, ptrs, int(hook_pooled), K._ptr(feats),
+                                                     K._ptr(pooled), K._ptr(self._ws), self._ws.numel(), K._stream()), "aves_forward")
+        out: Dict[str, object] = {"hooks": hooks}
         if want_features:
-            out["features"] = x32.view(B, Tt, E)
+            out["features"] = feats
         if want_pooled:
-            out["pooled"] = K.mean_pool(x32.view(B, Tt, E))
+            out["pooled"] = pooled
         return out
+
+    def overflow_events(self, sync: bool = True) -> int:
+        n = C.c_uint32(0)
+        _capi.check(_capi.lib().avexhip_aves_overflow_count(self._h, C.byref(n), K._stream(), int(bool(sync))), "aves_overflow_count")
+        return int(n.value)
+
+    def set_profiling(self, enabled: bool) -> None:
+        _capi.check(_capi.lib().avexhip_aves_set_profiling(self._h, int(enabled)), "aves_set_profiling")
+
+    def last_profile(self):
+        return K.handle_profile(_capi.lib().avexhip_aves_last_profile, self._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _capi.lib().avexhip_aves_destroy(self._h)
+            self._h = None
+        self._ws = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "common.h"
+#include "handle_core.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -146,36 +147,21 @@ extern "C" int avexhip_rel_bucket(int rel, int num_buckets, int max_distance) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// BEATs handle
+// BEATs handle (the shared parts -- weight table, layer parameters, the layer loop -- are in handle_core.h)
 // ---------------------------------------------------------------------------------------------
 const avx::FbankDev* avexhip_fbank_plan_dev(const avexhip_fbank_plan* plan);
 
+using avxh::align_up;
+using avxh::CoreCfg;
+using avxh::CoreIo;
+using avxh::CoreWs;
+using avxh::dev_f32;
+using avxh::dev_half;
+using avxh::Layer;
+using avxh::Prof;
+using avxh::Table;
+
 namespace {
-
-struct Layer {
-    void* w_qkv = nullptr; float* b_qkv = nullptr;
-    void* w_o = nullptr;   float* b_o = nullptr;
-    float* grep_w = nullptr; float* grep_b = nullptr; float* grep_a = nullptr;
-    float* ln1_w = nullptr; float* ln1_b = nullptr;
-    void* w_fc1 = nullptr; float* b_fc1 = nullptr;
-    void* w_fc2 = nullptr; float* b_fc2 = nullptr;
-    float* ln2_w = nullptr; float* ln2_b = nullptr;
-    // LayerNorm-folded copies (see GemmArgs): fc1 consumes LN1 of this layer, QKV consumes LN2 of the previous layer
-    void* w_fc1_f = nullptr; float* b_fc1_f = nullptr; float* s_fc1 = nullptr;
-    void* w_qkv_f = nullptr; float* b_qkv_f = nullptr; float* s_qkv = nullptr;
-    // residual-side folds (GemmArgs::lnr_prefolded): fc2 adds alpha * LN1(y1) of this layer, out_proj alpha * LN2(y2) of the previous layer;
-    // ga = alpha * gamma, bb = bias + alpha * beta
-    float* ga_fc2 = nullptr; float* bb_fc2 = nullptr;
-    float* ga_o = nullptr; float* bb_o = nullptr;
-};
-
-struct StageRec {
-    std::string name;
-    double flops;
-    hipEvent_t e0, e1;
-};
-
-size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // window / mel bank as the reference builds them (beats.py:75,82-118), fp32 arithmetic
 void default_window(int win, std::vector<float>& w) {
@@ -210,9 +196,8 @@ void default_mel(int n_fft, int n_mels, float sr, float low, float high, std::ve
 
 }  // namespace
 
-struct avexhip_beats {
+struct avexhip_beats : avxh::HandleBase {
     avexhip_beats_config cfg;
-    int dtype = AVEXHIP_F16;
     int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 256;
     bool fast = false;   // residual stream / pre-LN sums in the operand type
     bool ln_fold = false;  // fast mode: LayerNorms between the GEMMs folded into their epilogues
@@ -231,25 +216,15 @@ struct avexhip_beats {
     std::vector<float> rel_table;  // host [num_buckets, H]; empty if no relative position embedding
     std::map<int, float*> bias_tabs;       // per token count T: [H, 2T-1] Toeplitz rows; at most BIAS_TAB_CACHE entries, least recently used evicted
     std::vector<int> bias_tab_lru;         // token counts, most recent last
-    std::vector<void*> allocs;
-    // range alarm of the f16 conversions (GemmArgs::ovf): device counter every GEMM of a forward adds to, mirrored to pinned host
-    // memory by an asynchronous copy at the end of each forward (read without a synchronisation by avexhip_beats_overflow_count)
-    unsigned int* d_ovf = nullptr;
-    unsigned int* h_ovf = nullptr;
-    bool profiling = false;
-    std::vector<StageRec> recs;
-    std::vector<std::string> prof_names;
-    std::vector<const char*> prof_name_ptrs;
-    std::vector<float> prof_ms;
-    std::vector<double> prof_flops;
 
-    ~avexhip_beats() {
-        for (void* p : allocs) (void)hipFree(p);
+    CoreCfg core() const {
+        CoreCfg c;
+        c.E = E; c.F = F; c.H = H; c.L = L; c.alpha = alpha; c.eps = 1e-5f; c.hook_site = 0; c.fast = fast; c.fold = ln_fold;
+        return c;
+    }
+    ~avexhip_beats() override {
         for (auto& kv : bias_tabs) (void)hipFree(kv.second);
-        if (d_ovf) (void)hipFree(d_ovf);
-        if (h_ovf) (void)hipHostFree(h_ovf);
         if (fb) avexhip_fbank_plan_destroy(fb);
-        for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (int i = 0; i < 3; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
     }
@@ -257,128 +232,11 @@ struct avexhip_beats {
 
 namespace {
 
-struct Table {
-    const avexhip_tensor* t;
-    int n;
-    const avexhip_tensor* find(const std::string& name) const {
-        for (int i = 0; i < n; ++i) {
-            if (!t[i].name) continue;
-            const char* nm = t[i].name;
-            if (strncmp(nm, "backbone.", 9) == 0) nm += 9;
-            if (name == nm) return &t[i];
-        }
-        return nullptr;
-    }
-};
-
-// copy an fp32 tensor to the device (source may be host or device memory)
-int dev_f32(avexhip_beats* h, const Table& tb, const std::string& name, int64_t numel, float** out, bool required = true) {
-    const avexhip_tensor* t = tb.find(name);
-    if (!t) {
-        if (!required) { *out = nullptr; return AVEXHIP_OK; }
-        avexhip_set_error("beats_create: tensor '%s' missing from the weight table", name.c_str());
-        return AVEXHIP_ERR_MISSING;
-    }
-    if (t->numel != numel || !t->data) {
-        avexhip_set_error("beats_create: tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)t->numel, (long long)numel);
-        return AVEXHIP_ERR_INVALID;
-    }
-    float* d = nullptr;
-    AVX_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * (size_t)numel));
-    h->allocs.push_back(d);
-    AVX_HIP_CHECK(hipMemcpy(d, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
-    *out = d;
-    return AVEXHIP_OK;
-}
-
-// fp32 tensor -> half copy at dst (device), via a temporary fp32 device staging buffer
-int dev_half_into(avexhip_beats* h, const Table& tb, const std::string& name, int64_t numel, void* dst) {
-    const avexhip_tensor* t = tb.find(name);
-    if (!t) {
-        avexhip_set_error("beats_create: tensor '%s' missing from the weight table", name.c_str());
-        return AVEXHIP_ERR_MISSING;
-    }
-    if (t->numel != numel || !t->data) {
-        avexhip_set_error("beats_create: tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)t->numel, (long long)numel);
-        return AVEXHIP_ERR_INVALID;
-    }
-    float* tmp = nullptr;
-    AVX_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)numel));
-    hipError_t e = hipMemcpy(tmp, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault);
-    int rc = AVEXHIP_OK;
-    if (e != hipSuccess) {
-        avexhip_set_error("beats_create: copy of '%s' failed: %s", name.c_str(), hipGetErrorString(e));
-        rc = AVEXHIP_ERR_HIP;
-    } else {
-        rc = avx::cast_to_half(tmp, dst, numel, h->dtype, nullptr);
-        if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) {
-            avexhip_set_error("beats_create: cast of '%s' failed", name.c_str());
-            rc = AVEXHIP_ERR_HIP;
-        }
-    }
-    (void)hipFree(tmp);
-    return rc;
-}
-
-int dev_half(avexhip_beats* h, const Table& tb, const std::string& name, int64_t numel, void** out) {
-    void* d = nullptr;
-    AVX_HIP_CHECK(hipMalloc(&d, 2 * (size_t)numel));
-    h->allocs.push_back(d);
-    *out = d;
-    return dev_half_into(h, tb, name, numel, d);
-}
-
-// W' = half(W * diag(gamma)), b' = b + W beta, s[n] = sum_k float(W'[n][k]) for a consumer of LayerNorm(y; gamma, beta)
-// (W: [N, K] fp32 host rows gathered from the table by the caller)
-int fold_ln(avexhip_beats* h, const std::vector<float>& W, const std::vector<float>& b, int N, int K, const float* gamma_dev,
-            const float* beta_dev, void** w_out, float** b_out, float** s_out) {
-    std::vector<float> gamma(K), beta(K), Wg((size_t)N * K), bf(N);
-    AVX_HIP_CHECK(hipMemcpy(gamma.data(), gamma_dev, sizeof(float) * K, hipMemcpyDefault));
-    AVX_HIP_CHECK(hipMemcpy(beta.data(), beta_dev, sizeof(float) * K, hipMemcpyDefault));
-    for (int n = 0; n < N; ++n) {
-        double acc = b[n];
-        const float* wr = &W[(size_t)n * K];
-        float* wo = &Wg[(size_t)n * K];
-        for (int k = 0; k < K; ++k) { wo[k] = wr[k] * gamma[k]; acc += (double)wr[k] * (double)beta[k]; }
-        bf[n] = (float)acc;
-    }
-    float* tmp = nullptr;
-    AVX_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)N * K));
-    void* wd = nullptr; float* bd = nullptr; float* sd = nullptr;
-    int rc = AVEXHIP_OK;
-    if (hipMalloc(&wd, 2 * (size_t)N * K) != hipSuccess || hipMalloc((void**)&bd, sizeof(float) * N) != hipSuccess ||
-        hipMalloc((void**)&sd, sizeof(float) * N) != hipSuccess) {
-        avexhip_set_error("beats_create: device allocation for folded weights failed");
-        rc = AVEXHIP_ERR_HIP;
-    }
-    if (wd) h->allocs.push_back(wd);
-    if (bd) h->allocs.push_back(bd);
-    if (sd) h->allocs.push_back(sd);
-    if (rc == AVEXHIP_OK && (hipMemcpy(tmp, Wg.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice) != hipSuccess ||
-                             hipMemcpy(bd, bf.data(), sizeof(float) * N, hipMemcpyHostToDevice) != hipSuccess)) {
-        avexhip_set_error("beats_create: upload of folded weights failed");
-        rc = AVEXHIP_ERR_HIP;
-    }
-    if (rc == AVEXHIP_OK) rc = avx::cast_to_half(tmp, wd, (int64_t)N * K, h->dtype, nullptr);
-    if (rc == AVEXHIP_OK) rc = avx::row_sum_half(wd, N, K, sd, h->dtype, nullptr);
-    if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) { avexhip_set_error("beats_create: folding failed"); rc = AVEXHIP_ERR_HIP; }
-    (void)hipFree(tmp);
-    *w_out = wd; *b_out = bd; *s_out = sd;
-    return rc;
-}
-
-// gather an fp32 tensor of the table into a host vector (appending)
-int host_f32(const Table& tb, const std::string& name, int64_t numel, std::vector<float>& out) {
-    const avexhip_tensor* t = tb.find(name);
-    if (!t || t->numel != numel || !t->data) {
-        avexhip_set_error("beats_create: tensor '%s' missing or mis-sized", name.c_str());
-        return AVEXHIP_ERR_MISSING;
-    }
-    const size_t o = out.size();
-    out.resize(o + (size_t)numel);
-    AVX_HIP_CHECK(hipMemcpy(out.data() + o, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
-    return AVEXHIP_OK;
-}
+// parameter names of avex/models/beats/backbone.py's encoder layers (state-dict keys under "backbone.")
+const avxh::LayerNames BEATS_NAMES = {nullptr, "encoder.layers.%d.self_attn.q_proj", "encoder.layers.%d.self_attn.k_proj", "encoder.layers.%d.self_attn.v_proj",
+                                      "encoder.layers.%d.self_attn.out_proj", "encoder.layers.%d.self_attn_layer_norm", "encoder.layers.%d.fc1",
+                                      "encoder.layers.%d.fc2", "encoder.layers.%d.final_layer_norm", "encoder.layers.%d.self_attn.grep_linear",
+                                      "encoder.layers.%d.self_attn.grep_a"};
 
 int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
     const avexhip_beats_config& c = h->cfg;
@@ -437,72 +295,11 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
     RC(dev_f32(h, tb, "encoder.layer_norm.bias", E, &h->lnE_b));
 
     h->layers.resize(h->L);
-    for (int i = 0; i < h->L; ++i) {
-        Layer& ly = h->layers[i];
-        const std::string p = "encoder.layers." + std::to_string(i) + ".";
-        const std::string sa = p + "self_attn.";
-        // fused QKV weight [3E, E] and bias [3E]
-        AVX_HIP_CHECK(hipMalloc(&ly.w_qkv, 2 * (size_t)3 * E * E));
-        h->allocs.push_back(ly.w_qkv);
-        RC(dev_half_into(h, tb, sa + "q_proj.weight", (int64_t)E * E, ly.w_qkv));
-        RC(dev_half_into(h, tb, sa + "k_proj.weight", (int64_t)E * E, (char*)ly.w_qkv + 2 * (size_t)E * E));
-        RC(dev_half_into(h, tb, sa + "v_proj.weight", (int64_t)E * E, (char*)ly.w_qkv + 4 * (size_t)E * E));
-        AVX_HIP_CHECK(hipMalloc((void**)&ly.b_qkv, sizeof(float) * 3 * E));
-        h->allocs.push_back(ly.b_qkv);
-        const char* bn[3] = {"q_proj.bias", "k_proj.bias", "v_proj.bias"};
-        for (int j = 0; j < 3; ++j) {
-            const avexhip_tensor* t = tb.find(sa + bn[j]);
-            if (!t || t->numel != E) {
-                avexhip_set_error("beats_create: tensor '%s%s' missing or mis-sized", sa.c_str(), bn[j]);
-                return AVEXHIP_ERR_MISSING;
-            }
-            AVX_HIP_CHECK(hipMemcpy(ly.b_qkv + (size_t)j * E, t->data, sizeof(float) * E, hipMemcpyDefault));
-        }
-        RC(dev_half(h, tb, sa + "out_proj.weight", (int64_t)E * E, &ly.w_o));
-        RC(dev_f32(h, tb, sa + "out_proj.bias", E, &ly.b_o));
-        if (c.gru_rel_pos) {
-            RC(dev_f32(h, tb, sa + "grep_linear.weight", 8 * (E / H), &ly.grep_w));
-            RC(dev_f32(h, tb, sa + "grep_linear.bias", 8, &ly.grep_b));
-            RC(dev_f32(h, tb, sa + "grep_a", H, &ly.grep_a));
-        }
-        RC(dev_f32(h, tb, p + "self_attn_layer_norm.weight", E, &ly.ln1_w));
-        RC(dev_f32(h, tb, p + "self_attn_layer_norm.bias", E, &ly.ln1_b));
-        RC(dev_half(h, tb, p + "fc1.weight", (int64_t)F * E, &ly.w_fc1));
-        RC(dev_f32(h, tb, p + "fc1.bias", F, &ly.b_fc1));
-        RC(dev_half(h, tb, p + "fc2.weight", (int64_t)E * F, &ly.w_fc2));
-        RC(dev_f32(h, tb, p + "fc2.bias", E, &ly.b_fc2));
-        RC(dev_f32(h, tb, p + "final_layer_norm.weight", E, &ly.ln2_w));
-        RC(dev_f32(h, tb, p + "final_layer_norm.bias", E, &ly.ln2_b));
-        if (h->ln_fold) {
-            auto two = [&](float** ga, float** bb) -> int {
-                AVX_HIP_CHECK(hipMalloc((void**)ga, sizeof(float) * 2 * (size_t)E));
-                h->allocs.push_back(*ga);
-                *bb = *ga + E;
-                return AVEXHIP_OK;
-            };
-            RC(two(&ly.ga_fc2, &ly.bb_fc2));
-            RC(avx::lnr_fold(ly.ln1_w, ly.ln1_b, ly.b_fc2, h->alpha, E, ly.ga_fc2, ly.bb_fc2, nullptr));
-            if (i > 0) {
-                const Layer& prev = h->layers[i - 1];
-                RC(two(&ly.ga_o, &ly.bb_o));
-                RC(avx::lnr_fold(prev.ln2_w, prev.ln2_b, ly.b_o, h->alpha, E, ly.ga_o, ly.bb_o, nullptr));
-            }
-            std::vector<float> Wh, bh;
-            RC(host_f32(tb, p + "fc1.weight", (int64_t)F * E, Wh));
-            RC(host_f32(tb, p + "fc1.bias", F, bh));
-            RC(fold_ln(h, Wh, bh, F, E, ly.ln1_w, ly.ln1_b, &ly.w_fc1_f, &ly.b_fc1_f, &ly.s_fc1));
-            if (i > 0) {   // QKV of layer i reads LN2 of layer i-1
-                Wh.clear(); bh.clear();
-                RC(host_f32(tb, sa + "q_proj.weight", (int64_t)E * E, Wh));
-                RC(host_f32(tb, sa + "k_proj.weight", (int64_t)E * E, Wh));
-                RC(host_f32(tb, sa + "v_proj.weight", (int64_t)E * E, Wh));
-                RC(host_f32(tb, sa + "q_proj.bias", E, bh));
-                RC(host_f32(tb, sa + "k_proj.bias", E, bh));
-                RC(host_f32(tb, sa + "v_proj.bias", E, bh));
-                const Layer& prev = h->layers[i - 1];
-                RC(fold_ln(h, Wh, bh, 3 * E, E, prev.ln2_w, prev.ln2_b, &ly.w_qkv_f, &ly.b_qkv_f, &ly.s_qkv));
-            }
-        }
+    {
+        avxh::LayerNames nm = BEATS_NAMES;
+        if (!c.gru_rel_pos) { nm.grep_linear = nullptr; nm.grep_a = nullptr; }
+        const CoreCfg cc = h->core();
+        for (int i = 0; i < h->L; ++i) RC(avxh::build_layer(h, tb, nm, cc, h->layers, i));
     }
     // shared relative-position table (owned by layer 0, backbone.py:100-103)
     if (c.num_buckets > 0) {
@@ -518,6 +315,8 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
     AVX_HIP_CHECK(hipDeviceSynchronize());
     return AVEXHIP_OK;
 }
+
+// [H, 2T-1] Toeplitz rows of compute_bias (backbone.py:475-492), cached per T
 
 // [H, 2T-1] Toeplitz rows of compute_bias (backbone.py:475-492), cached per T
 int bias_tab_for(avexhip_beats* h, int T, float** out) {
@@ -556,9 +355,8 @@ int bias_tab_for(avexhip_beats* h, int T, float** out) {
 }
 
 struct Ws {
-    char* patches; float* f0; char* h0; float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
-    float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
-    float* r1; float* r2;     // ... reduced to (rstd, -mu rstd) per row by avx::ln_rowstats
+    char* patches; float* f0; char* h0;
+    CoreWs core;
     size_t total;
 };
 
@@ -571,18 +369,7 @@ Ws carve(const avexhip_beats* h, char* base, int Bc, int Tt) {
     w.patches = take(M * PP * 2);
     w.f0 = (float*)take(M * h->D * 4);
     w.h0 = take(M * h->D * 2);
-    w.x = (float*)take(M * h->E * 4);
-    w.xh = take(M * h->E * 2);
-    w.pre = (float*)take(h->fast ? 256 : M * h->E * 4);
-    w.preh = take(h->fast ? M * h->E * 2 : 256);
-    w.qkv = take(M * 3 * h->E * 2);
-    w.ah = take(M * h->E * 2);
-    w.hh = take(M * h->F * 2);
-    w.raw = (float*)take(M * h->E * 4);
-    w.st1 = (float*)take(h->ln_fold ? M * (h->E / 64) * 8 : 256);
-    w.st2 = (float*)take(h->ln_fold ? M * (h->E / 64) * 8 : 256);
-    w.r1 = (float*)take(h->ln_fold ? (M + 256) * 8 : 256);
-    w.r2 = (float*)take(h->ln_fold ? (M + 256) * 8 : 256);
+    w.core = avxh::carve_core(h->core(), M, take);
     w.total = off;
     return w;
 }
@@ -602,29 +389,6 @@ void plan_chunks(const avexhip_beats* h, int B, int Tt, int* chunk, int* lanes) 
     }
     *chunk = c; *lanes = l;
 }
-
-struct Prof {
-    avexhip_beats* h;
-    hipStream_t s;
-    size_t next = 0;
-    void begin(const char* name, double flops) {
-        if (!h->profiling) return;
-        if (next == h->recs.size()) {
-            StageRec r;
-            (void)hipEventCreate(&r.e0);
-            (void)hipEventCreate(&r.e1);
-            h->recs.push_back(r);
-        }
-        h->recs[next].name = name;
-        h->recs[next].flops = flops;
-        (void)hipEventRecord(h->recs[next].e0, s);
-    }
-    void end() {
-        if (!h->profiling) return;
-        (void)hipEventRecord(h->recs[next].e1, s);
-        ++next;
-    }
-};
 
 int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int B, int64_t T, int64_t stride, int frames,
                  const uint8_t* frame_pad, uint32_t hook_mask, float* const* hook_out, int hook_pooled,
@@ -705,9 +469,9 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         // "fast" keeps the residual stream (post-LN x) and the pre-LN sums in the operand type between
         // kernels; otherwise they are fp32.  x32 / pre32 / preh below are NULL when unused.
         const bool fast = h->fast;
-        float* x32 = w.x;                       // fp32 x (precise mode; in fast mode only hook 0 / final output scratch)
-        float* pre32 = fast ? nullptr : w.pre;
-        void* preh = fast ? w.preh : nullptr;
+        float* x32 = w.core.x;                       // fp32 x (precise mode; in fast mode only hook 0 / final output scratch)
+        float* pre32 = fast ? nullptr : w.core.pre;
+        void* preh = fast ? w.core.preh : nullptr;
         const bool hook0 = (hook_mask & 1u) != 0;
         avx::GemmArgs g;
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
@@ -720,14 +484,14 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         if (h->w_post) {
             RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, nullptr, D, w.h0, D, dt, cs));
         } else {   // embed_dim == encoder_embed_dim: the LayerNorm output is x itself; padded tokens are zeroed here (backbone.py:169-170)
-            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, fast ? nullptr : x32, E, w.xh, E, dt, cs));
-            RC(avx::zero_rows(fast ? nullptr : x32, E, w.xh, E, M, E, pad, cs));
+            RC(avx::layernorm(fast ? nullptr : w.f0, fast ? w.h0 : nullptr, D, h->ln0_w, h->ln0_b, 1e-5f, M, D, fast ? nullptr : x32, E, w.core.xh, E, dt, cs));
+            RC(avx::zero_rows(fast ? nullptr : x32, E, w.core.xh, E, M, E, pad, cs));
         }
         prof.end();
         if (h->w_post) {
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.h0; g.lda = D; g.W = h->w_post; g.ldw = D; g.M = M; g.N = E; g.K = D; g.bias = h->b_post;
-            g.out_half = w.xh; g.ldh = E; g.row_zero = pad;
+            g.out_half = w.core.xh; g.ldh = E; g.row_zero = pad;
             if (!fast || hook0) { g.out_f32 = x32; g.ldo = E; }
             prof.begin("gemm.post_extract_proj", 2.0 * Md * E * D);
             RC(avx::gemm(g, dt, cs));
@@ -741,112 +505,17 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         }
         // 3. convolutional positional embedding + residual, encoder LayerNorm
         prof.begin("posconv", 2.0 * Md * E * (E / h->cfg.conv_pos_groups) * h->cfg.conv_pos);
-        RC(avx::posconv(w.xh, fast ? nullptr : x32, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, pre32, preh, dt, cs));
+        RC(avx::posconv(w.core.xh, fast ? nullptr : x32, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, pre32, preh, dt, cs));
         prof.end();
         prof.begin("layernorm", 0.0);
-        RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
+        RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.core.xh, E, dt, cs));
         prof.end();
 
-        // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375)
-        // "fold": the two LayerNorms of a layer never run as kernels.  y1 = x*alpha + attn (preh) and y2 = x1*alpha + ffn (xh) stay raw
-        // in the operand type with per-row partial statistics from the epilogue that wrote them; fc1 / the next QKV read them
-        // through LayerNorm-folded weights, out_proj / fc2 apply LayerNorm to their residual on the fly (GemmArgs, gemm.hip).
-        const bool fold = fast && h->ln_fold;      // any M: the same arithmetic whatever the chunking
-        const int nseg = E / 64;
-        for (int i = 0; i < L; ++i) {
-            const Layer& ly = h->layers[i];
-            const bool raw_in = fold && i > 0;      // xh holds y2 of layer i-1 (raw) instead of its LayerNorm
-            const Layer* pl = i > 0 ? &h->layers[i - 1] : nullptr;
-            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-            g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
-            g.out_half = w.qkv; g.ldh = 3 * E;
-            if (raw_in) { g.W = ly.w_qkv_f; g.bias = ly.b_qkv_f; g.ln_rows = w.r2; g.ln_s = ly.s_qkv; }
-            prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
-            RC(avx::gemm(g, dt, cs));
-            prof.end();
-            prof.begin("attention", 4.0 * Md * Tt * E + 2.0 * Md * 8 * (E / H) * H);
-            RC(avx::attention(w.qkv, Bc, Tt, H, bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, pad, w.ah, dt, cs));
-            prof.end();
-            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-            g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = h->alpha;
-            if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
-            else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
-            if (fold) {
-                g.stats_out = w.st1;
-                if (raw_in) {
-                    g.resid_half = nullptr; g.ldrh = 0;
-                    g.lnr_y = w.xh; g.ldy = E; g.lnr_rows = w.r2; g.lnr_gamma = ly.ga_o; g.lnr_beta = ly.bb_o; g.lnr_prefolded = 1;
-                }
-            }
-            prof.begin("gemm.out_proj", 2.0 * Md * E * E);
-            RC(avx::gemm(g, dt, cs));
-            prof.end();
-            if (fold) {
-                prof.begin("ln_rowstats", 0.0);
-                RC(avx::ln_rowstats(w.st1, M, nseg, 1e-5f, w.r1, cs));
-                prof.end();
-            }
-            if (!fold) {
-                prof.begin("layernorm", 0.0);
-                RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
-                prof.end();
-            }
-            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-            g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
-            g.out_half = w.hh; g.ldh = F;
-            if (fold) { g.A = preh; g.W = ly.w_fc1_f; g.bias = ly.b_fc1_f; g.ln_rows = w.r1; g.ln_s = ly.s_fc1; }
-            prof.begin("gemm.fc1", 2.0 * Md * F * E);
-            RC(avx::gemm(g, dt, cs));
-            prof.end();
-            const bool hooked = (hook_mask >> (i + 1)) & 1u;
-            memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-            g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = h->alpha;
-            if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
-            else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
-            if (fold) {   // residual = LN1(y1) on the fly; y2 (raw) goes to xh, which nothing reads any more in this layer
-                g.resid_half = nullptr; g.ldrh = 0;
-                g.lnr_y = preh; g.ldy = E; g.lnr_rows = w.r1; g.lnr_gamma = ly.ga_fc2; g.lnr_beta = ly.bb_fc2; g.lnr_prefolded = 1;
-                g.out_half = w.xh; g.stats_out = (i + 1 < L) ? w.st2 : nullptr;      // the last layer's y2 goes to a LayerNorm kernel that takes its own statistics
-            }
-            if (hooked) {
-                g.out_raw = hook_pooled ? w.raw : hook_out[i + 1] + (size_t)c0 * Tt * E;
-                g.ldraw = E;
-            }
-            prof.begin("gemm.fc2", 2.0 * Md * E * F);
-            RC(avx::gemm(g, dt, cs));
-            prof.end();
-            if (hooked && hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, hook_out[i + 1] + (size_t)c0 * E, cs));
-            const bool last = i == L - 1;
-            if (fold && !last) {
-                prof.begin("ln_rowstats", 0.0);
-                RC(avx::ln_rowstats(w.st2, M, nseg, 1e-5f, w.r2, cs));
-                prof.end();
-            }
-            // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
-            float* xo = nullptr;
-            if (last) xo = features_out ? features_out + (size_t)c0 * Tt * E : ((pooled_out || !fast) ? x32 : nullptr);
-            else if (!fast) xo = x32;
-            // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
-            const bool fused_pool = last && pooled_out && !features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
-            if (fused_pool) {      // the pre-LayerNorm sums y2 sit in preh, with the fold in xh
-                prof.begin("layernorm+mean_pool", 0.0);
-                RC(avx::layernorm_pool(fold ? w.xh : preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, Bc, Tt, E, pooled_out + (size_t)c0 * E, dt, cs));
-                prof.end();
-            } else if (!fold) {
-                prof.begin("layernorm", 0.0);
-                if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
-                prof.end();
-            } else if (last && xo) {   // the only LayerNorm of the layer stack that still runs: fp32 features from the raw y2
-                prof.begin("layernorm", 0.0);
-                RC(avx::layernorm(nullptr, w.xh, E, ly.ln2_w, ly.ln2_b, 1e-5f, M, E, xo, E, nullptr, E, dt, cs));
-                prof.end();
-            }
-            if (last && pooled_out && !fused_pool) {
-                prof.begin("mean_pool", 0.0);
-                RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, pooled_out + (size_t)c0 * E, cs));
-                prof.end();
-            }
-        }
+        // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375): avxh::run_layers; hook i + 1 = layer i's raw fc2 output
+        CoreIo io;
+        io.Bc = Bc; io.Tt = Tt; io.c0 = (size_t)c0; io.bias_tab = bias_tab; io.pad = pad; io.hook_mask = hook_mask; io.hook_bit0 = 1;
+        io.hook_out = hook_out; io.hook_pooled = hook_pooled; io.features_out = features_out; io.pooled_out = pooled_out;
+        RC(avxh::run_layers(h, h->core(), h->layers, w.core, io, prof, cs));
         if (L == 0) {
             // no layers: features = encoder LayerNorm output; recompute it in fp32 for the outputs
             if (features_out || pooled_out) {
@@ -866,28 +535,10 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     }
     }   // rounds
 #undef RC
-    if (h->d_ovf && h->h_ovf) AVX_HIP_CHECK(hipMemcpyAsync(h->h_ovf, h->d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-    if (h->profiling) {
-        AVX_HIP_CHECK(hipStreamSynchronize(s));
-        std::map<std::string, std::pair<double, double>> agg;  // name -> (ms, flops)
-        std::vector<std::string> order;
-        for (size_t i = 0; i < prof.next; ++i) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, h->recs[i].e0, h->recs[i].e1);
-            if (!agg.count(h->recs[i].name)) order.push_back(h->recs[i].name);
-            agg[h->recs[i].name].first += ms;
-            agg[h->recs[i].name].second += h->recs[i].flops;
-        }
-        h->prof_names = order;
-        h->prof_ms.clear(); h->prof_flops.clear(); h->prof_name_ptrs.clear();
-        for (auto& nm : h->prof_names) {
-            h->prof_ms.push_back((float)agg[nm].first);
-            h->prof_flops.push_back(agg[nm].second);
-        }
-        for (auto& nm : h->prof_names) h->prof_name_ptrs.push_back(nm.c_str());
-    }
-    return AVEXHIP_OK;
+    { const int rc2 = h->mirror_alarm(s); if (rc2 != AVEXHIP_OK) return rc2; }
+    return prof.collect();
 }
+
 
 }  // namespace
 
@@ -959,13 +610,11 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
             return nullptr;
         }
     }
-    if (hipMalloc((void**)&h->d_ovf, sizeof(unsigned int)) != hipSuccess || hipMemset(h->d_ovf, 0, sizeof(unsigned int)) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_ovf, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
-        avexhip_set_error("beats_create: cannot allocate the range-alarm counter");
+    h->who = "beats_create";
+    if (h->init_alarm() != AVEXHIP_OK) {
         delete h;
         return nullptr;
     }
-    *h->h_ovf = 0;
     h->alpha = c.deep_norm ? powf(2.0f * (float)c.encoder_layers, 0.25f) : 1.0f;
     if (build(h, tensors, n_tensors) != AVEXHIP_OK) {
         delete h;
@@ -1013,16 +662,12 @@ extern "C" int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank,
 
 extern "C" int avexhip_beats_overflow_count(avexhip_beats* h, uint32_t* events, void* sync_stream, int synchronize) {
     AVX_REQUIRE(h && events, "overflow_count: null argument");
-    if (synchronize) AVX_HIP_CHECK(hipStreamSynchronize((hipStream_t)sync_stream));
-    *events = h->h_ovf ? *(volatile unsigned int*)h->h_ovf : 0u;
-    return AVEXHIP_OK;
+    return h->overflow_count(events, (hipStream_t)sync_stream, synchronize);
 }
 
 extern "C" int avexhip_beats_overflow_reset(avexhip_beats* h, void* stream) {
     AVX_REQUIRE(h, "overflow_reset: null handle");
-    AVX_HIP_CHECK(hipMemsetAsync(h->d_ovf, 0, sizeof(unsigned int), (hipStream_t)stream));
-    AVX_HIP_CHECK(hipMemcpyAsync(h->h_ovf, h->d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    return AVEXHIP_OK;
+    return h->overflow_reset((hipStream_t)stream);
 }
 
 extern "C" int avexhip_beats_set_profiling(avexhip_beats* h, int enabled) {

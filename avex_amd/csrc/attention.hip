@@ -355,10 +355,10 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     auto set_qblock = [&](int qb) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-            qi[u] = qb * 512 + (wave + NW * u) * 32 + r32;
+            qi[u] = qb * 512 + (NQ * wave + u) * 32 + r32;   // ADJACENT tiles: tile 1's bias values at key tile k are tile 0's at key tile k - 1 (below)
             iq[u] = qi[u] < Tn ? qi[u] : Tn - 1;         // clamped for loads; stores are masked
         }
-        has_q = qb * 512 + wave * 32 < Tn;
+        has_q = qb * 512 + NQ * wave * 32 < Tn;
     };
     set_qblock(0);
 
@@ -641,11 +641,16 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Sq[u][r] = -m_run[u];
             };
+            // The bias is Toeplitz (it depends on key - query only) and a wave's two query tiles are 32 rows apart, so the 16 values tile 1
+            // needs at key tile k are the ones tile 0 used at key tile k - 1: they stay in registers (tcur) instead of coming from LDS a
+            // second time.  The kernel is LDS-bandwidth-bound (scripts/micro/att_lds16.hip: 2 449 cycles per key tile with its LDS reads,
+            // 1 498 without), and the bias vectors were half of a wave's 16 KB per key tile; now 12 KB.
+            f32x4 tcur[4];
             if (has_bias) {
 #pragma unroll
-                for (int u = 0; u < NQ; ++u)
+                for (int g4 = 0; g4 < 4; ++g4) { tcur[g4] = *(const f32x4*)(tp[0] + 8 * g4); acc_start(0, g4, tcur[g4]); }
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) acc_start(u, g4, *(const f32x4*)(tp[u] + 8 * g4));
+                for (int g4 = 0; g4 < 4; ++g4) acc_start(1, g4, *(const f32x4*)(tp[1] + 8 * g4));
             } else { acc_plain(0); acc_plain(1); }
             if (masked_at(0)) { mask_acc(0, 0); mask_acc(1, 0); }
 #define AVX_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -728,13 +733,13 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                         const v4 lo = __builtin_bit_cast(v4, vt[s2][dh][0]), hi = __builtin_bit_cast(v4, vt[s2][dh][1]);
                         vf[s2][dh] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
-                f32x4 t4n[NQ][4];
+                f32x4 t4n[4];
                 if (ktl + 1 < 8) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
                     if (has_bias) {
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) t4n[0][g4] = *(const f32x4*)(tp[0] + (ktl + 1) * 32 + 8 * g4);
+                        for (int g4 = 0; g4 < 4; ++g4) t4n[g4] = *(const f32x4*)(tp[0] + (ktl + 1) * 32 + 8 * g4);
                     }
                 }
                 AVX_FENCE();
@@ -760,20 +765,20 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 // stage 4
                 if (has_bias) {
                     o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
-                    if (ktl + 1 < 8) {
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) t4n[1][g4] = *(const f32x4*)(tp[1] + (ktl + 1) * 32 + 8 * g4);    // tile 1's values: two MFMAs ahead of their use
-                        acc_start(0, 0, t4n[0][0]); acc_start(0, 1, t4n[0][1]);
-                    }
+                    if (ktl + 1 < 8) { acc_start(0, 0, t4n[0]); acc_start(0, 1, t4n[1]); }
                     AVX_FENCE();
                     o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
-                    if (ktl + 1 < 8) { acc_start(0, 2, t4n[0][2]); acc_start(0, 3, t4n[0][3]); }
+                    if (ktl + 1 < 8) { acc_start(0, 2, t4n[2]); acc_start(0, 3, t4n[3]); }
                     AVX_FENCE();
                     o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
-                    if (ktl + 1 < 8) { acc_start(1, 0, t4n[1][0]); acc_start(1, 1, t4n[1][1]); }
+                    if (ktl + 1 < 8) { acc_start(1, 0, tcur[0]); acc_start(1, 1, tcur[1]); }       // tile 1 at key tile k + 1 = tile 0's values at key tile k
                     AVX_FENCE();
                     o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
-                    if (ktl + 1 < 8) { acc_start(1, 2, t4n[1][2]); acc_start(1, 3, t4n[1][3]); }
+                    if (ktl + 1 < 8) {
+                        acc_start(1, 2, tcur[2]); acc_start(1, 3, tcur[3]);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) tcur[g4] = t4n[g4];
+                    }
                     AVX_FENCE();
                 } else {
                     o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);

@@ -1,0 +1,519 @@
+// What the encoder handles (avexhip_beats in api.cpp; avexhip_eat / avexhip_aves in encoders.cpp) share: the weight-table helpers,
+// the per-layer parameter block, and the post-LN transformer layer loop on the GEMM / attention / LayerNorm kernels -- with the
+// LayerNorms folded into the GEMM epilogues (GemmArgs) when the residual stream is kept in the operand type.
+//
+// The three encoders differ only in what surrounds the loop (frontend, positional scheme) and in four parameters of it:
+//   alpha     DeepNorm residual scale (BEATs: (2 L)^(1/4), backbone.py:304-308; EAT, wav2vec2: 1)
+//   eps       LayerNorm epsilon (BEATs / wav2vec2 1e-5, EAT 1e-6)
+//   bias/gate relative-position bias table + gate (BEATs only)
+//   hook site which raw GEMM output a layer's hook taps: fc2 (BEATs backbone.encoder.layers.{i}.fc2, AVES ...output_dense) or
+//             the attention output projection (EAT backbone.model.blocks.{i}.attn.proj)
+#pragma once
+#include <math.h>
+#include <stdlib.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace avxh {
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct StageRec {
+    std::string name;
+    double flops;
+    hipEvent_t e0, e1;
+};
+
+// state every handle has: operand type, device allocations to free, the f16 range alarm, per-stage profiling
+struct HandleBase {
+    int dtype = AVEXHIP_F16;
+    const char* who = "create";            // prefix of error messages
+    std::vector<void*> allocs;
+    // range alarm of the f16 conversions (GemmArgs::ovf): device counter every GEMM of a forward adds to, mirrored to pinned host
+    // memory by an asynchronous copy at the end of each forward (read without a synchronisation by *_overflow_count)
+    unsigned int* d_ovf = nullptr;
+    unsigned int* h_ovf = nullptr;
+    bool profiling = false;
+    std::vector<StageRec> recs;
+    std::vector<std::string> prof_names;
+    std::vector<const char*> prof_name_ptrs;
+    std::vector<float> prof_ms;
+    std::vector<double> prof_flops;
+
+    int init_alarm() {
+        if (hipMalloc((void**)&d_ovf, sizeof(unsigned int)) != hipSuccess || hipMemset(d_ovf, 0, sizeof(unsigned int)) != hipSuccess ||
+            hipHostMalloc((void**)&h_ovf, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
+            avexhip_set_error("%s: cannot allocate the range-alarm counter", who);
+            return AVEXHIP_ERR_HIP;
+        }
+        *h_ovf = 0;
+        return AVEXHIP_OK;
+    }
+    int mirror_alarm(hipStream_t s) {
+        if (d_ovf && h_ovf) AVX_HIP_CHECK(hipMemcpyAsync(h_ovf, d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        return AVEXHIP_OK;
+    }
+    int overflow_count(uint32_t* events, hipStream_t s, int synchronize) {
+        if (synchronize) AVX_HIP_CHECK(hipStreamSynchronize(s));
+        *events = h_ovf ? *(volatile unsigned int*)h_ovf : 0u;
+        return AVEXHIP_OK;
+    }
+    int overflow_reset(hipStream_t s) {
+        AVX_HIP_CHECK(hipMemsetAsync(d_ovf, 0, sizeof(unsigned int), s));
+        AVX_HIP_CHECK(hipMemcpyAsync(h_ovf, d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        return AVEXHIP_OK;
+    }
+    virtual ~HandleBase() {
+        for (void* p : allocs) (void)hipFree(p);
+        if (d_ovf) (void)hipFree(d_ovf);
+        if (h_ovf) (void)hipHostFree(h_ovf);
+        for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    }
+};
+
+// HIP events around every stage of a forward when the handle is in profiling mode
+struct Prof {
+    HandleBase* h;
+    hipStream_t s;
+    size_t next = 0;
+    void begin(const char* name, double flops) {
+        if (!h->profiling) return;
+        if (next == h->recs.size()) {
+            StageRec r;
+            (void)hipEventCreate(&r.e0);
+            (void)hipEventCreate(&r.e1);
+            h->recs.push_back(r);
+        }
+        h->recs[next].name = name;
+        h->recs[next].flops = flops;
+        (void)hipEventRecord(h->recs[next].e0, s);
+    }
+    void end() {
+        if (!h->profiling) return;
+        (void)hipEventRecord(h->recs[next].e1, s);
+        ++next;
+    }
+    // after the forward: aggregate by stage name (forces a stream synchronisation)
+    int collect() {
+        if (!h->profiling) return AVEXHIP_OK;
+        AVX_HIP_CHECK(hipStreamSynchronize(s));
+        std::map<std::string, std::pair<double, double>> agg;  // name -> (ms, flops)
+        std::vector<std::string> order;
+        for (size_t i = 0; i < next; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, h->recs[i].e0, h->recs[i].e1);
+            if (!agg.count(h->recs[i].name)) order.push_back(h->recs[i].name);
+            agg[h->recs[i].name].first += ms;
+            agg[h->recs[i].name].second += h->recs[i].flops;
+        }
+        h->prof_names = order;
+        h->prof_ms.clear(); h->prof_flops.clear(); h->prof_name_ptrs.clear();
+        for (auto& nm : h->prof_names) {
+            h->prof_ms.push_back((float)agg[nm].first);
+            h->prof_flops.push_back(agg[nm].second);
+        }
+        for (auto& nm : h->prof_names) h->prof_name_ptrs.push_back(nm.c_str());
+        return AVEXHIP_OK;
+    }
+};
+
+// name -> fp32 tensor table handed to *_create; a key matches with or without the wrapper prefixes of the reference's state dicts
+struct Table {
+    const avexhip_tensor* t;
+    int n;
+    const char* strip1 = "backbone.";      // avex/models/beats_model.py, eat_hf.py: self.backbone
+    const char* strip2 = nullptr;          // e.g. "model." (EAT: backbone.model.*, AVES: model.*)
+    const avexhip_tensor* find(const std::string& name) const {
+        for (int i = 0; i < n; ++i) {
+            if (!t[i].name) continue;
+            const char* nm = t[i].name;
+            if (strip1 && strncmp(nm, strip1, strlen(strip1)) == 0) nm += strlen(strip1);
+            if (strip2 && strncmp(nm, strip2, strlen(strip2)) == 0) nm += strlen(strip2);
+            if (name == nm) return &t[i];
+        }
+        return nullptr;
+    }
+};
+
+// copy an fp32 tensor to the device (source may be host or device memory)
+inline int dev_f32(HandleBase* h, const Table& tb, const std::string& name, int64_t numel, float** out, bool required = true) {
+    const avexhip_tensor* t = tb.find(name);
+    if (!t) {
+        if (!required) { *out = nullptr; return AVEXHIP_OK; }
+        avexhip_set_error("%s: tensor '%s' missing from the weight table", h->who, name.c_str());
+        return AVEXHIP_ERR_MISSING;
+    }
+    if (t->numel != numel || !t->data) {
+        avexhip_set_error("%s: tensor '%s' has %lld elements, expected %lld", h->who, name.c_str(), (long long)t->numel, (long long)numel);
+        return AVEXHIP_ERR_INVALID;
+    }
+    float* d = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * (size_t)numel));
+    h->allocs.push_back(d);
+    AVX_HIP_CHECK(hipMemcpy(d, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
+    *out = d;
+    return AVEXHIP_OK;
+}
+
+// gather an fp32 tensor of the table into a host vector (appending)
+inline int host_f32(HandleBase* h, const Table& tb, const std::string& name, int64_t numel, std::vector<float>& out) {
+    const avexhip_tensor* t = tb.find(name);
+    if (!t || t->numel != numel || !t->data) {
+        avexhip_set_error("%s: tensor '%s' missing or mis-sized", h->who, name.c_str());
+        return AVEXHIP_ERR_MISSING;
+    }
+    const size_t o = out.size();
+    out.resize(o + (size_t)numel);
+    AVX_HIP_CHECK(hipMemcpy(out.data() + o, t->data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
+    return AVEXHIP_OK;
+}
+
+// host fp32 values -> half at dst (device), via a temporary fp32 device staging buffer
+inline int upload_half(HandleBase* h, const float* host_or_dev, int64_t numel, void* dst, const char* what) {
+    float* tmp = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)numel));
+    hipError_t e = hipMemcpy(tmp, host_or_dev, sizeof(float) * (size_t)numel, hipMemcpyDefault);
+    int rc = AVEXHIP_OK;
+    if (e != hipSuccess) {
+        avexhip_set_error("%s: copy of '%s' failed: %s", h->who, what, hipGetErrorString(e));
+        rc = AVEXHIP_ERR_HIP;
+    } else {
+        rc = avx::cast_to_half(tmp, dst, numel, h->dtype, nullptr);
+        if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) {
+            avexhip_set_error("%s: cast of '%s' failed", h->who, what);
+            rc = AVEXHIP_ERR_HIP;
+        }
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+// fp32 tensor of the table -> half copy at dst (device)
+inline int dev_half_into(HandleBase* h, const Table& tb, const std::string& name, int64_t numel, void* dst) {
+    const avexhip_tensor* t = tb.find(name);
+    if (!t) {
+        avexhip_set_error("%s: tensor '%s' missing from the weight table", h->who, name.c_str());
+        return AVEXHIP_ERR_MISSING;
+    }
+    if (t->numel != numel || !t->data) {
+        avexhip_set_error("%s: tensor '%s' has %lld elements, expected %lld", h->who, name.c_str(), (long long)t->numel, (long long)numel);
+        return AVEXHIP_ERR_INVALID;
+    }
+    return upload_half(h, (const float*)t->data, numel, dst, name.c_str());
+}
+
+inline int dev_half(HandleBase* h, const Table& tb, const std::string& name, int64_t numel, void** out) {
+    void* d = nullptr;
+    AVX_HIP_CHECK(hipMalloc(&d, 2 * (size_t)numel));
+    h->allocs.push_back(d);
+    *out = d;
+    return dev_half_into(h, tb, name, numel, d);
+}
+
+// W' = half(W * diag(gamma)), b' = b + W beta, s[n] = sum_k float(W'[n][k]) for a consumer of LayerNorm(y; gamma, beta)
+// (W: [N, K] fp32 host rows gathered from the table by the caller)
+inline int fold_ln(HandleBase* h, const std::vector<float>& W, const std::vector<float>& b, int N, int K, const float* gamma_dev,
+                   const float* beta_dev, void** w_out, float** b_out, float** s_out) {
+    std::vector<float> gamma(K), beta(K), Wg((size_t)N * K), bf(N);
+    AVX_HIP_CHECK(hipMemcpy(gamma.data(), gamma_dev, sizeof(float) * K, hipMemcpyDefault));
+    AVX_HIP_CHECK(hipMemcpy(beta.data(), beta_dev, sizeof(float) * K, hipMemcpyDefault));
+    for (int n = 0; n < N; ++n) {
+        double acc = b[n];
+        const float* wr = &W[(size_t)n * K];
+        float* wo = &Wg[(size_t)n * K];
+        for (int k = 0; k < K; ++k) { wo[k] = wr[k] * gamma[k]; acc += (double)wr[k] * (double)beta[k]; }
+        bf[n] = (float)acc;
+    }
+    float* tmp = nullptr;
+    AVX_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)N * K));
+    void* wd = nullptr; float* bd = nullptr; float* sd = nullptr;
+    int rc = AVEXHIP_OK;
+    if (hipMalloc(&wd, 2 * (size_t)N * K) != hipSuccess || hipMalloc((void**)&bd, sizeof(float) * N) != hipSuccess ||
+        hipMalloc((void**)&sd, sizeof(float) * N) != hipSuccess) {
+        avexhip_set_error("%s: device allocation for folded weights failed", h->who);
+        rc = AVEXHIP_ERR_HIP;
+    }
+    if (wd) h->allocs.push_back(wd);
+    if (bd) h->allocs.push_back(bd);
+    if (sd) h->allocs.push_back(sd);
+    if (rc == AVEXHIP_OK && (hipMemcpy(tmp, Wg.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemcpy(bd, bf.data(), sizeof(float) * N, hipMemcpyHostToDevice) != hipSuccess)) {
+        avexhip_set_error("%s: upload of folded weights failed", h->who);
+        rc = AVEXHIP_ERR_HIP;
+    }
+    if (rc == AVEXHIP_OK) rc = avx::cast_to_half(tmp, wd, (int64_t)N * K, h->dtype, nullptr);
+    if (rc == AVEXHIP_OK) rc = avx::row_sum_half(wd, N, K, sd, h->dtype, nullptr);
+    if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) { avexhip_set_error("%s: folding failed", h->who); rc = AVEXHIP_ERR_HIP; }
+    (void)hipFree(tmp);
+    *w_out = wd; *b_out = bd; *s_out = sd;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One post-LN transformer layer's parameters on the device
+// ---------------------------------------------------------------------------------------------
+struct Layer {
+    void* w_qkv = nullptr; float* b_qkv = nullptr;
+    void* w_o = nullptr;   float* b_o = nullptr;
+    float* grep_w = nullptr; float* grep_b = nullptr; float* grep_a = nullptr;
+    float* ln1_w = nullptr; float* ln1_b = nullptr;
+    void* w_fc1 = nullptr; float* b_fc1 = nullptr;
+    void* w_fc2 = nullptr; float* b_fc2 = nullptr;
+    float* ln2_w = nullptr; float* ln2_b = nullptr;
+    // LayerNorm-folded copies (see GemmArgs): fc1 consumes LN1 of this layer, QKV consumes LN2 of the previous layer
+    void* w_fc1_f = nullptr; float* b_fc1_f = nullptr; float* s_fc1 = nullptr;
+    void* w_qkv_f = nullptr; float* b_qkv_f = nullptr; float* s_qkv = nullptr;
+    // residual-side folds (GemmArgs::lnr_prefolded): fc2 adds alpha * LN1(y1) of this layer, out_proj alpha * LN2(y2) of the previous layer;
+    // ga = alpha * gamma, bb = bias + alpha * beta
+    float* ga_fc2 = nullptr; float* bb_fc2 = nullptr;
+    float* ga_o = nullptr; float* bb_o = nullptr;
+};
+
+// parameter names of layer i under a family's naming scheme ("%d" = layer index)
+struct LayerNames {
+    const char* qkv_fused;        // "blocks.%d.attn.qkv" ([3E, E] in one tensor), or NULL when q / k / v are separate:
+    const char* q; const char* k; const char* v;
+    const char* out_proj; const char* ln1; const char* fc1; const char* fc2; const char* ln2;
+    const char* grep_linear; const char* grep_a;      // BEATs' gated relative position bias, or NULL
+};
+
+inline std::string fmt_name(const char* pattern, int i, const char* suffix) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), pattern, i);
+    return std::string(buf) + suffix;
+}
+
+struct CoreCfg {
+    int E = 0, F = 0, H = 0, L = 0;
+    float alpha = 1.f, eps = 1e-5f;
+    int hook_site = 0;            // 0: fc2's raw output, 1: the attention output projection's raw output
+    bool fast = false;            // residual stream / pre-LN sums in the operand type
+    bool fold = false;            // fast mode: the LayerNorms between the GEMMs folded into their epilogues
+};
+
+// upload layer i (and, with the fold, its LayerNorm-folded copies; layer i - 1 must have been built)
+inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, const CoreCfg& c, std::vector<Layer>& layers, int i) {
+    const int E = c.E, F = c.F, H = c.H;
+    Layer& ly = layers[i];
+    int rc;
+#define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
+    AVX_HIP_CHECK(hipMalloc(&ly.w_qkv, 2 * (size_t)3 * E * E));
+    h->allocs.push_back(ly.w_qkv);
+    AVX_HIP_CHECK(hipMalloc((void**)&ly.b_qkv, sizeof(float) * 3 * E));
+    h->allocs.push_back(ly.b_qkv);
+    std::vector<float> Wqkv, bqkv;          // host copies for the fold
+    if (nm.qkv_fused) {
+        RC(dev_half_into(h, tb, fmt_name(nm.qkv_fused, i, ".weight"), (int64_t)3 * E * E, ly.w_qkv));
+        RC(host_f32(h, tb, fmt_name(nm.qkv_fused, i, ".bias"), 3 * E, bqkv));
+        if (c.fold && i > 0) RC(host_f32(h, tb, fmt_name(nm.qkv_fused, i, ".weight"), (int64_t)3 * E * E, Wqkv));
+    } else {
+        const char* part[3] = {nm.q, nm.k, nm.v};
+        for (int j = 0; j < 3; ++j) {
+            RC(dev_half_into(h, tb, fmt_name(part[j], i, ".weight"), (int64_t)E * E, (char*)ly.w_qkv + 2 * (size_t)j * E * E));
+            RC(host_f32(h, tb, fmt_name(part[j], i, ".bias"), E, bqkv));
+            if (c.fold && i > 0) RC(host_f32(h, tb, fmt_name(part[j], i, ".weight"), (int64_t)E * E, Wqkv));
+        }
+    }
+    AVX_HIP_CHECK(hipMemcpy(ly.b_qkv, bqkv.data(), sizeof(float) * 3 * E, hipMemcpyHostToDevice));
+    RC(dev_half(h, tb, fmt_name(nm.out_proj, i, ".weight"), (int64_t)E * E, &ly.w_o));
+    RC(dev_f32(h, tb, fmt_name(nm.out_proj, i, ".bias"), E, &ly.b_o));
+    if (nm.grep_linear) {
+        RC(dev_f32(h, tb, fmt_name(nm.grep_linear, i, ".weight"), 8 * (E / H), &ly.grep_w));
+        RC(dev_f32(h, tb, fmt_name(nm.grep_linear, i, ".bias"), 8, &ly.grep_b));
+        RC(dev_f32(h, tb, fmt_name(nm.grep_a, i, ""), H, &ly.grep_a));
+    }
+    RC(dev_f32(h, tb, fmt_name(nm.ln1, i, ".weight"), E, &ly.ln1_w));
+    RC(dev_f32(h, tb, fmt_name(nm.ln1, i, ".bias"), E, &ly.ln1_b));
+    RC(dev_half(h, tb, fmt_name(nm.fc1, i, ".weight"), (int64_t)F * E, &ly.w_fc1));
+    RC(dev_f32(h, tb, fmt_name(nm.fc1, i, ".bias"), F, &ly.b_fc1));
+    RC(dev_half(h, tb, fmt_name(nm.fc2, i, ".weight"), (int64_t)E * F, &ly.w_fc2));
+    RC(dev_f32(h, tb, fmt_name(nm.fc2, i, ".bias"), E, &ly.b_fc2));
+    RC(dev_f32(h, tb, fmt_name(nm.ln2, i, ".weight"), E, &ly.ln2_w));
+    RC(dev_f32(h, tb, fmt_name(nm.ln2, i, ".bias"), E, &ly.ln2_b));
+    if (c.fold) {
+        auto two = [&](float** ga, float** bb) -> int {
+            AVX_HIP_CHECK(hipMalloc((void**)ga, sizeof(float) * 2 * (size_t)E));
+            h->allocs.push_back(*ga);
+            *bb = *ga + E;
+            return AVEXHIP_OK;
+        };
+        RC(two(&ly.ga_fc2, &ly.bb_fc2));
+        RC(avx::lnr_fold(ly.ln1_w, ly.ln1_b, ly.b_fc2, c.alpha, E, ly.ga_fc2, ly.bb_fc2, nullptr));
+        std::vector<float> Wh, bh;
+        RC(host_f32(h, tb, fmt_name(nm.fc1, i, ".weight"), (int64_t)F * E, Wh));
+        RC(host_f32(h, tb, fmt_name(nm.fc1, i, ".bias"), F, bh));
+        RC(fold_ln(h, Wh, bh, F, E, ly.ln1_w, ly.ln1_b, &ly.w_fc1_f, &ly.b_fc1_f, &ly.s_fc1));
+        if (i > 0) {   // QKV and out_proj of layer i read LN2 of layer i - 1
+            const Layer& prev = layers[i - 1];
+            RC(two(&ly.ga_o, &ly.bb_o));
+            RC(avx::lnr_fold(prev.ln2_w, prev.ln2_b, ly.b_o, c.alpha, E, ly.ga_o, ly.bb_o, nullptr));
+            RC(fold_ln(h, Wqkv, bqkv, 3 * E, E, prev.ln2_w, prev.ln2_b, &ly.w_qkv_f, &ly.b_qkv_f, &ly.s_qkv));
+        }
+    }
+#undef RC
+    return AVEXHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The layer loop's buffers inside a caller-provided workspace, and the loop itself
+// ---------------------------------------------------------------------------------------------
+struct CoreWs {
+    float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
+    float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
+    float* r1; float* r2;     // ... reduced to (rstd, -mu rstd) per row by avx::ln_rowstats
+};
+
+// `take(bytes)` hands out consecutive aligned pieces of the workspace (NULL base: sizes only)
+template <typename Take>
+inline CoreWs carve_core(const CoreCfg& c, size_t M, Take&& take) {
+    CoreWs w;
+    w.x = (float*)take(M * c.E * 4);
+    w.xh = (char*)take(M * c.E * 2);
+    w.pre = (float*)take(c.fast ? 256 : M * c.E * 4);
+    w.preh = (char*)take(c.fast ? M * c.E * 2 : 256);
+    w.qkv = (char*)take(M * 3 * c.E * 2);
+    w.ah = (char*)take(M * c.E * 2);
+    w.hh = (char*)take(M * c.F * 2);
+    w.raw = (float*)take(M * c.E * 4);
+    w.st1 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
+    w.st2 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
+    w.r1 = (float*)take(c.fold ? (M + 256) * 8 : 256);
+    w.r2 = (float*)take(c.fold ? (M + 256) * 8 : 256);
+    return w;
+}
+
+struct CoreIo {
+    int Bc = 0, Tt = 0;
+    size_t c0 = 0;                        // first clip of this chunk within the caller's batch (offset of the outputs)
+    const float* bias_tab = nullptr;      // [H, 2 Tt - 1] or NULL
+    const uint8_t* pad = nullptr;         // [Bc, Tt] key padding or NULL
+    uint32_t hook_mask = 0;               // bit (hook_bit0 + i) selects layer i
+    int hook_bit0 = 0;
+    float* const* hook_out = nullptr;     // indexed like the mask's bits
+    int hook_pooled = 0;
+    float* features_out = nullptr;        // caller's [B, Tt, E] or NULL
+    float* pooled_out = nullptr;          // caller's [B, E] (mean over the Tt tokens) or NULL
+    float* final_f32 = nullptr;           // out: where the fp32 features of this chunk were written (caller's buffer or w.x), NULL if nowhere
+};
+
+// x (the encoder input after its own LayerNorm) is in w.xh (fast) / w.x + w.xh (fp32 residual stream); runs the L layers and the outputs
+inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>& layers, const CoreWs& w, CoreIo& io, Prof& prof, hipStream_t cs) {
+    const int E = c.E, F = c.F, H = c.H, L = c.L, dt = h->dtype, Bc = io.Bc, Tt = io.Tt;
+    const int M = Bc * Tt;
+    const double Md = (double)M;
+    const bool fast = c.fast;
+    float* x32 = w.x;
+    float* pre32 = fast ? nullptr : w.pre;
+    void* preh = fast ? w.preh : nullptr;
+    int rc;
+#define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
+    // "fold": the two LayerNorms of a layer never run as kernels.  y1 = x*alpha + attn (preh) and y2 = x1*alpha + ffn (xh) stay raw
+    // in the operand type with per-row partial statistics from the epilogue that wrote them; fc1 / the next QKV read them
+    // through LayerNorm-folded weights, out_proj / fc2 apply LayerNorm to their residual on the fly (GemmArgs, gemm.hip).
+    const bool fold = fast && c.fold;      // any M: the same arithmetic whatever the chunking
+    const int nseg = E / 64;
+    avx::GemmArgs g;
+    io.final_f32 = nullptr;
+    for (int i = 0; i < L; ++i) {
+        const Layer& ly = layers[i];
+        const bool raw_in = fold && i > 0;      // xh holds y2 of layer i-1 (raw) instead of its LayerNorm
+        const bool hooked = (io.hook_mask >> (io.hook_bit0 + i)) & 1u;
+        float* tap = nullptr;
+        if (hooked) tap = io.hook_pooled ? w.raw : io.hook_out[io.hook_bit0 + i] + io.c0 * Tt * E;
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
+        g.out_half = w.qkv; g.ldh = 3 * E;
+        if (raw_in) { g.W = ly.w_qkv_f; g.bias = ly.b_qkv_f; g.ln_rows = w.r2; g.ln_s = ly.s_qkv; }
+        prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
+        RC(avx::attention(w.qkv, Bc, Tt, H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, dt, cs));
+        prof.end();
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = c.alpha;
+        if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
+        else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
+        if (fold) {
+            g.stats_out = w.st1;
+            if (raw_in) {
+                g.resid_half = nullptr; g.ldrh = 0;
+                g.lnr_y = w.xh; g.ldy = E; g.lnr_rows = w.r2; g.lnr_gamma = ly.ga_o; g.lnr_beta = ly.bb_o; g.lnr_prefolded = 1;
+            }
+        }
+        if (hooked && c.hook_site == 1) { g.out_raw = tap; g.ldraw = E; }
+        prof.begin("gemm.out_proj", 2.0 * Md * E * E);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        if (hooked && c.hook_site == 1 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        if (fold) {
+            prof.begin("ln_rowstats", 0.0);
+            RC(avx::ln_rowstats(w.st1, M, nseg, c.eps, w.r1, cs));
+            prof.end();
+        } else {
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, c.eps, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
+            prof.end();
+        }
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
+        g.out_half = w.hh; g.ldh = F;
+        if (fold) { g.A = preh; g.W = ly.w_fc1_f; g.bias = ly.b_fc1_f; g.ln_rows = w.r1; g.ln_s = ly.s_fc1; }
+        prof.begin("gemm.fc1", 2.0 * Md * F * E);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        const bool last = i == L - 1;
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
+        if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
+        else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
+        if (fold) {   // residual = LN1(y1) on the fly; y2 (raw) goes to xh, which nothing reads any more in this layer
+            g.resid_half = nullptr; g.ldrh = 0;
+            g.lnr_y = preh; g.ldy = E; g.lnr_rows = w.r1; g.lnr_gamma = ly.ga_fc2; g.lnr_beta = ly.bb_fc2; g.lnr_prefolded = 1;
+            g.out_half = w.xh; g.stats_out = !last ? w.st2 : nullptr;      // the last layer's y2 goes to a LayerNorm kernel that takes its own statistics
+        }
+        if (hooked && c.hook_site == 0) { g.out_raw = tap; g.ldraw = E; }
+        prof.begin("gemm.fc2", 2.0 * Md * E * F);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        if (hooked && c.hook_site == 0 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        if (fold && !last) {
+            prof.begin("ln_rowstats", 0.0);
+            RC(avx::ln_rowstats(w.st2, M, nseg, c.eps, w.r2, cs));
+            prof.end();
+        }
+        // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
+        float* xo = nullptr;
+        if (last) xo = io.features_out ? io.features_out + io.c0 * Tt * E : ((io.pooled_out || !fast) ? x32 : nullptr);
+        else if (!fast) xo = x32;
+        // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
+        const bool fused_pool = last && io.pooled_out && !io.features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
+        if (fused_pool) {      // the pre-LayerNorm sums y2 sit in preh, with the fold in xh
+            prof.begin("layernorm+mean_pool", 0.0);
+            RC(avx::layernorm_pool(fold ? w.xh : preh, E, ly.ln2_w, ly.ln2_b, c.eps, Bc, Tt, E, io.pooled_out + io.c0 * E, dt, cs));
+            prof.end();
+        } else if (!fold) {
+            prof.begin("layernorm", 0.0);
+            if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, c.eps, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
+            prof.end();
+        } else if (last && xo) {   // the only LayerNorm of the layer stack that still runs: fp32 features from the raw y2
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(nullptr, w.xh, E, ly.ln2_w, ly.ln2_b, c.eps, M, E, xo, E, nullptr, E, dt, cs));
+            prof.end();
+        }
+        if (last) io.final_f32 = xo;
+        if (last && io.pooled_out && !fused_pool) {
+            prof.begin("mean_pool", 0.0);
+            RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, io.pooled_out + io.c0 * E, cs));
+            prof.end();
+        }
+    }
+#undef RC
+    return AVEXHIP_OK;
+}
+
+}  // namespace avxh

@@ -18,9 +18,9 @@ BEATs path.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, Iterable, Mapping, Optional
 
-import numpy as np
 import torch
 
 from . import _capi
@@ -30,60 +30,51 @@ __all__ = ["EatEncoder"]
 
 
 class EatEncoder:
-    """``[B, T]`` fp32 waveforms (or a ``[B, 1024, 128]`` log-mel image) on the GPU -> ``[B, 513, 768]`` features / hook taps."""
+    """``[B, T]`` fp32 waveforms (or a ``[B, 1024, 128]`` log-mel image) on the GPU -> ``[B, 513, 768]`` features / hook taps.
+    A thin wrapper over the ``avexhip_eat`` handle (csrc/encoders.cpp): the library owns the weights, this class the output tensors
+    and the workspace."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype: str = "f16", prefix: str = "backbone.model.",
-                 norm_mean: float = -4.268, norm_std: float = 4.569) -> None:
+                 norm_mean: float = -4.268, norm_std: float = 4.569, max_chunk_clips: int = 0, residual: str = "half") -> None:
         _capi.require_gpu()
         self.cfg = dict(cfg)
         self.dtype = operand_dtype
         self.E = int(cfg["embed_dim"]); self.H = int(cfg["num_heads"]); self.L = int(cfg["depth"]); self.P = int(cfg["patch_size"])
         self.target_length = int(cfg["target_length"]); self.n_mels = int(cfg["n_mels"])
         self.eps = float(cfg.get("norm_eps", 1e-6))
-        if self.E != 64 * self.H:
-            raise K.AvexHipError("EAT: head_dim must be 64")
         if bool(cfg.get("layer_norm_first", False)):
             raise K.AvexHipError("EAT: layer_norm_first=True (pre-LN blocks) is not built")
-        if self.P != 16 or self.n_mels % 16 or self.target_length % 16:
-            raise K.AvexHipError("EAT: only 16 x 16 patches over a (16 a) x (16 b) image are built")
-        dev = torch.device("cuda", torch.cuda.current_device())
-
-        def f32(name: str) -> torch.Tensor:
-            v = state[prefix + name]
-            if isinstance(v, torch.Tensor):
-                return v.detach().to(device=dev, dtype=torch.float32).contiguous()
-            return torch.from_numpy(np.ascontiguousarray(np.asarray(v, np.float32))).to(dev)
-
-        half = lambda t: K.to_half(t.contiguous(), operand_dtype)
-        self.n_patches = (self.target_length // 16) * (self.n_mels // 16)
-        self.w_pe = half(f32("local_encoder.proj.weight").reshape(self.E, 256)); self.b_pe = f32("local_encoder.proj.bias")
-        self.cls = f32("extra_tokens").reshape(self.E)
-        pos = f32("fixed_positional_encoder.positions").reshape(-1, self.E)
-        if pos.shape[0] < self.n_patches:
-            raise K.AvexHipError(f"EAT: position table has {pos.shape[0]} rows, {self.n_patches} patches need one each")
-        self.pos = pos[: self.n_patches].contiguous()
-        self.pre_norm = (f32("pre_norm.weight"), f32("pre_norm.bias"))
-        self.layers = []
-        for i in range(self.L):
-            p = f"blocks.{i}."
-            self.layers.append(dict(
-                w_qkv=half(f32(p + "attn.qkv.weight")), b_qkv=f32(p + "attn.qkv.bias"),
-                w_o=half(f32(p + "attn.proj.weight")), b_o=f32(p + "attn.proj.bias"),
-                ln1=(f32(p + "norm1.weight"), f32(p + "norm1.bias")),
-                w1=half(f32(p + "mlp.fc1.weight")), b1=f32(p + "mlp.fc1.bias"),
-                w2=half(f32(p + "mlp.fc2.weight")), b2=f32(p + "mlp.fc2.bias"),
-                ln2=(f32(p + "norm2.weight"), f32(p + "norm2.bias"))))
-        win = 400
-        per_sample = norm_mean == 0.0 and norm_std == 1.0
-        if per_sample:
-            raise K.AvexHipError("EAT: per-sample normalisation (norm_mean 0, norm_std 1) is only built in EATAudioProcessor, not in the fused path")
-        self.plan = K.FbankPlan(win_length=win, hop_length=160, n_mels=self.n_mels, input_scale=1.0, preemph=0.97, remove_dc=True,
-                                log_floor=K.F32_EPS, norm_mean=float(norm_mean), norm_div=2.0 * float(norm_std), window=K.hann_window(win),
-                                mel_fb=K.kaldi_mel_filterbank(self.n_mels, 512, 16000.0, 20.0, 0.0))
+        self.n_patches = (self.target_length // 16) * (self.n_mels // 16) if self.P == 16 else 0
+        c = _capi.EatConfig()
+        c.embed_dim, c.num_heads, c.depth = self.E, self.H, self.L
+        c.ffn_dim = int(cfg.get("ffn_dim", int(float(cfg.get("mlp_ratio", 4.0)) * self.E)))
+        c.patch_size, c.target_length, c.n_mels = self.P, self.target_length, self.n_mels
+        c.norm_eps, c.norm_mean, c.norm_std = self.eps, float(norm_mean), float(norm_std)
+        c.operand_dtype = _capi.dtype_code(operand_dtype)
+        c.max_chunk_clips = int(max_chunk_clips)
+        c.residual_dtype = K.RESIDUAL_CODES[str(residual).lower()]
+        sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
+        arr, n, keep = K.tensor_table(sub)
+        self._h = _capi.lib().avexhip_eat_create(C.byref(c), arr, n)
+        del keep
+        if not self._h:
+            raise K.AvexHipError(f"eat_create failed: {_capi.last_error()}")
+        self._ws: Optional[torch.Tensor] = None
+        self._norm = (float(norm_mean), float(norm_std))
+        self._plan = None
 
     @property
     def num_tokens(self) -> int:
-        return self.n_patches + 1
+        return int(_capi.lib().avexhip_eat_num_tokens(self._h))
+
+    @property
+    def plan(self) -> "K.FbankPlan":
+        """The frontend as a stand-alone plan (the handle has its own copy): for callers that want the patch rows themselves."""
+        if self._plan is None:
+            self._plan = K.FbankPlan(win_length=400, hop_length=160, n_mels=self.n_mels, input_scale=1.0, preemph=0.97, remove_dc=True,
+                                     log_floor=K.F32_EPS, norm_mean=self._norm[0], norm_div=2.0 * self._norm[1], window=K.hann_window(400),
+                                     mel_fb=K.kaldi_mel_filterbank(self.n_mels, 512, 16000.0, 20.0, 0.0))
+        return self._plan
 
     def patches_from_wav(self, wav: torch.Tensor) -> torch.Tensor:
         return self.plan.patches(wav, out_frames=self.target_length, patch=16, remove_clip_mean=True, dtype=self.dtype)
@@ -97,45 +88,69 @@ class EatEncoder:
 
     @torch.no_grad()
     def forward(self, wav: Optional[torch.Tensor] = None, *, spec: Optional[torch.Tensor] = None, hook_layers: Iterable[int] = (),
-                want_features: bool = True, pooling: Optional[str] = None) -> Dict[str, object]:
-        """``hook_layers``: block indices whose ``attn.proj`` output is returned (fp32 ``[B, 513, 768]``); ``pooling``: ``"cls"`` /
-        ``"mean"`` adds ``out["pooled"]`` ``[B, 768]`` (eat_hf.py:283-288)."""
+                want_features: bool = True, pooling: Optional[str] = None, hook_pooled: bool = False) -> Dict[str, object]:
+        """``hook_layers``: block indices whose ``attn.proj`` output is returned (fp32 ``[B, 513, 768]``, or ``[B, 768]`` token means with
+        ``hook_pooled``); ``pooling``: ``"cls"`` / ``"mean"`` adds ``out["pooled"]`` ``[B, 768]`` (eat_hf.py:283-288)."""
         if (wav is None) == (spec is None):
             raise ValueError("give exactly one of wav / spec")
+        if pooling not in (None, "cls", "mean"):
+            raise ValueError("pooling must be 'cls' or 'mean'")
         if wav is not None:
             if wav.dim() != 2 or wav.dtype != torch.float32 or not wav.is_cuda:
                 raise ValueError("wav must be a [B, T] float32 CUDA tensor")
-            B = wav.shape[0]
-            patches = self.patches_from_wav(wav.contiguous())
+            if wav.stride(1) != 1:
+                wav = wav.contiguous()
+            B, T, dev = wav.shape[0], wav.shape[1], wav.device
         else:
             if spec.dim() != 3 or tuple(spec.shape[1:]) != (self.target_length, self.n_mels) or not spec.is_cuda:
                 raise ValueError(f"spec must be a [B, {self.target_length}, {self.n_mels}] CUDA tensor")
-            B = spec.shape[0]
-            patches = self.patches_from_spec(spec.float())
-        hooks = set(int(i) for i in hook_layers)
+            spec = spec.float().contiguous()
+            B, T, dev = spec.shape[0], 0, spec.device
         E, Tt = self.E, self.num_tokens
-        pe = K.gemm(patches, self.w_pe, bias=self.b_pe, out_f32=False, out_half=True)["half"]
-        x, _ = K.token_embed_ln(pe, self.pos, self.cls, *self.pre_norm, self.eps, B)
-        out: Dict[str, object] = {"hooks": {}}
-        x32 = None
-        for i, ly in enumerate(self.layers):
-            qkv = K.gemm(x, ly["w_qkv"], bias=ly["b_qkv"], out_f32=False, out_half=True)["half"]
-            a = K.attention(qkv, B, Tt, self.H, None, None, None, None)
-            r = K.gemm(a, ly["w_o"], bias=ly["b_o"], resid_half=x, alpha=1.0, out_f32=False, out_half=True, out_raw=i in hooks)
-            if i in hooks:
-                out["hooks"][i] = r["raw"].view(B, Tt, E)
-            _, x = K.layernorm(r["half"], *ly["ln1"], eps=self.eps, want_f32=False)
-            hdn = K.gemm(x, ly["w1"], bias=ly["b1"], gelu=True, out_f32=False, out_half=True)["half"]
-            y = K.gemm(hdn, ly["w2"], bias=ly["b2"], resid_half=x, alpha=1.0, out_f32=False, out_half=True)["half"]
-            last = i == self.L - 1
-            x32, x = K.layernorm(y, *ly["ln2"], eps=self.eps, want_f32=last, want_half=not last)
-        feats = x32.view(B, Tt, E)
+        need = int(_capi.lib().avexhip_eat_workspace_bytes(self._h, B))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        hooks: Dict[int, torch.Tensor] = {}
+        ptrs = (C.c_void_p * max(self.L, 1))()
+        mask = 0
+        for i in sorted(set(int(x) for x in hook_layers)):
+            if not 0 <= i < self.L:
+                raise ValueError(f"hook layer {i} out of range 0..{self.L - 1}")
+            hooks[i] = torch.empty((B, E) if hook_pooled else (B, Tt, E), dtype=torch.float32, device=dev)
+            ptrs[i] = int(hooks[i].data_ptr())
+            mask |= 1 << i
+        feats = torch.empty((B, Tt, E), dtype=torch.float32, device=dev) if want_features else None
+        pooled = torch.empty((B, E), dtype=torch.float32, device=dev) if pooling else None
+        _capi.check(_capi.lib().avexhip_eat_forward(self._h, K._ptr(wav), B, T, wav.stride(0) if wav is not None else 0, K._ptr(spec), mask, ptrs,
+                                                    int(hook_pooled), K._ptr(feats), K._ptr(pooled), {None: 0, "cls": 1, "mean": 2}[pooling],
+                                                    K._ptr(self._ws), self._ws.numel(), K._stream()), "eat_forward")
+        out: Dict[str, object] = {"hooks": hooks}
         if want_features:
             out["features"] = feats
-        if pooling == "cls":
-            out["pooled"] = feats[:, 0].contiguous()
-        elif pooling == "mean":
-            out["pooled"] = K.mean_pool(feats)
-        elif pooling is not None:
-            raise ValueError("pooling must be 'cls' or 'mean'")
+        if pooling:
+            out["pooled"] = pooled
         return out
+
+    def overflow_events(self, sync: bool = True) -> int:
+        n = C.c_uint32(0)
+        _capi.check(_capi.lib().avexhip_eat_overflow_count(self._h, C.byref(n), K._stream(), int(bool(sync))), "eat_overflow_count")
+        return int(n.value)
+
+    def set_profiling(self, enabled: bool) -> None:
+        _capi.check(_capi.lib().avexhip_eat_set_profiling(self._h, int(enabled)), "eat_set_profiling")
+
+    def last_profile(self):
+        return K.handle_profile(_capi.lib().avexhip_eat_last_profile, self._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _capi.lib().avexhip_eat_destroy(self._h)
+            self._h = None
+        self._ws = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -270,25 +270,7 @@ def extract_embeddings_streaming(model: Any, dataloader: Any, target_layers: Lis
 
             it = iter(dataloader)
             nxt = next(it, None)
-            gathers: Dict[int, Any] = {}                        # position in the output list -> PipelinedGather
-
-            def my_rows(b: Dict[str, Any]) -> Optional[Tuple[int, int]]:
-                return adist.shard_bounds(int(b["raw_wav"].shape[0]), rank, world) if sharded else None
-
-            def exchange(parts: List[Tuple[str, torch.Tensor]], n_total: int) -> List[Tuple[str, torch.Tensor]]:
-                """Sharded run: start this batch's all-gathers, hand back the PREVIOUS batch's finished ones (clip order)."""
-                done = []
-                for i, (name, t) in enumerate(parts):
-                    if i not in gathers:
-                        gathers[i] = [adist.PipelinedGather(group), None]
-                    pg = gathers[i]
-                    prev = pg[0].push(t, n_total)
-                    if prev is not None:       # (a host tensor aliases the gather's buffer, which the push after next overwrites)
-                        done.append((pg[1], prev if prev.is_cuda else prev.clone()))
-                    pg[1] = name
-                return done
-
-            staged = _stage(nxt, device, copy_stream, my_rows(nxt)) if nxt is not None else None
+            staged = _stage(nxt, device, copy_stream) if nxt is not None else None
             while nxt is not None:
                 batch, (wav, mask, ready) = nxt, staged
                 nxt = next(it, None)

@@ -584,6 +584,38 @@ def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_
     return c
 
 
+def tensor_table(state: Mapping[str, object]):
+    """A state dict (torch tensors or numpy arrays, host or device) as the ``avexhip_tensor`` table the ``*_create`` entry points take:
+    ``(array, count, keep_alive)``; the library copies every tensor during the call, ``keep_alive`` must live until it returns."""
+    keep = []
+    entries = []
+    for name, val in state.items():
+        if isinstance(val, torch.Tensor):
+            t = val.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            entries.append((name.encode(), int(t.data_ptr()), t.numel()))
+        else:
+            a = np.ascontiguousarray(val, np.float32)
+            keep.append(a)
+            entries.append((name.encode(), int(a.ctypes.data), a.size))
+    arr = (Tensor * len(entries))()
+    for i, (n, p, k) in enumerate(entries):
+        arr[i].name, arr[i].data, arr[i].numel = n, p, k
+    return arr, len(entries), keep
+
+
+def handle_profile(fn, h) -> List[Tuple[str, float, float]]:
+    """``*_last_profile`` of an encoder handle as ``[(stage, ms, flops)]``."""
+    names = C.POINTER(C.c_char_p)()
+    ms = C.POINTER(C.c_float)()
+    fl = C.POINTER(C.c_double)()
+    n = C.c_int(0)
+    check(fn(h, C.byref(names), C.byref(ms), C.byref(fl), C.byref(n)), "last_profile")
+    return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
+
+
 class BeatsEncoder:
     """Owns an ``avexhip_beats`` handle built from an fp32 state dict (torch tensors or numpy arrays,
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
@@ -607,23 +639,8 @@ class BeatsEncoder:
         self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual)
         self.E = int(cfg["encoder_embed_dim"])
         self.L = int(cfg["encoder_layers"])
-        keep = []  # keep arrays alive during the call
-        entries = []
-        for name, val in state.items():
-            if isinstance(val, torch.Tensor):
-                t = val.detach()
-                if t.dtype != torch.float32 or not t.is_contiguous():
-                    t = t.float().contiguous()
-                keep.append(t)
-                entries.append((name.encode(), int(t.data_ptr()), t.numel()))
-            else:
-                a = np.ascontiguousarray(val, np.float32)
-                keep.append(a)
-                entries.append((name.encode(), int(a.ctypes.data), a.size))
-        arr = (Tensor * len(entries))()
-        for i, (n, p, k) in enumerate(entries):
-            arr[i].name, arr[i].data, arr[i].numel = n, p, k
-        self._h = lib().avexhip_beats_create(C.byref(self.ccfg), arr, len(entries))
+        arr, n, keep = tensor_table(state)
+        self._h = lib().avexhip_beats_create(C.byref(self.ccfg), arr, n)
         del keep
         if not self._h:
             raise AvexHipError(f"beats_create failed: {_capi.last_error()}")

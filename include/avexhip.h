@@ -376,6 +376,82 @@ int avexhip_beats_set_profiling(avexhip_beats* h, int enabled);
 int avexhip_beats_last_profile(const avexhip_beats* h, const char* const** names, const float** ms,
                                const double** flops, int* count);
 
+/* ------------------------------------------------------------------------------------------
+ * EAT encoder handle: what EATHFModel.forward does per batch (avex/models/eat_hf.py:241-289) --
+ * EATAudioProcessor's kaldi fbank image (avex/models/eat/audio_processor.py:72-143) and the HF remote Data2Vec-multi image
+ * encoder (backbone.extract_features): 16 x 16 patch rows -> local_encoder -> class token + fixed positions + pre_norm ->
+ * `depth` post-LN blocks -> features [B, n_patches + 1, embed_dim].  Same contract as the BEATs handle: the weight table is
+ * copied at creation (keys as in the reference's state dict, with or without the "backbone." / "backbone.model." prefixes:
+ * local_encoder.proj.*, extra_tokens, fixed_positional_encoder.positions, pre_norm.*, blocks.{i}.attn.qkv / attn.proj / norm1 /
+ * mlp.fc1 / mlp.fc2 / norm2), the caller owns every buffer and the stream, nothing synchronises.
+ * PARITY UNPINNED: the remote model code is absent from the reference tree; checker oracle/eat_oracle.py.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_eat avexhip_eat;
+typedef struct {
+    int32_t embed_dim;        /* 768 */
+    int32_t num_heads;        /* 12 (head_dim 64) */
+    int32_t depth;            /* 12 */
+    int32_t ffn_dim;          /* 3072 */
+    int32_t patch_size;       /* 16 */
+    int32_t target_length;    /* 1024 frames (eat_hf.py:150) */
+    int32_t n_mels;           /* 128 */
+    float   norm_eps;         /* 1e-6 */
+    float   norm_mean;        /* -4.268: the image is (logmel - norm_mean) / (2 norm_std) (audio_processor.py:137) */
+    float   norm_std;         /* 4.569 */
+    int32_t operand_dtype;    /* AVEXHIP_F16 / AVEXHIP_BF16 */
+    int32_t max_chunk_clips;  /* 0 = 256 */
+    int32_t residual_dtype;   /* 0 = fp32 residual stream, 1 = operand type (LayerNorms folded into the GEMMs) */
+} avexhip_eat_config;
+avexhip_eat* avexhip_eat_create(const avexhip_eat_config* cfg, const avexhip_tensor* tensors, int n_tensors);
+void avexhip_eat_destroy(avexhip_eat* h);
+int avexhip_eat_num_tokens(const avexhip_eat* h);                  /* n_patches + 1 (513) */
+size_t avexhip_eat_workspace_bytes(const avexhip_eat* h, int B);
+/* Exactly one of wav_dev ([B, T] fp32, row stride wav_stride) / spec_dev ([B, target_length, n_mels] fp32, an EATAudioProcessor image).
+ * hook_mask bit i selects blocks.{i}.attn.proj's raw output (eat_hf.py:220-236) -> hook_out[i] ([B, tokens, E], or [B, E] token
+ * means when hook_pooled).  features_out [B, tokens, E] (the last norm2) and / or pooled_out [B, E] with pooling 1 = class token,
+ * 2 = mean over the tokens (eat_hf.py:283-288); pooling 0 <=> pooled_out NULL. */
+int avexhip_eat_forward(avexhip_eat* h, const float* wav_dev, int B, int64_t T, int64_t wav_stride, const float* spec_dev,
+                        uint32_t hook_mask, float* const* hook_out, int hook_pooled, float* features_out, float* pooled_out,
+                        int pooling, void* workspace, size_t workspace_bytes, void* stream);
+int avexhip_eat_overflow_count(avexhip_eat* h, uint32_t* events, void* sync_stream, int synchronize);
+int avexhip_eat_set_profiling(avexhip_eat* h, int enabled);
+int avexhip_eat_last_profile(const avexhip_eat* h, const char* const** names, const float** ms, const double** flops, int* count);
+
+/* ------------------------------------------------------------------------------------------
+ * AVES encoder handle: aves_model.Model.forward (avex/models/aves_model.py:128-151) = torchaudio wav2vec2_model(...)
+ * .extract_features(x)[0][-1]: convolutional feature extractor (conv_kernel / conv_stride per layer, 512 channels, layer 0
+ * with GroupNorm), LayerNorm(512) -> Linear(512, E), weight-normed positional conv, `num_layers` post-LN layers ->
+ * features [B, T', E].  Weight table keys as torchaudio names them (with or without the "model." prefix).
+ * PARITY UNPINNED: torchaudio is absent from the reference tree; checker oracle/aves_oracle.py.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_aves avexhip_aves;
+typedef struct {
+    int32_t embed_dim;        /* 768 */
+    int32_t num_heads;        /* 12 */
+    int32_t num_layers;       /* 12 */
+    int32_t ffn_dim;          /* 3072 */
+    int32_t pos_conv_kernel;  /* 128 */
+    int32_t pos_conv_groups;  /* 16 */
+    int32_t n_conv_layers;    /* 7 */
+    int32_t conv_kernel[8];   /* 10, 3, 3, 3, 3, 2, 2 (aves_model.py:25-33) */
+    int32_t conv_stride[8];   /* 5, 2, 2, 2, 2, 2, 2 */
+    int32_t operand_dtype;
+    int32_t max_chunk_clips;  /* 0 = 64 (layer 0 of the extractor holds 32 MB per 10 s clip) */
+    int32_t residual_dtype;
+} avexhip_aves_config;
+avexhip_aves* avexhip_aves_create(const avexhip_aves_config* cfg, const avexhip_tensor* tensors, int n_tensors);
+void avexhip_aves_destroy(avexhip_aves* h);
+int avexhip_aves_num_tokens(const avexhip_aves* h, int64_t T);     /* frames of the last conv layer for T samples, 0 if too short */
+size_t avexhip_aves_workspace_bytes(const avexhip_aves* h, int B, int64_t T);
+/* hook_mask bit i selects encoder.transformer.layers.{i}.feed_forward.output_dense's raw output (aves_model.py:100-126);
+ * frame_pad optional [B, T'] uint8 (1 = padded frame: masked as a key); pooled_out = mean over the T' frames. */
+int avexhip_aves_forward(avexhip_aves* h, const float* wav_dev, int B, int64_t T, int64_t wav_stride, const uint8_t* frame_pad,
+                         uint32_t hook_mask, float* const* hook_out, int hook_pooled, float* features_out, float* pooled_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int avexhip_aves_overflow_count(avexhip_aves* h, uint32_t* events, void* sync_stream, int synchronize);
+int avexhip_aves_set_profiling(avexhip_aves* h, int enabled);
+int avexhip_aves_last_profile(const avexhip_aves* h, const char* const** names, const float** ms, const double** flops, int* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,9 +41,11 @@ def test_fbank_patches_match_frontend(built_lib):
     assert np.abs(got.reshape(3, 512, 256) - ref).max() < 2e-3                     # f16 rounding of values in [-2.5, 2.5]
 
 
-@pytest.mark.parametrize("dtype,tol", [("f16", 1.5e-3), ("bf16", 1.2e-2)])
-def test_eat_encoder_matches_oracle(built_lib, dtype, tol):
-    """EAT-base, all 12 blocks, 513 tokens (two query blocks / three key blocks in the attention), 2 clips of 5 s."""
+@pytest.mark.parametrize("dtype,tol,ftol", [("f16", 1.0e-3, 2.0e-3), ("bf16", 6.0e-3, 1.5e-2)])
+def test_eat_encoder_matches_oracle(built_lib, dtype, tol, ftol):
+    """EAT-base, all 12 blocks, 513 tokens (two query blocks / three key blocks in the attention), 2 clips of 5 s.
+    Measured (profiles/r03_parity.json): f16 pooled 4.7e-4, class token 1.1e-3, frame level 1.2e-3, taps 5.9e-4; bf16 3.8e-3 / 9.2e-3 /
+    9.3e-3 / 4.5e-3.  The pooled bar is north_star's 1e-3 (f16); ``ftol`` is the un-averaged (class token, frame level) bar."""
     from avex_amd.eat_encoder import EatEncoder
     cfg = synth.EAT_BASE_CFG
     sd = synth.eat_state_dict(cfg)
@@ -54,8 +56,8 @@ def test_eat_encoder_matches_oracle(built_lib, dtype, tol):
     f = r["features"].cpu().numpy()
     assert f.shape == ref.shape == (2, 513, 768)
     assert rel_l2(f.mean(1), ref.mean(1)) < tol                                    # pooled embedding
-    assert rel_l2(f[:, 0], ref[:, 0]) < 4 * tol                                    # CLS token (no averaging)
-    assert rel_l2(f, ref) < 4 * tol
+    assert rel_l2(f[:, 0], ref[:, 0]) < ftol                                       # CLS token (no averaging)
+    assert rel_l2(f, ref) < ftol
     for i in (0, 5, 11):
         t = taps[f"backbone.model.blocks.{i}.attn.proj"]
         assert rel_l2(r["hooks"][i].cpu().numpy().mean(1), t.mean(1)) < 2 * tol
@@ -63,7 +65,7 @@ def test_eat_encoder_matches_oracle(built_lib, dtype, tol):
     # the same image handed over as a spectrogram gives the same answer as the fused frontend (f16 patches either way)
     spec = torch.from_numpy(O.eat_preprocess(wav)).cuda()
     r2 = enc.forward(spec=spec, pooling="cls")
-    assert rel_l2(r2["features"].cpu().numpy(), f) < max(2e-3, tol)         # two roundings of the same image to the operand type
+    assert rel_l2(r2["features"].cpu().numpy(), f) < max(2e-3, ftol)        # two roundings of the same image to the operand type
     assert torch.equal(r2["pooled"], r2["features"][:, 0])
 
 
