@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             if (LNA && wid == 1) __builtin_amdgcn_global_load_lds((gptr_t*)(p.ln_s + n0b + lane * 4), (lptr_t*)(ldslns + par * 256), 16, 0, 0);
             if (LNA && (wid == 2 || wid == 3)) {
                 int r = m0b + 128 * (wid - 2) + 2 * lane;                 // two rows (16 bytes) per lane
-                const int last = (p.M - 2) & ~1;                           // rows past M are never stored: any valid, aligned address will do
+                const int last = (p.M - 1) & ~1;                           // the pair that holds row M - 1 (ln_rows is readable up to M rounded up to even); rows past M are never stored
                 r = r < last ? r : last;
                 __builtin_amdgcn_global_load_lds((gptr_t*)(p.ln_rows + 2 * (int64_t)r), (lptr_t*)(ldsrows + par * 512 + (wid - 2) * 256), 16, 0, 0);
             }

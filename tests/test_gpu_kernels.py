@@ -138,8 +138,8 @@ def test_gemm_persistent_walk_and_epilogues_agree(built_lib, dtype, shape, monke
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M", [700, 1536])
-def test_gemm_folded_layernorm(built_lib, dtype, M):
+@pytest.mark.parametrize("M", [700, 1536, 1539])
+def test_gemm_folded_layernorm(built_lib, dtype, M, monkeypatch):
     """LayerNorm folded into the GEMMs around it (include/avexhip.h, avexhip_gemm_args): the producer writes raw rows y and
     per-segment statistics; a consumer takes LN(y) as its A operand through folded weights (W diag(gamma), bias + W beta,
     column sums); another takes LN(y) as its residual.  Checked against the explicit two-pass fp32 LayerNorm of the same
@@ -180,6 +180,12 @@ def test_gemm_folded_layernorm(built_lib, dtype, M):
         if gelu:
             ref1 = O.gelu_erf(ref1.astype(np.float32))
         assert rel_l2(r1["half"].float().cpu().numpy(), ref1) < (6e-4 if dtype == "f16" else 5e-3)
+        # the fast epilogue (row pairs by LDS-DMA, two rows per lane: an odd M ends in half a pair) against the generic one (plain loads)
+        monkeypatch.setenv("AVEX_AMD_GEMM_GENERIC", "1")
+        r1x = K.gemm(r["half"], _dev(w1f, td), bias=_dev(b1f), gelu=gelu, out_f32=False, out_half=True, ln_rows=rows, ln_s=_dev(s1))
+        monkeypatch.delenv("AVEX_AMD_GEMM_GENERIC")
+        assert torch.equal(r1x["half"], r1["half"])
+        assert rel_l2(r1["half"][-1].float().cpu().numpy(), ref1[-1]) < (2e-3 if dtype == "f16" else 1.5e-2)       # the last row on its own
         # and it agrees with the unfused formulation up to the rounding of the folded weights
         ref_unf = ln @ w1.astype(np.float64).T + b1
         if gelu:
