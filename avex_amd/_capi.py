@@ -68,6 +68,11 @@ class AvesConfig(C.Structure):
                 ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32), ("residual_dtype", C.c_int32)]
 
 
+class EffnetConfig(C.Structure):
+    _fields_ = [("n_stages", C.c_int32), ("stage", (C.c_int32 * 6) * 8), ("stem_channels", C.c_int32), ("head_channels", C.c_int32),
+                ("bn_eps", C.c_float), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32)]
+
+
 class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
 
@@ -149,6 +154,16 @@ SYMBOLS = {
     "avexhip_aves_set_profiling": (C.c_int, [_P, C.c_int]),
     "avexhip_aves_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_double)),
                                             C.POINTER(C.c_int)]),
+    "avexhip_effnet_create": (_P, [C.POINTER(EffnetConfig), C.POINTER(Tensor), C.c_int]),
+    "avexhip_effnet_destroy": (None, [_P]),
+    "avexhip_effnet_num_taps": (C.c_int, [_P]),
+    "avexhip_effnet_tap_shape": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "avexhip_effnet_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
+    "avexhip_effnet_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(_P), _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_effnet_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
+    "avexhip_effnet_set_profiling": (C.c_int, [_P, C.c_int]),
+    "avexhip_effnet_last_profile": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_double)),
+                                              C.POINTER(C.c_int)]),
 }
 
 # exported by the diagnostic build only (-DAVEX_DIAG; AVEX_AMD_DIAG=1 python -m avex_amd.build, then AVEX_AMD_LIB=.../libavexhip_diag.so)

@@ -319,6 +319,9 @@ static __device__ __forceinline__ void a2_dma16(const void* src, const char* lds
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
 }
 
+#ifndef ATT_BIAS_REUSE
+#define ATT_BIAS_REUSE 1      // 0: A/B build, each query tile reads its bias vectors from LDS (round 2's form; tiles 256 rows apart)
+#endif
 template <typename T, bool LONG, bool BIAS>      // BIAS false: no relative-position table (EAT, wav2vec2): the S accumulators start at -m alone
 __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block, int nqb_main,
                                                         const float* __restrict__ bias_tab,
@@ -355,10 +358,10 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     auto set_qblock = [&](int qb) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-            qi[u] = qb * 512 + (NQ * wave + u) * 32 + r32;   // ADJACENT tiles: tile 1's bias values at key tile k are tile 0's at key tile k - 1 (below)
+            qi[u] = qb * 512 + (ATT_BIAS_REUSE ? (NQ * wave + u) : (wave + NW * u)) * 32 + r32;   // ADJACENT tiles: tile 1's bias values at key tile k are tile 0's at key tile k - 1 (below)
             iq[u] = qi[u] < Tn ? qi[u] : Tn - 1;         // clamped for loads; stores are masked
         }
-        has_q = qb * 512 + NQ * wave * 32 < Tn;
+        has_q = qb * 512 + (ATT_BIAS_REUSE ? NQ * wave : wave) * 32 < Tn;
     };
     set_qblock(0);
 
@@ -771,13 +774,19 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                     if (ktl + 1 < 8) { acc_start(0, 2, t4n[2]); acc_start(0, 3, t4n[3]); }
                     AVX_FENCE();
                     o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
+                    if (!ATT_BIAS_REUSE && ktl + 1 < 8) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) tcur[g4] = *(const f32x4*)(tp[1] + (ktl + 1) * 32 + 8 * g4);      // A/B build: tile 1's values from LDS as before
+                    }
                     if (ktl + 1 < 8) { acc_start(1, 0, tcur[0]); acc_start(1, 1, tcur[1]); }       // tile 1 at key tile k + 1 = tile 0's values at key tile k
                     AVX_FENCE();
                     o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
                     if (ktl + 1 < 8) {
                         acc_start(1, 2, tcur[2]); acc_start(1, 3, tcur[3]);
+                        if (ATT_BIAS_REUSE) {
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) tcur[g4] = t4n[g4];
+                            for (int g4 = 0; g4 < 4; ++g4) tcur[g4] = t4n[g4];
+                        }
                     }
                     AVX_FENCE();
                 } else {

@@ -261,6 +261,8 @@ struct GemmArgs {
     int nt;                   // set by the launcher: bit 0 non-temporal output stores (256-tile kernels)
 };
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
+// fp32 NHWC rows [B * HW, ld] -> NCHW [B, C, HW], optionally undoing a folded BatchNorm: (x - shift[c]) / scale[c] (effnet.hip)
+int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s);
 // partial statistics [M][nseg][2] (GemmArgs::stats_out) -> [M][2] (rstd, -mu * rstd), summed in segment order (deterministic)
 int ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, hipStream_t s);
 // ga = alpha * gamma, bb = bias + alpha * beta: the column vectors a residual-side fold takes (GemmArgs::lnr_prefolded)

@@ -247,3 +247,40 @@ extern "C" int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
+
+// fp32 rows [B * HW, ld] (NHWC, the layout every kernel of the stack works in) -> [B, C, HW] (the reference's NCHW), optionally undoing a
+// folded BatchNorm on the way: out = (in - shift[c]) / scale[c].  A hook tap of the reference is the convolution's output BEFORE its
+// BatchNorm (efficientnet.py:82-114: model.features.0.0, *.block.3.0, model.features.8.0), while the GEMM / stem epilogues hold
+// conv * scale + shift.  32 x 32 tiles through LDS: coalesced on both sides.
+namespace {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int64_t ld, int HW, int C, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (p < HW && c < C) {
+            v = in[((int64_t)b * HW + p) * ld + c];
+            if (scale) v = (v - shift[c]) / scale[c];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) out[((int64_t)b * C + c) * HW + p] = tile[tx][r];
+    }
+}
+}  // namespace
+
+namespace avx {
+int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s) {
+    AVX_REQUIRE(in && out && B > 0 && HW > 0 && C > 0 && ld >= C && B <= 65535, "nhwc_to_nchw: bad arguments");
+    AVX_REQUIRE((scale == nullptr) == (shift == nullptr), "nhwc_to_nchw: scale and shift come together");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, in, ld, HW, C, scale, shift, out);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+}  // namespace avx

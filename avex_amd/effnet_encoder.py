@@ -16,6 +16,7 @@ PARITY UNPINNED: torchvision is third-party, absent from the reference tree and 
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -28,125 +29,104 @@ from .synth import EFFNET_B0_STAGES
 __all__ = ["EfficientNetB0Encoder"]
 
 
-def _pad128(c: int) -> int:
-    return ((c + 127) // 128) * 128
-
-
 class EfficientNetB0Encoder:
-    """``[B, n_mels, frames]`` fp32 mel images on the GPU -> ``features [B, 1280, H', W']`` (and the reference's hook taps)."""
+    """``[B, n_mels, frames]`` fp32 mel images on the GPU -> ``features [B, 1280, H', W']`` (and the reference's hook taps).
+    A thin wrapper over the ``avexhip_effnet`` handle (csrc/effnet_handle.cpp): the library owns the (BatchNorm-folded) weights, this
+    class the output tensors and the workspace."""
 
     def __init__(self, state: Mapping[str, np.ndarray], operand_dtype: str = "f16", prefix: str = "model.", stages: Sequence = EFFNET_B0_STAGES,
-                 bn_eps: float = 1e-5) -> None:
+                 bn_eps: float = 1e-5, max_chunk_clips: int = 0) -> None:
         _capi.require_gpu()
         self.dtype = operand_dtype
         self.stages = [tuple(int(v) for v in s) for s in stages]
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.dev = dev
-        get = lambda n: np.asarray(state[prefix + n], np.float32)
-
-        def bnfold(name):
-            sc = get(name + ".weight") / np.sqrt(get(name + ".running_var") + np.float32(bn_eps))
-            return sc.astype(np.float32), (get(name + ".bias") - get(name + ".running_mean") * sc).astype(np.float32)
-
-        def t32(a):
-            return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(dev)
-
-        def pw(conv, bn, kp=None):                # 1x1 conv + BN -> ([Np, Kp] half weight, [Np] fp32 bias, scale, shift)
-            w = get(conv + ".weight")[:, :, 0, 0]
-            sc, sh = bnfold(bn)
-            N, Kd = w.shape
-            wp = np.zeros((_pad128(N), kp or _pad128(Kd)), np.float32)      # Kp = channel padding of the activation it reads
-            wp[:N, :Kd] = w * sc[:, None]
-            bp = np.zeros((_pad128(N),), np.float32); bp[:N] = sh
-            return K.to_half(t32(wp), operand_dtype), t32(bp), sc, sh
-
-        # stem: channel-summed (the three input channels are copies), BN-folded, [9, Cp]
-        w0 = get("features.0.0.weight").sum(axis=1)                                      # [32, 3, 3]
-        sc, sh = bnfold("features.0.1")
-        c0 = w0.shape[0]
-        # GEMM outputs need a channel count that is a multiple of 128 (N), GEMM inputs only a multiple of 64 (K): the stem and
-        # the depthwise layer behind it (the highest-resolution tensors of the network) carry 64 channels, not 128
-        cp = ((c0 + 63) // 64) * 64
-        ws = np.zeros((9, cp), np.float32); ws[:, :c0] = (w0 * sc[:, None, None]).reshape(c0, 9).T
-        bs = np.zeros((cp,), np.float32); bs[:c0] = sh
-        self.stem = (t32(ws), t32(bs), c0, sc, sh)
-        self.blocks = []
-        for si, (er, k, s, cin, cout, n) in enumerate(self.stages, start=1):
-            for j in range(n):
-                ci = cin if j == 0 else cout
-                ce = ci * er
-                p = f"features.{si}.{j}.block."
-                d = 1 if er != 1 else 0
-                blk = dict(name=prefix + p, k=k, stride=s if j == 0 else 1, cin=ci, cexp=ce, cout=cout, tap=(d == 1))
-                if d:
-                    blk["expand"] = pw(p + "0.0", p + "0.1", kp=cp)[:2]
-                    cp = _pad128(ce)
-                wd = get(p + f"{d}.0.weight")[:, 0]                                      # [ce, k, k]
-                scd, shd = bnfold(p + f"{d}.1")
-                wdp = np.zeros((k * k, cp), np.float32); wdp[:, :ce] = (wd * scd[:, None, None]).reshape(ce, k * k).T
-                bdp = np.zeros((cp,), np.float32); bdp[:ce] = shd
-                blk["dw"] = (t32(wdp), t32(bdp))
-                blk["se"] = (t32(get(p + f"{d + 1}.fc1.weight")[:, :, 0, 0]), t32(get(p + f"{d + 1}.fc1.bias")),
-                             t32(get(p + f"{d + 1}.fc2.weight")[:, :, 0, 0]), t32(get(p + f"{d + 1}.fc2.bias")))
-                wp_, bp_, scp, shp = pw(p + f"{d + 2}.0", p + f"{d + 2}.1", kp=cp)
-                cp = _pad128(cout)
-                blk["project"] = (wp_, bp_)
-                blk["project_bn"] = (t32(scp), t32(shp))
-                self.blocks.append(blk)
-        last = len(self.stages) + 1
-        wh, bh, sch, shh = pw(f"features.{last}.0", f"features.{last}.1", kp=cp)
-        self.head = (wh, bh, t32(sch), t32(shh), int(sch.shape[0]))
-        self.head_name = prefix + f"features.{last}.0"
-        self.stem_name = prefix + "features.0.0"
+        if len(self.stages) > 8:
+            raise K.AvexHipError("EfficientNet: at most 8 stages")
+        c = _capi.EffnetConfig()
+        c.n_stages = len(self.stages)
+        for i, st in enumerate(self.stages):
+            for j in range(6):
+                c.stage[i][j] = st[j]
+        c.stem_channels, c.head_channels, c.bn_eps = 32, 1280, float(bn_eps)
+        c.operand_dtype, c.max_chunk_clips = _capi.dtype_code(operand_dtype), int(max_chunk_clips)
+        sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
+        arr, n, keep = K.tensor_table(sub)
+        self._h = _capi.lib().avexhip_effnet_create(C.byref(c), arr, n)
+        del keep
+        if not self._h:
+            raise K.AvexHipError(f"effnet_create failed: {_capi.last_error()}")
+        self._ws: Optional[torch.Tensor] = None
+        # hookable convolutions in the reference's order (efficientnet.py:82-114): stem, every block's projection (blocks with an expansion), head
+        names = [prefix + "features.0.0"]
+        for si, (er, _k, _s, _cin, _cout, n_rep) in enumerate(self.stages, start=1):
+            if er != 1:
+                names += [prefix + f"features.{si}.{j}.block.3.0" for j in range(n_rep)]
+        names.append(prefix + f"features.{len(self.stages) + 1}.0")
+        self._tap_names = names
+        if len(names) != int(_capi.lib().avexhip_effnet_num_taps(self._h)):
+            raise K.AvexHipError("EfficientNet: tap list of the wrapper and of the library disagree")
+        self.stem_name, self.head_name = names[0], names[-1]
 
     def tap_names(self) -> List[str]:
-        return [self.stem_name] + [b["name"] + "3.0" for b in self.blocks if b["tap"]] + [self.head_name]
+        return list(self._tap_names)
+
+    def _shape(self, tap: int, H: int, W: int) -> Tuple[int, int, int]:
+        cc, ho, wo = C.c_int(0), C.c_int(0), C.c_int(0)
+        _capi.check(_capi.lib().avexhip_effnet_tap_shape(self._h, tap, H, W, C.byref(cc), C.byref(ho), C.byref(wo)), "effnet_tap_shape")
+        return cc.value, ho.value, wo.value
 
     @torch.no_grad()
     def forward(self, mel: torch.Tensor, hook_layers: Iterable[str] = (), want_features: bool = True, want_pooled: bool = False) -> Dict[str, object]:
         """``hook_layers``: names out of ``tap_names()``; their raw (pre-BatchNorm) convolution outputs come back as fp32 NCHW."""
         if mel.dim() != 3 or mel.dtype != torch.float32 or not mel.is_cuda:
             raise ValueError("mel must be a [B, n_mels, frames] float32 CUDA tensor")
-        hooks = set(hook_layers)
-        out: Dict[str, object] = {"hooks": {}}
-        B = mel.shape[0]
-        ws, bs, c0, sc0, sh0 = self.stem
-        if self.stem_name in hooks:
-            x, raw = K.effnet_stem(mel, ws, bs, self.dtype, want_raw=True)
-            # raw holds the BN output before SiLU; the tap is the convolution before its BatchNorm
-            r = (raw[..., :c0] - torch.from_numpy(sh0).to(raw.device)) / torch.from_numpy(sc0).to(raw.device)
-            out["hooks"][self.stem_name] = r.permute(0, 3, 1, 2).contiguous()
-        else:
-            x = K.effnet_stem(mel, ws, bs, self.dtype)
-        for blk in self.blocks:
-            Bn, H, W, Cp = x.shape
-            inp = x
-            if "expand" in blk:
-                we, be = blk["expand"]
-                x = K.gemm(x.view(Bn * H * W, Cp), we, bias=be, silu=True, out_f32=False, out_half=True)["half"].view(Bn, H, W, -1)
-            wd, bd = blk["dw"]
-            x, pool = K.effnet_dwconv(x, wd, bd, blk["k"], blk["stride"])
-            K.effnet_se(x, pool, blk["cexp"], *blk["se"])
-            Bn, H2, W2, Ce = x.shape
-            wp, bp = blk["project"]
-            res = inp.view(Bn * H * W, Cp) if (blk["stride"] == 1 and blk["cin"] == blk["cout"]) else None
-            tap = blk["tap"] and (blk["name"] + "3.0") in hooks
-            r = K.gemm(x.view(Bn * H2 * W2, Ce), wp, bias=bp, resid_half=res, alpha=1.0, out_f32=False, out_half=True, out_raw=tap)
-            if tap:        # out_raw = conv * bn_scale + bn_shift (before the residual); undo the folded BatchNorm for the tap
-                scp, shp = blk["project_bn"]
-                c = blk["cout"]
-                rr = (r["raw"][:, :c] - shp) / scp
-                out["hooks"][blk["name"] + "3.0"] = rr.view(Bn, H2, W2, c).permute(0, 3, 1, 2).contiguous()
-            x = r["half"].view(Bn, H2, W2, -1)
-        Bn, H, W, Cp = x.shape
-        wh, bh, sch, shh, ch = self.head
-        tap = self.head_name in hooks
-        r = K.gemm(x.view(Bn * H * W, Cp), wh, bias=bh, silu=True, out_f32=True, out_half=False, out_raw=tap)
-        if tap:
-            out["hooks"][self.head_name] = ((r["raw"][:, :ch] - shh) / sch).view(Bn, H, W, ch).permute(0, 3, 1, 2).contiguous()
-        f = r["f32"][:, :ch].view(Bn, H, W, ch)
+        mel = mel.contiguous()
+        B, H, W = mel.shape
+        dev = mel.device
+        need = int(_capi.lib().avexhip_effnet_workspace_bytes(self._h, B, H, W))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        hooks: Dict[str, torch.Tensor] = {}
+        ptrs = (C.c_void_p * len(self._tap_names))()
+        mask = 0
+        for name in set(hook_layers):
+            if name not in self._tap_names:
+                raise ValueError(f"{name!r} is not a hookable layer: {self._tap_names}")
+            i = self._tap_names.index(name)
+            hooks[name] = torch.empty((B,) + self._shape(i, H, W), dtype=torch.float32, device=dev)
+            ptrs[i] = int(hooks[name].data_ptr())
+            mask |= 1 << i
+        ch, ho, wo = self._shape(-1, H, W)
+        feats = torch.empty((B, ch, ho, wo), dtype=torch.float32, device=dev) if want_features else None
+        pooled = torch.empty((B, ch), dtype=torch.float32, device=dev) if want_pooled else None
+        _capi.check(_capi.lib().avexhip_effnet_forward(self._h, K._ptr(mel), B, H, W, mask, ptrs, K._ptr(feats), K._ptr(pooled), K._ptr(self._ws),
+                                                       self._ws.numel(), K._stream()), "effnet_forward")
+        out: Dict[str, object] = {"hooks": hooks}
         if want_features:
-            out["features"] = f.permute(0, 3, 1, 2).contiguous()                       # (B, C, H, W) like the reference
+            out["features"] = feats                                  # (B, C, H, W) like the reference
         if want_pooled:
-            out["pooled"] = K.mean_pool(f.reshape(Bn, H * W, ch).contiguous())
+            out["pooled"] = pooled
         return out
+
+    def overflow_events(self, sync: bool = True) -> int:
+        n = C.c_uint32(0)
+        _capi.check(_capi.lib().avexhip_effnet_overflow_count(self._h, C.byref(n), K._stream(), int(bool(sync))), "effnet_overflow_count")
+        return int(n.value)
+
+    def set_profiling(self, enabled: bool) -> None:
+        _capi.check(_capi.lib().avexhip_effnet_set_profiling(self._h, int(enabled)), "effnet_set_profiling")
+
+    def last_profile(self):
+        return K.handle_profile(_capi.lib().avexhip_effnet_last_profile, self._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _capi.lib().avexhip_effnet_destroy(self._h)
+            self._h = None
+        self._ws = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

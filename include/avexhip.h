@@ -452,6 +452,41 @@ int avexhip_aves_overflow_count(avexhip_aves* h, uint32_t* events, void* sync_st
 int avexhip_aves_set_profiling(avexhip_aves* h, int enabled);
 int avexhip_aves_last_profile(const avexhip_aves* h, const char* const** names, const float** ms, const double** flops, int* count);
 
+/* ------------------------------------------------------------------------------------------
+ * EfficientNet-B0 / B1 encoder handle: torchvision efficientnet_b0().features as efficientnet.Model.forward calls it
+ * (avex/models/efficientnet.py:55-66,163-215) on the AudioProcessor's mel image ([B, n_mels, frames] fp32, made by
+ * avexhip_melspec_forward; the reference repeats it to three channels, :138-140).  `stage` rows are torchvision's MBConv settings
+ * (expand_ratio, kernel, stride, in_channels, out_channels, repeats): B0 = (1,3,1,32,16,1) (6,3,2,16,24,2) (6,5,2,24,40,2)
+ * (6,3,2,40,80,3) (6,5,1,80,112,3) (6,5,2,112,192,4) (6,3,1,192,320,1); B1 adds a repeat per stage as torchvision does.
+ * Weight table keys as torchvision names them (with or without the wrapper's "model." prefix): features.0.0 / .0.1 (stem conv + BN),
+ * features.{s}.{j}.block.{d}.0 / .1, .fc1 / .fc2 (squeeze-excitation), features.{last}.0 / .1 (head).
+ * Hook taps (efficientnet.py:82-114): 0 = model.features.0.0, then every *.block.3.0 in order, last = the head conv; each is the
+ * convolution's output BEFORE its BatchNorm, NCHW fp32 [B, C, H', W'] (avexhip_effnet_tap_shape gives C, H', W').
+ * PARITY UNPINNED: torchvision is absent from the reference tree; checker oracle/effnet_oracle.py.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_effnet avexhip_effnet;
+typedef struct {
+    int32_t n_stages;         /* 7 */
+    int32_t stage[8][6];      /* expand_ratio, kernel (3 | 5), stride (1 | 2), in_channels, out_channels, repeats */
+    int32_t stem_channels;    /* 32 */
+    int32_t head_channels;    /* 1280 */
+    float   bn_eps;           /* 1e-5 */
+    int32_t operand_dtype;
+    int32_t max_chunk_clips;  /* 0 = 256 */
+} avexhip_effnet_config;
+avexhip_effnet* avexhip_effnet_create(const avexhip_effnet_config* cfg, const avexhip_tensor* tensors, int n_tensors);
+void avexhip_effnet_destroy(avexhip_effnet* h);
+int avexhip_effnet_num_taps(const avexhip_effnet* h);                      /* 17 for B0 */
+/* tap -1 = the feature map [head_channels, H', W'] */
+int avexhip_effnet_tap_shape(const avexhip_effnet* h, int tap, int H, int W, int* C, int* Ho, int* Wo);
+size_t avexhip_effnet_workspace_bytes(const avexhip_effnet* h, int B, int H, int W);
+/* mel_dev [B, H, W] fp32; features_out [B, head, H', W'] (efficientnet.py:208) and / or pooled_out [B, head] = mean over H' x W'. */
+int avexhip_effnet_forward(avexhip_effnet* h, const float* mel_dev, int B, int H, int W, uint32_t hook_mask, float* const* hook_out,
+                           float* features_out, float* pooled_out, void* workspace, size_t workspace_bytes, void* stream);
+int avexhip_effnet_overflow_count(avexhip_effnet* h, uint32_t* events, void* sync_stream, int synchronize);
+int avexhip_effnet_set_profiling(avexhip_effnet* h, int enabled);
+int avexhip_effnet_last_profile(const avexhip_effnet* h, const char* const** names, const float** ms, const double** flops, int* count);
+
 #ifdef __cplusplus
 }
 #endif
