@@ -101,6 +101,10 @@ SYMBOLS = {
     "avexhip_resample_out_length": (C.c_int64, [_P, C.c_int64]),
     "avexhip_resample_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "avexhip_pcm_to_mono_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P, _P]),
+    "avexhip_flac_open": (_P, [_P, C.c_size_t]),
+    "avexhip_flac_close": (None, [_P]),
+    "avexhip_flac_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), _P]),
+    "avexhip_flac_decode_i32": (C.c_int, [_P, _P, C.c_int, _P]),
     "avexhip_wavconv0_frames": (C.c_int, [C.c_int64]),
     "avexhip_wavconv0_stats_floats": (C.c_int64, [C.c_int, C.c_int64]),
     "avexhip_wavconv0": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int, C.c_int, _P]),

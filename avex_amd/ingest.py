@@ -8,9 +8,10 @@ augmentations.py:274-276; ``librosa.resample(..., res_type="kaiser_best")``, bir
 parses the container: the raw PCM bytes go to the device as they are and ``avexhip_pcm_to_mono_f32`` / ``avexhip_resample_forward``
 do the rest (a 44.1 kHz stereo minute is 10 MB over PCIe instead of 3.8 MB of finished floats, but no host core touches a sample).
 
-Containers: RIFF/WAVE with integer PCM (8 / 16 / 24 / 32 bit) or IEEE float (32 / 64 bit), incl. WAVE_FORMAT_EXTENSIBLE; anything else
-(FLAC, MP3, OGG need a codec library that neither machine has) raises ``ValueError`` -- decode those with the reference's reader and
-hand the array to :func:`to_device_mono`.  The resampler is torchaudio's algorithm (Hann-windowed sinc); librosa's ``kaiser_best``
+Containers: RIFF/WAVE with integer PCM (8 / 16 / 24 / 32 bit) or IEEE float (32 / 64 bit), incl. WAVE_FORMAT_EXTENSIBLE, and -- round 3 --
+FLAC (:class:`FlacStream`: the bitstream is parsed on the host, the predictors run on the device, bit-exact against the MD5 every
+stream carries); lossy codecs (MP3, OGG Vorbis) need a codec library that neither machine has and raise ``ValueError`` -- decode
+those with the reference's reader and hand the array to :func:`to_device_mono`.  The resampler is torchaudio's algorithm (Hann-windowed sinc); librosa's ``kaiser_best``
 filter is a different low-pass design and is NOT reproduced sample for sample (PARITY UNPINNED for both: neither library is
 installed; checker = oracle/ingest_oracle.py).
 """
@@ -25,7 +26,7 @@ import torch
 from . import _capi
 from ._capi import AvexHipError, check, lib
 
-__all__ = ["parse_wav", "Resampler", "to_device_mono", "load_audio"]
+__all__ = ["parse_wav", "FlacStream", "Resampler", "to_device_mono", "load_audio"]
 
 
 def parse_wav(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int, int]:
@@ -67,6 +68,43 @@ def parse_wav(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int, i
     frame_bytes = ch * bits // 8
     n = len(payload) // frame_bytes                                     # a truncated last frame is dropped
     return np.frombuffer(payload, dtype=np.uint8, count=n * frame_bytes), sr, ch, code
+
+
+class FlacStream:
+    """A FLAC stream parsed on the host (``avexhip_flac_open``: metadata, frame / subframe headers, Rice-coded residuals, every CRC) and
+    decoded on the device (``avexhip_flac_decode_i32``: predictors + inter-channel decorrelation), bit-exact -- the stream's STREAMINFO
+    carries the MD5 of its unencoded audio (``md5``).  Raises ``ValueError`` for anything that is not a well-formed FLAC stream."""
+
+    def __init__(self, data: Union[str, bytes]) -> None:
+        raw = data if isinstance(data, (bytes, bytearray)) else open(data, "rb").read()
+        self._buf = bytes(raw)
+        self._h = lib().avexhip_flac_open(self._buf, len(self._buf))
+        if not self._h:
+            raise ValueError(f"FLAC: {_capi.last_error()}")
+        import ctypes as C
+        sr, ch, bps, tot, md5 = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), (C.c_uint8 * 16)()
+        check(lib().avexhip_flac_info(self._h, C.byref(sr), C.byref(ch), C.byref(bps), C.byref(tot), md5), "flac_info")
+        self.sample_rate, self.channels, self.bits_per_sample, self.total_samples, self.md5 = sr.value, ch.value, bps.value, tot.value, bytes(md5)
+
+    def decode(self, device: Optional[torch.device] = None, left_justify: bool = False) -> torch.Tensor:
+        """Interleaved ``[total_samples, channels]`` int32 samples on the device (``left_justify``: shifted to 32-bit full scale)."""
+        _capi.require_gpu()
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            out = torch.empty((self.total_samples, self.channels), dtype=torch.int32, device=dev)
+            check(lib().avexhip_flac_decode_i32(self._h, out.data_ptr(), int(left_justify), torch.cuda.current_stream().cuda_stream), "flac_decode_i32")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().avexhip_flac_close(self._h)
+            self._h = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 # resampy's published filters: (num_zeros, precision, rolloff, Kaiser beta)
@@ -147,9 +185,16 @@ _RESAMPLERS: Dict[Tuple[int, int], Resampler] = {}
 
 
 def load_audio(path_or_bytes: Union[str, bytes], target_sr: Optional[int] = 16000, device: Optional[torch.device] = None) -> Tuple[torch.Tensor, int]:
-    """WAV file -> ``(mono float32 [T] on the device, sample_rate)``; resampled to ``target_sr`` when it differs (``None``: keep)."""
-    raw, sr, ch, code = parse_wav(path_or_bytes)
-    x = to_device_mono(raw, ch, code, device)
+    """WAV or FLAC file -> ``(mono float32 [T] on the device, sample_rate)``; resampled to ``target_sr`` when it differs (``None``: keep)."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    if data[:4] == b"fLaC":
+        fl = FlacStream(data)
+        pcm = fl.decode(device, left_justify=True)          # int32 at 32-bit full scale: normalised like 32-bit PCM (soundfile's float32 reading)
+        x, sr = to_device_mono(pcm, fl.channels, 32, device), fl.sample_rate
+        fl.close()
+    else:
+        raw, sr, ch, code = parse_wav(data)
+        x = to_device_mono(raw, ch, code, device)
     if target_sr is not None and sr != target_sr:
         key = (sr, int(target_sr))
         if key not in _RESAMPLERS:

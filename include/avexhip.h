@@ -151,6 +151,19 @@ int avexhip_resample_forward(const avexhip_resample_plan* plan, const float* x_d
                              int64_t out_stride, void* stream);
 int avexhip_pcm_to_mono_f32(const void* raw_dev, int sample_format, int channels, int64_t frames, float* out_dev, void* stream);
 
+/* FLAC decode (the reference reads its .flac samples through torchaudio.load / soundfile: augmentations.py:258-262,
+ * tests/samples/animalspeak2/16khz).  avexhip_flac_open parses a whole stream held in host memory -- metadata, frame and
+ * subframe headers, the Rice-coded residuals, every CRC-8 / CRC-16 -- and returns NULL (avexhip_last_error) on any violation;
+ * avexhip_flac_decode_i32 runs the predictors and the inter-channel decorrelation on the device and writes interleaved
+ * [total_samples][channels] int32 samples, bit-exact (STREAMINFO carries the MD5 of the unencoded audio: avexhip_flac_info);
+ * left_justify != 0 shifts them to 32-bit full scale so that avexhip_pcm_to_mono_f32(format 32) normalises them like soundfile.
+ * 4..32 bits per sample, 1..8 channels, fixed or variable block size; 32-bit stereo with side channels (33-bit samples) refused. */
+typedef struct avexhip_flac avexhip_flac;
+avexhip_flac* avexhip_flac_open(const uint8_t* data_host, size_t n_bytes);
+void avexhip_flac_close(avexhip_flac* h);
+int avexhip_flac_info(const avexhip_flac* h, int* sample_rate, int* channels, int* bits_per_sample, int64_t* total_samples, uint8_t* md5_16);
+int avexhip_flac_decode_i32(const avexhip_flac* h, int32_t* out_dev, int left_justify, void* stream);
+
 /* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
  * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):
  *   Conv1d(1, 512, k=10, s=5) -> GroupNorm(512, 512, eps) over time per (clip, channel) -> GELU

@@ -1,5 +1,6 @@
 """Ingest: WAV container parsing on the host (no GPU), PCM -> mono and the sinc resampler on the device vs the oracle."""
 import io
+import os
 import struct
 import wave
 
@@ -146,3 +147,94 @@ def test_load_audio_end_to_end(built_lib, tmp_path):
     from avex_amd import kernels as K
     fb = K.FbankPlan()(wav.unsqueeze(0))
     assert fb.shape == (1, 98, 128) and torch.isfinite(fb).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# FLAC: host bitstream parser + device predictors, bit-exact
+# ------------------------------------------------------------------------------------------------------------------------
+FLAC_FIXTURES = {"inaturalist_246886.flac": (505313, "843507851a89aa36d4ca0dd93b9720d1"), "xenocanto_XC564654.flac": (386361, "f795f9fe47921f35a64288483dfca4a1")}
+
+
+def _fixture(name):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flac", name)
+
+
+def test_flac_oracle_reproduces_the_md5_of_the_reference_samples():
+    """The two libFLAC-encoded files of the reference's own tests: the oracle's output hashes to the MD5 of the unencoded audio that
+    the encoder stored in STREAMINFO -- the restatement is pinned bit for bit."""
+    from oracle import flac_oracle as F
+    for name, (total, md5) in FLAC_FIXTURES.items():
+        data = open(_fixture(name), "rb").read()
+        x, info = F.flac_decode(data)                     # raises on any CRC-8 / CRC-16 / MD5 mismatch
+        assert x.shape == (total, 1) and x.dtype == np.int32 and info["sample_rate"] == 16000 and info["bps"] == 16
+        assert F.pcm_md5(x, 16).hex() == md5 == info["md5"].hex()
+
+
+def test_flac_encoder_cases_round_trip_through_the_oracle():
+    """Every syntax element the fixtures lack (CONSTANT / VERBATIM / FIXED subframes, the three stereo decorrelations, 4- and 5-bit Rice
+    parameters, escaped partitions, wasted bits, explicit block sizes, 8 / 12 / 24-bit samples, three channels), encoded by tests/_flac_enc.py."""
+    import _flac_enc as E
+    from oracle import flac_oracle as F
+    for name, (pcm, sr, bps, bs, plan) in E.cases().items():
+        data = E.encode(pcm, sr, bps, bs, plan)
+        x, info = F.flac_decode(data)
+        assert np.array_equal(x, pcm.astype(np.int32)), name
+        assert (info["sample_rate"], info["bps"], info["channels"], info["total"]) == (sr, bps, pcm.shape[1], pcm.shape[0])
+
+
+def test_flac_host_parser_accepts_and_refuses(built_lib):
+    """avexhip_flac_open runs on the host: stream info of the fixtures, every CRC checked, violations refused with ValueError."""
+    import _flac_enc as E
+    for name, (total, md5) in FLAC_FIXTURES.items():
+        f = ingest.FlacStream(_fixture(name))
+        assert (f.sample_rate, f.channels, f.bits_per_sample, f.total_samples, f.md5.hex()) == (16000, 1, 16, total, md5)
+        f.close()
+    for name, (pcm, sr, bps, bs, plan) in E.cases().items():
+        f = ingest.FlacStream(E.encode(pcm, sr, bps, bs, plan))
+        assert (f.sample_rate, f.channels, f.bits_per_sample, f.total_samples) == (sr, pcm.shape[1], bps, pcm.shape[0]), name
+    data = bytearray(open(_fixture("xenocanto_XC564654.flac"), "rb").read())
+    bad = bytearray(data); bad[3000] ^= 0x04                                   # a flipped bit inside a frame: CRC-16
+    with pytest.raises(ValueError, match="CRC"):
+        ingest.FlacStream(bytes(bad))
+    bad = bytearray(data); bad[88] ^= 0x01                                     # inside the first frame header: CRC-8 (or a reserved code)
+    with pytest.raises(ValueError):
+        ingest.FlacStream(bytes(bad))
+    with pytest.raises(ValueError):
+        ingest.FlacStream(bytes(data[:20000]))                                  # truncated
+    with pytest.raises(ValueError, match="fLaC"):
+        ingest.FlacStream(b"RIFF" + bytes(64))
+    with pytest.raises(ValueError):
+        ingest.parse_wav(bytes(data))                                           # and the WAV parser does not take it for a WAV
+
+
+@pytest.mark.gpu
+def test_flac_device_decoder_is_bit_exact(built_lib):
+    import hashlib
+    import _flac_enc as E
+    from oracle import flac_oracle as F
+    for name, (total, md5) in FLAC_FIXTURES.items():
+        f = ingest.FlacStream(_fixture(name))
+        x = f.decode().cpu().numpy()
+        assert x.shape == (total, 1)
+        assert F.pcm_md5(x, 16).hex() == md5                                   # the encoder's input, bit for bit
+        xj = f.decode(left_justify=True).cpu().numpy()
+        assert np.array_equal(xj, x << 16)
+    for name, (pcm, sr, bps, bs, plan) in E.cases().items():
+        f = ingest.FlacStream(E.encode(pcm, sr, bps, bs, plan))
+        assert np.array_equal(f.decode().cpu().numpy(), pcm.astype(np.int32)), name
+
+
+@pytest.mark.gpu
+def test_load_audio_reads_flac(built_lib):
+    """load_audio on a FLAC file = the decoded integers / 2^(bits - 1), channels averaged, resampled like a WAV of the same samples."""
+    import _flac_enc as E
+    from oracle import flac_oracle as F
+    x, sr = ingest.load_audio(_fixture("xenocanto_XC564654.flac"), target_sr=None)
+    ref, _ = F.flac_decode(open(_fixture("xenocanto_XC564654.flac"), "rb").read())
+    assert sr == 16000 and np.array_equal(x.cpu().numpy(), ref[:, 0].astype(np.float32) / np.float32(32768.0))
+    pcm, fsr, bps, bs, plan = E.cases()["stereo16_all_modes"]
+    y, sr2 = ingest.load_audio(E.encode(pcm, fsr, bps, bs, plan), target_sr=None)
+    assert np.allclose(y.cpu().numpy(), pcm.astype(np.float32).mean(1) / 32768.0, atol=1e-7)
+    z, sr3 = ingest.load_audio(_fixture("xenocanto_XC564654.flac"), target_sr=8000)
+    want = IO.resample(ref[:, 0].astype(np.float32) / np.float32(32768.0), 16000, 8000)
+    assert sr3 == 8000 and np.abs(z.cpu().numpy() - want).max() < 2e-6
