@@ -35,9 +35,50 @@ for c in range(cases):
     rh, rhd = rnd_half(rng.standard_normal((M, N)).astype(np.float32), dt)
     ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
     ad, wd, rhd, bd = ad.cuda(), wd.cuda(), rhd.cuda(), torch.from_numpy(bias).cuda()
-    mode = int(rng.integers(0, 4))
+    mode = int(rng.integers(0, 6))
     tolh = 7e-4 if dt == "f16" else 5e-3
-    if mode == 0:
+    fold_ok = N % 256 == 0 and Kd >= 128 and M >= 2
+    if mode >= 4 and not fold_ok:
+        mode -= 2
+    if mode >= 4:
+        # folded LayerNorm (round 3): the producer writes y = rh * alpha + a @ w.T + bias with row statistics; mode 4 consumes LN(y) as
+        # the A operand of a second product through folded weights, mode 5 as the residual of one; against the two-pass fp64 LayerNorm of
+        # the stored rows.  Every second case through the generic epilogue.
+        generic = bool(rng.integers(0, 2))
+        alpha = 2.2133638
+        p = K.gemm(ad, wd, bias=bd, resid_half=rhd, alpha=alpha, out_f32=False, out_half=True, stats_out=True, variant=5)
+        y = p["half"].float().cpu().numpy().astype(np.float64)
+        rows = K.ln_rowstats(p["stats"])
+        gamma = (1.0 + 0.2 * rng.standard_normal(N)).astype(np.float32); beta = (0.2 * rng.standard_normal(N)).astype(np.float32)
+        mu = y.mean(1, keepdims=True); rstd = 1.0 / np.sqrt(y.var(1, keepdims=True) + 1e-5)
+        ln = (y - mu) * rstd * gamma + beta
+        N2 = int(rng.choice([256, 512, 768]))
+        if generic:
+            os.environ["AVEX_AMD_GEMM_GENERIC"] = "1"
+        if mode == 4:
+            w2 = (0.05 * rng.standard_normal((N2, N))).astype(np.float32); b2 = (0.1 * rng.standard_normal(N2)).astype(np.float32)
+            w2f, w2fd = rnd_half((w2 * gamma[None, :]).astype(np.float32), dt)
+            s2 = w2f.astype(np.float64).sum(1).astype(np.float32)
+            b2f = (b2 + w2.astype(np.float64) @ beta).astype(np.float32)
+            act = bool(rng.integers(0, 2))
+            r = K.gemm(p["half"], w2fd.cuda(), bias=torch.from_numpy(b2f).cuda(), gelu=act, out_f32=False, out_half=True, ln_rows=rows, ln_s=torch.from_numpy(s2).cuda())
+            want = ((y - mu) * rstd) @ w2f.astype(np.float64).T + b2f
+            if act:
+                want = O.gelu_erf(want.astype(np.float32))
+            e = rel(r["half"].float().cpu().numpy(), want) / (1.0e-3 if dt == "f16" else 6e-3)
+        else:
+            a2, a2d = rnd_half(rng.standard_normal((M, 128)).astype(np.float32), dt)
+            w2, w2d = rnd_half((0.05 * rng.standard_normal((N, 128))).astype(np.float32), dt)
+            b2 = (0.1 * rng.standard_normal(N)).astype(np.float32)
+            r = K.gemm(a2d.cuda(), w2d.cuda(), bias=torch.from_numpy(b2).cuda(), alpha=alpha, lnr_y=p["half"], lnr_rows=rows, lnr_gamma=torch.from_numpy(gamma).cuda(),
+                       lnr_beta=torch.from_numpy(beta).cuda(), out_f32=False, out_half=True, stats_out=bool(rng.integers(0, 2)))
+            want = alpha * ln + a2.astype(np.float64) @ w2.astype(np.float64).T + b2
+            e = rel(r["half"].float().cpu().numpy(), want) / (1.0e-3 if dt == "f16" else 6e-3)
+            if "stats" in r:
+                o = r["half"].float().cpu().numpy().astype(np.float64).reshape(M, N // 64, 64)
+                assert np.allclose(r["stats"][..., 0].cpu().numpy(), o.sum(-1), rtol=2e-3, atol=0.5 if dt == "f16" else 4.0), "row statistics"
+        os.environ.pop("AVEX_AMD_GEMM_GENERIC", None)
+    elif mode == 0:
         r = K.gemm(ad, wd, bias=bd, variant=variant); e = rel(r["f32"].cpu().numpy(), ref) / 3e-6
     elif mode == 1:
         r = K.gemm(ad, wd, bias=bd, gelu=True, out_f32=False, out_half=True, variant=variant)
