@@ -48,7 +48,7 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
                                                         const float* __restrict__ grep_b,
                                                         const float* __restrict__ grep_a,
                                                         const uint8_t* __restrict__ key_pad,
-                                                        T* __restrict__ out, int dbg_arg) {
+                                                        T* __restrict__ out, int q_log2e, int dbg_arg) {
     AVX_ATT_DBG(dbg_arg)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
@@ -104,14 +104,18 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
             a = (grep_w[0 * 64 + tid] + grep_w[1 * 64 + tid]) + (grep_w[2 * 64 + tid] + grep_w[3 * 64 + tid]);
             bb = (grep_w[4 * 64 + tid] + grep_w[5 * 64 + tid]) + (grep_w[6 * 64 + tid] + grep_w[7 * 64 + tid]);
         }
-        gw[tid] = a;
-        gw[64 + tid] = bb;
+        // q_log2e: the caller's Q columns already carry log2(e) (folded into W_q / b_q in fp32 when the weights were packed, so that Q is
+        // rounded to the operand type once and no rounded constant enters the scores); the gate wants the plain q: its weights take 1 / log2(e)
+        const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;
+        gw[tid] = a * ginv;
+        gw[64 + tid] = bb * ginv;
         if (tid == 0) {
             gw[128] = grep_w ? (grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]) : 0.f;
             gw[129] = grep_w ? (grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]) : 0.f;
         }
     }
     __syncthreads();
+    const float sscale = q_log2e ? 0.125f : 0.125f * 1.4426950408889634f;
 
     const int nqt = (Tn + 31) >> 5;
     const int hh = lane >> 5, r32 = lane & 31;
@@ -181,14 +185,14 @@ __global__ __launch_bounds__(1024) void attention_kernel(const T* __restrict__ q
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int jo = (r & 3) + 8 * (r >> 2);
-                    sc[r] = __builtin_fmaf(S[r], 0.125f * 1.4426950408889634f, gate * tv[r]) + kadd[jb + jo];
+                    sc[r] = __builtin_fmaf(S[r], sscale, gate * tv[r]) + kadd[jb + jo];
                     mx = fmaxf(mx, sc[r]);
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int jo = (r & 3) + 8 * (r >> 2);
-                    sc[r] = __builtin_fmaf(S[r], 0.125f * 1.4426950408889634f, gate * tv[r]);
+                    sc[r] = __builtin_fmaf(S[r], sscale, gate * tv[r]);
                     mx = fmaxf(mx, sc[r]);
                 }
             }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                                                         const float* __restrict__ grep_b,
                                                         const float* __restrict__ grep_a,
                                                         const uint8_t* __restrict__ key_pad,
-                                                        T* __restrict__ out, int dbg_arg) {
+                                                        T* __restrict__ out, int q_log2e, int dbg_arg) {
     AVX_ATT_DBG(dbg_arg)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
@@ -341,16 +345,20 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_items = Bc * H;
-    const int it0 = blockIdx.x * per_block;
-    const int it1 = it0 + per_block < n_items ? it0 + per_block : n_items;
-    if (it0 >= it1) return;
+    // The unit of work is (item, query block of 512): a workgroup takes per_block consecutive units, so a few long clips still fill the
+    // chip (1 clip x 12 heads x 4 query blocks = 48 workgroups instead of 12); short clips have one query block per item.
+    const int nqb = LONG ? nqb_main : 1;                             // query blocks per item (a short last block may be left to the tail kernel)
+    const int n_units = Bc * H * nqb;
+    const int w0 = blockIdx.x * per_block;
+    const int w1 = w0 + per_block < n_units ? w0 + per_block : n_units;
+    if (w0 >= w1) return;
+    const int it0 = LONG ? w0 / nqb : w0;
+    const int qb0 = LONG ? w0 - it0 * nqb : 0;
     const int E = H * 64;
     const int64_t ld = 3 * (int64_t)E;
     const float NEG_INF = -__builtin_inff();
     const int nh = LONG ? (Tn + 255) >> 8 : (Tn > 256 ? 2 : 1);      // key blocks of 256 per query block
-    const int nqb = LONG ? nqb_main : 1;                             // query blocks of 512 per item (a short last block may be left to the tail kernel)
-    const int np = (it1 - it0) * nqb * nh;
+    const int np = (w1 - w0) * nh;
     const int nkt = (Tn + 31) >> 5;
     const int hh = lane >> 5, r32 = lane & 31;
     int qi[NQ], iq[NQ];
@@ -363,13 +371,13 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         }
         has_q = qb * 512 + (ATT_BIAS_REUSE ? NQ * wave : wave) * 32 < Tn;
     };
-    set_qblock(0);
+    set_qblock(qb0);
 
     // Items are h * Bc + b, walked in order: (h, b) of the item being computed and of the one being loaded are kept
     // incrementally (no division in the loop).  A workgroup's range stays on one head, or two at a seam.
     int h_cur = it0 / Bc, b_cur = it0 - h_cur * Bc;      // item of the phase being computed
-    int qb_cur = 0, half = 0;                            // its query block and key block
-    int h_ld = h_cur, b_ld = b_cur, half_ld = 0, qb_ld = 0;   // (item, query block, key block) the next DMA fetches
+    int qb_cur = qb0, half = 0;                          // its query block and key block
+    int h_ld = h_cur, b_ld = b_cur, half_ld = 0, qb_ld = qb0;   // (item, query block, key block) the next DMA fetches
     int item_par = 0;                                    // parity of the item being computed: its kadd slot
 
     auto issue_next = [&](int ph) __attribute__((always_inline)) {      // DMA for phase ph = (h_ld, b_ld, half_ld), then advance
@@ -436,8 +444,9 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             a = (grep_w[0 * 64 + tid] + grep_w[1 * 64 + tid]) + (grep_w[2 * 64 + tid] + grep_w[3 * 64 + tid]);
             bb = (grep_w[4 * 64 + tid] + grep_w[5 * 64 + tid]) + (grep_w[6 * 64 + tid] + grep_w[7 * 64 + tid]);
         }
-        gw[tid] = a;
-        gw[64 + tid] = bb;
+        const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;      // (see attention_kernel: the gate reads the unscaled q)
+        gw[tid] = a * ginv;
+        gw[64 + tid] = bb * ginv;
         if (tid == 0) {
             gw[128] = grep_w ? (grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]) : 0.f;
             gw[129] = grep_w ? (grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]) : 0.f;
@@ -456,7 +465,8 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     }
     const int li = lane & 15;
     const int v_lane = 64 * (4 * hh + (li >> 2)) + 32 * ((lane >> 4) & 1) + 8 * (li & 3);   // transposed-read address, per lane
-    const float cs = 0.125f * 1.4426950408889634f;
+    // 1/8 is exact in the operand type; log2(e) is not (bf16: 0.18 % off, a temperature error on every logit): handles fold it into W_q in fp32
+    const float cs = q_log2e ? 0.125f : 0.125f * 1.4426950408889634f;
 
     // Output of item (h, b): the lane pair (l, l + 32) holds a query row's d = 8g + 4hh + 0..3; two v_permlane32_swap per
     // pair of g give each lane 8 consecutive d, so a row is written in 16-byte pieces (four stores per 32-query tile).
@@ -981,7 +991,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 template <typename T>
 __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict__ qkv, int Tn, int H, int T0, int R, const float* __restrict__ bias_tab,
                                                             const float* __restrict__ grep_w, const float* __restrict__ grep_b, const float* __restrict__ grep_a,
-                                                            const uint8_t* __restrict__ key_pad, T* __restrict__ out) {
+                                                            const uint8_t* __restrict__ key_pad, T* __restrict__ out, int q_log2e) {
     extern __shared__ float sc[];                            // [Tn] scores, then probabilities; + 64 floats of q
     float* qs = sc + Tn;
     const int lane = threadIdx.x;
@@ -995,15 +1005,16 @@ __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict_
     qs[lane] = qv;
     float gate = 1.f;
     if (grep_w) {
-        const float wa = (grep_w[0 * 64 + lane] + grep_w[1 * 64 + lane]) + (grep_w[2 * 64 + lane] + grep_w[3 * 64 + lane]);
-        const float wb = (grep_w[4 * 64 + lane] + grep_w[5 * 64 + lane]) + (grep_w[6 * 64 + lane] + grep_w[7 * 64 + lane]);
+        const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;
+        const float wa = ((grep_w[0 * 64 + lane] + grep_w[1 * 64 + lane]) + (grep_w[2 * 64 + lane] + grep_w[3 * 64 + lane])) * ginv;
+        const float wb = ((grep_w[4 * 64 + lane] + grep_w[5 * 64 + lane]) + (grep_w[6 * 64 + lane] + grep_w[7 * 64 + lane])) * ginv;
         const float sa = wave_sum(qv * wa) + ((grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]));
         const float sb = wave_sum(qv * wb) + ((grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]));
         const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
         gate = ga * (gb * grep_a[h] - 1.f) + 2.f;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float cs = 0.125f * 1.4426950408889634f;
+    const float cs = q_log2e ? 0.125f : 0.125f * 1.4426950408889634f;
     float mx = NEG_INF;
     for (int j = lane; j < Tn; j += 64) {
         typedef typename Half<T>::v8 v8;
@@ -1046,7 +1057,7 @@ __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict_
 
 template <typename T>
 int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const float* grep_w, const float* grep_b,
-           const float* grep_a, const uint8_t* key_pad, void* out, hipStream_t s) {
+           const float* grep_a, const uint8_t* key_pad, void* out, int q_log2e, hipStream_t s) {
     AVX_ENSURE_LDS(attention_kernel<T>, ATT_LDS);
     static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
     int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
@@ -1054,24 +1065,25 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
     if (variant == 2) {
         int n_cu = 256;
         { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
-        const int n_items = B * H;
         int n_wg = n_cu;
-        if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several items per workgroup
-        const int per_block = (n_items + n_wg - 1) / n_wg;
-        const int grid = (n_items + per_block - 1) / per_block;
+        if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several units per workgroup
+        // a last query block of at most 32 rows goes to the tail kernel (one wave per row) instead of a whole 512-row block
+        const int rem = Tn % 512;
+        const bool use_tail = Tn > TMAX && rem > 0 && rem <= 32 && !getenv("AVEX_AMD_ATT_NO_TAIL");
+        const int nqb_main = Tn > TMAX ? (use_tail ? Tn / 512 : (Tn + 511) / 512) : 1;
+        AVX_REQUIRE((int64_t)B * H * nqb_main < (1ll << 31), "attention: too many (item, query block) units");
+        const int n_units = B * H * nqb_main;            // (clip, head, query block of 512) units, dealt to the workgroups in consecutive runs
+        const int per_block = (n_units + n_wg - 1) / n_wg;
+        const int grid = (n_units + per_block - 1) / per_block;
         if (Tn > TMAX) {
-            // a last query block of at most 32 rows goes to the tail kernel (one wave per row) instead of a whole 512-row block
-            const int rem = Tn % 512;
-            const bool use_tail = rem > 0 && rem <= 32 && !getenv("AVEX_AMD_ATT_NO_TAIL");
-            const int nqb_main = use_tail ? Tn / 512 : (Tn + 511) / 512;
             if (bias_tab) {
                 AVX_ENSURE_LDS((attention2_kernel<T, true, true>), ATT2L_LDS);
                 hipLaunchKernelGGL((attention2_kernel<T, true, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
-                                   grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+                                   grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
             } else {
                 AVX_ENSURE_LDS((attention2_kernel<T, true, false>), ATT2L_LDS);
                 hipLaunchKernelGGL((attention2_kernel<T, true, false>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
-                                   grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+                                   grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
             }
             AVX_LAUNCH_CHECK();
             if (use_tail) {
@@ -1079,22 +1091,22 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
                 const size_t lds = sizeof(float) * ((size_t)Tn + 64);
                 AVX_ENSURE_LDS(attention_tail_kernel<T>, 160 * 1024);
                 hipLaunchKernelGGL(attention_tail_kernel<T>, dim3(B * H * rem), dim3(64), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b,
-                                   grep_a, key_pad, (T*)out);
+                                   grep_a, key_pad, (T*)out, q_log2e);
             }
         } else if (bias_tab) {
             AVX_ENSURE_LDS((attention2_kernel<T, false, true>), ATT2_LDS);
             hipLaunchKernelGGL((attention2_kernel<T, false, true>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, 1, bias_tab,
-                               grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+                               grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
         } else {
             AVX_ENSURE_LDS((attention2_kernel<T, false, false>), ATT2_LDS);
             hipLaunchKernelGGL((attention2_kernel<T, false, false>), dim3(grid), dim3(512), ATT2_LDS, s, (const T*)qkv, Tn, H, B, per_block, 1, bias_tab,
-                               grep_w, grep_b, grep_a, key_pad, (T*)out, dbg);
+                               grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
         }
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }
     hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(1024), ATT_LDS, s, (const T*)qkv, Tn, H, bias_tab, grep_w,
-                       grep_b, grep_a, key_pad, (T*)out, dbg);
+                       grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
@@ -1113,13 +1125,13 @@ namespace avx {
 
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
-              hipStream_t s) {
+              hipStream_t s, int q_log2e) {
     AVX_REQUIRE(qkv && out, "attention: null buffer");
     AVX_REQUIRE(B > 0 && H > 0, "attention: bad B=%d H=%d", B, H);
     AVX_REQUIRE(T > 0 && T <= 32768, "attention: T=%d tokens unsupported (1..32768)", T);
     AVX_REQUIRE(!grep_w || (grep_b && grep_a), "attention: grep_b/grep_a required with grep_w");
-    if (dtype == AVEXHIP_F16) return launch<_Float16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, s);
-    if (dtype == AVEXHIP_BF16) return launch<__bf16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, s);
+    if (dtype == AVEXHIP_F16) return launch<_Float16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, q_log2e, s);
+    if (dtype == AVEXHIP_BF16) return launch<__bf16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, q_log2e, s);
     avexhip_set_error("attention: unknown dtype %d", dtype);
     return AVEXHIP_ERR_INVALID;
 }

@@ -282,9 +282,11 @@ int zero_rows(float* x32, int64_t ld32, void* x_half, int64_t ldh, int M, int C,
 // final LayerNorm + mean over tokens in one pass (half rows in, [B, C] fp32 out); C % 8 == 0, C <= 768
 int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int B, int T, int C, float* out, int dtype,
                    hipStream_t s);
+// q_log2e != 0: the Q columns of qkv already carry log2(e) (folded into W_q / b_q in fp32 by the handles); the kernel then scales by the
+// exact 1/8 only and feeds the gate with weights divided by log2(e)
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
-              hipStream_t s);
+              hipStream_t s, int q_log2e = 0);
 int posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed, int dtype,
                  hipStream_t s);
 // residual = x_f32 if non-null else x_half; writes out_f32 and/or out_half

@@ -37,6 +37,10 @@ struct HandleBase {
     // memory by an asynchronous copy at the end of each forward (read without a synchronisation by *_overflow_count)
     unsigned int* d_ovf = nullptr;
     unsigned int* h_ovf = nullptr;
+    // log2(e) of the attention's exp2 folded into W_q / b_q in fp32 when the weights are packed (avx::attention's q_log2e): Q is rounded to the
+    // operand type once and the scores are scaled by the exact 1/8.  AVEX_AMD_Q_LOG2E=0 keeps plain Q (the kernel then scales by a constant
+    // it rounds to the operand type: 0.18 % off in bf16)
+    bool q_log2e = !(getenv("AVEX_AMD_Q_LOG2E") && atoi(getenv("AVEX_AMD_Q_LOG2E")) == 0);
     bool profiling = false;
     std::vector<StageRec> recs;
     std::vector<std::string> prof_names;
@@ -305,19 +309,23 @@ inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, con
     h->allocs.push_back(ly.w_qkv);
     AVX_HIP_CHECK(hipMalloc((void**)&ly.b_qkv, sizeof(float) * 3 * E));
     h->allocs.push_back(ly.b_qkv);
-    std::vector<float> Wqkv, bqkv;          // host copies for the fold
+    std::vector<float> Wqkv, bqkv;          // host copies: rows [0, E) are W_q (scaled by log2(e) here, in fp32), kept for the LayerNorm fold
     if (nm.qkv_fused) {
-        RC(dev_half_into(h, tb, fmt_name(nm.qkv_fused, i, ".weight"), (int64_t)3 * E * E, ly.w_qkv));
+        RC(host_f32(h, tb, fmt_name(nm.qkv_fused, i, ".weight"), (int64_t)3 * E * E, Wqkv));
         RC(host_f32(h, tb, fmt_name(nm.qkv_fused, i, ".bias"), 3 * E, bqkv));
-        if (c.fold && i > 0) RC(host_f32(h, tb, fmt_name(nm.qkv_fused, i, ".weight"), (int64_t)3 * E * E, Wqkv));
     } else {
         const char* part[3] = {nm.q, nm.k, nm.v};
         for (int j = 0; j < 3; ++j) {
-            RC(dev_half_into(h, tb, fmt_name(part[j], i, ".weight"), (int64_t)E * E, (char*)ly.w_qkv + 2 * (size_t)j * E * E));
+            RC(host_f32(h, tb, fmt_name(part[j], i, ".weight"), (int64_t)E * E, Wqkv));
             RC(host_f32(h, tb, fmt_name(part[j], i, ".bias"), E, bqkv));
-            if (c.fold && i > 0) RC(host_f32(h, tb, fmt_name(part[j], i, ".weight"), (int64_t)E * E, Wqkv));
         }
     }
+    if (h->q_log2e) {
+        const float l2e = 1.4426950408889634f;
+        for (size_t j = 0; j < (size_t)E * E; ++j) Wqkv[j] *= l2e;
+        for (int j = 0; j < E; ++j) bqkv[j] *= l2e;
+    }
+    RC(upload_half(h, Wqkv.data(), (int64_t)3 * E * E, ly.w_qkv, "qkv.weight"));
     AVX_HIP_CHECK(hipMemcpy(ly.b_qkv, bqkv.data(), sizeof(float) * 3 * E, hipMemcpyHostToDevice));
     RC(dev_half(h, tb, fmt_name(nm.out_proj, i, ".weight"), (int64_t)E * E, &ly.w_o));
     RC(dev_f32(h, tb, fmt_name(nm.out_proj, i, ".bias"), E, &ly.b_o));
@@ -432,7 +440,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         RC(avx::gemm(g, dt, cs));
         prof.end();
         prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
-        RC(avx::attention(w.qkv, Bc, Tt, H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, dt, cs));
+        RC(avx::attention(w.qkv, Bc, Tt, H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, dt, cs, h->q_log2e ? 1 : 0));
         prof.end();
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = c.alpha;

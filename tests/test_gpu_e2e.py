@@ -22,26 +22,32 @@ def base_sd():
     return synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0)
 
 
-@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres", "f16-halfres-nofold", "bf16-halfres-nofold"])
+@pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres", "f16-halfres-nofold", "bf16-halfres-nofold",
+                                        "f16-halfres-plainq", "bf16-plainq"])
 def encoder(request, built_lib, base_sd):
     """f32 residual stream (generic GEMM epilogues), half residual stream (default: the LayerNorms folded into the streaming GEMM's
-    epilogues) and half residual stream with LayerNorm kernels (AVEX_AMD_LN_FOLD=0, read when the handle is created)."""
+    epilogues), half residual stream with LayerNorm kernels (AVEX_AMD_LN_FOLD=0) and the attention fed with plain Q instead of
+    log2(e) Q (AVEX_AMD_Q_LOG2E=0); both knobs are read when the handle is created."""
     import os
     from avex_amd import kernels as K
     dt = request.param.split("-")[0]
-    old = os.environ.get("AVEX_AMD_LN_FOLD")
-    if request.param.endswith("nofold"):
-        os.environ["AVEX_AMD_LN_FOLD"] = "0"
-    else:
-        os.environ.pop("AVEX_AMD_LN_FOLD", None)
+    knobs = {"AVEX_AMD_LN_FOLD": "0" if request.param.endswith("nofold") else None,
+             "AVEX_AMD_Q_LOG2E": "0" if request.param.endswith("plainq") else None}
+    old = {k: os.environ.get(k) for k in knobs}
+    for k, v in knobs.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     try:
         enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, base_sd, operand_dtype=dt, max_chunk_clips=3,
                              residual="half" if "halfres" in request.param else "f32")
     finally:
-        if old is None:
-            os.environ.pop("AVEX_AMD_LN_FOLD", None)
-        else:
-            os.environ["AVEX_AMD_LN_FOLD"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     enc.dtype_name = dt
     yield enc
     enc.close()

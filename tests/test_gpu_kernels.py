@@ -360,11 +360,12 @@ def test_attention_large_logits(built_lib, variant, monkeypatch):
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("T,grid", [(513, 0), (600, 7), (1000, 5), (1537, 3), (520, 0), (544, 4), (545, 0)])
+@pytest.mark.parametrize("T,grid", [(513, 0), (600, 7), (1000, 5), (1537, 3), (1537, 7), (2100, 11), (520, 0), (544, 4), (545, 0)])
 def test_attention_long_clips(built_lib, T, grid, monkeypatch):
     """More than 512 tokens (the reference has no length limit, backbone.py:151-221; EAT has 513): queries in blocks of 512,
     keys in blocks of 256, a bias-row window and a key mask per (query block, key block) phase.  Gate, key padding (a masked
-    first key tile, a clip whose last query block is one row), items that cross a head seam, vs the fp64 restatement."""
+    first key tile, a clip whose last query block is one row), items that cross a head seam, workgroups whose run of (item, query
+    block) units starts in the middle of an item (grid 5 at T = 1000: 72 units in runs of 15), vs the fp64 restatement."""
     from avex_amd import kernels as K
     if grid:
         monkeypatch.setenv("AVEX_AMD_ATT_GRID", str(grid))
