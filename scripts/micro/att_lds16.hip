@@ -110,5 +110,8 @@ int main() {
     run<2, 512, true>("A  8 waves x 2 query tiles, with the LDS reads (128 KB / key tile)");
     run<1, 1024, false>("B 16 waves x 1 query tile,  registers only");
     run<1, 1024, true>("B 16 waves x 1 query tile,  with the LDS reads (192 KB / key tile)");
+    // C: one wave per SIMD with FOUR query tiles (accumulators in AGPRs, 512 registers per lane): half of A's K / V reads per MFMA
+    run<4, 256, false>("C  4 waves x 4 query tiles, registers only");
+    run<4, 256, true>("C  4 waves x 4 query tiles, with the LDS reads (96 KB / key tile)");
     return 0;
 }
