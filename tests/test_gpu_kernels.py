@@ -337,8 +337,9 @@ def test_attention_persistent_items(built_lib, T, grid, variant, monkeypatch):
     assert rel_l2(out2.float().cpu().numpy(), ref2) < 1.5e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("variant", ["1", "2"])
-def test_attention_large_logits(built_lib, variant, monkeypatch):
+def test_attention_large_logits(built_lib, variant, dtype, monkeypatch):
     """Row maxima that keep growing along the keys exercise the deferred-maximum rescale of variant 2 (the branch is
     data dependent and rare on gaussian scores): q.k grows with the key index, so every tile moves the reference."""
     from avex_amd import kernels as K
@@ -351,13 +352,17 @@ def test_attention_large_logits(built_lib, variant, monkeypatch):
     ramp = (np.arange(T, dtype=np.float32) / T)[None, :, None, None]
     qkv[:, :, 0] = 3.0 + 0.3 * qkv[:, :, 0]                       # q ~ 3
     qkv[:, :, 1] = 3.0 * ramp * (1.0 + 0.1 * qkv[:, :, 1])        # k grows along the sequence: logits up to ~ 70 (log2 ~ 100)
-    qkv = round_half(qkv.reshape(B * T, 3 * E), "f16")
+    qkv = round_half(qkv.reshape(B * T, 3 * E), dtype)
     table = synth.normal("rel", (320, H), 0.5)
     tab = _toeplitz(table, T, 320, 800)
-    out = K.attention(_dev(qkv, torch.float16), B, T, H, _dev(tab), None, None, None)
+    out = K.attention(_dev(qkv, _tdt(dtype)), B, T, H, _dev(tab), None, None, None)
     ref = _attention_ref(qkv, B, T, H, table, None, None, None)
     assert np.isfinite(out.float().cpu().numpy()).all()
-    assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+    # bf16 through the PUBLIC entry point (plain Q): the kernel scales Q by log2(e) / 8 rounded to bf16 (0.18 % off) and rounds the product
+    # again, so logits of ~ 70 move by ~ 0.1 -- the bar below states that; the handles fold log2(e) into W_q in fp32 instead (q_log2e)
+    err = rel_l2(out.float().cpu().numpy(), ref)
+    print(f"large logits {dtype} variant {variant}: {err:.3e}")
+    assert err < (1.5e-3 if dtype == "f16" else 5e-2)
 
 
 @pytest.mark.parametrize("T,grid", [(513, 0), (600, 7), (1000, 5), (1537, 3), (1537, 7), (2100, 11), (520, 0), (544, 4), (545, 0)])
