@@ -89,6 +89,28 @@ BEATS_TINY_CFG: Dict[str, object] = dict(
 )
 
 
+# small config on the kernels' geometry (head_dim 64, positional conv k = 128 with 48 channels per group, tile-multiple widths): the base of
+# the configuration-space variants below (BEATsConfig options no official checkpoint uses, beats.py:181-212)
+BEATS_SMALL_CFG: Dict[str, object] = dict(
+    BEATS_BASE_CFG,
+    encoder_layers=2, encoder_embed_dim=384, encoder_ffn_embed_dim=768, encoder_attention_heads=6, embed_dim=256,
+    conv_pos=128, conv_pos_groups=8, finetuned_model=False,
+)
+BEATS_VARIANTS: Dict[str, Dict[str, object]] = {
+    # pre-LN blocks (backbone.py:328-348, final LayerNorm after the stack :146-147), ReLU, patch-embedding bias
+    "preln_relu_convbias": dict(BEATS_SMALL_CFG, layer_norm_first=True, deep_norm=False, activation_fn="relu", conv_bias=True),
+    # post-LN without DeepNorm (alpha = 1), tanh-form GELU (modules.py:177-188), no relative position bias at all
+    "postln_geluacc_norel": dict(BEATS_SMALL_CFG, deep_norm=False, activation_fn="gelu_accurate", relative_position_embedding=False),
+    # post-LN with the gated-linear-unit FFN (fc1 = GLU_Linear(E, F, "swish"), backbone.py:296-297) and an UNGATED position bias
+    # (the reference cannot build glu with deep_norm: its DeepNorm init reads fc1.weight, backbone.py:121)
+    "postln_glu_nogate": dict(BEATS_SMALL_CFG, deep_norm=False, activation_fn="glu", gru_rel_pos=False),
+    # pre-LN with tanh, encoder width = patch width (no post_extract_proj, beats.py:357-358)
+    "preln_tanh_nopost": dict(BEATS_SMALL_CFG, layer_norm_first=True, deep_norm=False, activation_fn="tanh", embed_dim=384),
+    # "linear" FFN (identity activation)
+    "postln_linear": dict(BEATS_SMALL_CFG, activation_fn="linear"),
+}
+
+
 def beats_state_dict(cfg: Mapping[str, object] = BEATS_BASE_CFG, seed: int = 0,
                      include_predictor: bool = True, nontrivial_affine: bool = True
                      ) -> Dict[str, np.ndarray]:
@@ -125,6 +147,8 @@ def beats_state_dict(cfg: Mapping[str, object] = BEATS_BASE_CFG, seed: int = 0,
         n("post_extract_proj.weight", (E, D), 1.0 / math.sqrt(3.0 * D))      # U(+-1/sqrt(D)) std
         sd[pre + "post_extract_proj.bias"] = uniform("post_extract_proj.bias", (E,), 1.0 / math.sqrt(D), seed)
     sd[pre + "patch_embedding.weight"] = uniform("patch_embedding.weight", (D, 1, P, P), 1.0 / P, seed)
+    if bool(cfg.get("conv_bias", False)):
+        sd[pre + "patch_embedding.bias"] = uniform("patch_embedding.bias", (D,), 1.0 / P, seed)
     aff("layer_norm.weight", D, True); aff("layer_norm.bias", D, False)
 
     std_pc = math.sqrt(4.0 / (KP * E))
@@ -139,22 +163,30 @@ def beats_state_dict(cfg: Mapping[str, object] = BEATS_BASE_CFG, seed: int = 0,
 
     xav = math.sqrt(2.0 / (E + E))
     rel = normal("encoder.layers.0.self_attn.relative_attention_bias.weight", (NB, H), 0.02 if not nontrivial_affine else 0.3, seed)
+    has_rel = bool(cfg.get("relative_position_embedding", True))
+    has_gate = bool(cfg.get("gru_rel_pos", True))
+    glu = str(cfg.get("activation_fn", "gelu")) == "glu"
     for i in range(L):
         p = f"encoder.layers.{i}."
         n(p + "self_attn.q_proj.weight", (E, E), xav); bias(p + "self_attn.q_proj.bias", E)
         n(p + "self_attn.k_proj.weight", (E, E), xav); bias(p + "self_attn.k_proj.bias", E)
         n(p + "self_attn.v_proj.weight", (E, E), xav * beta); bias(p + "self_attn.v_proj.bias", E)
         n(p + "self_attn.out_proj.weight", (E, E), xav * beta); bias(p + "self_attn.out_proj.bias", E)
-        n(p + "self_attn.grep_linear.weight", (8, hd), 0.02 if not nontrivial_affine else 0.1)
-        bias(p + "self_attn.grep_linear.bias", 8, 0.1)
-        ga = np.ones((1, H, 1, 1), np.float32)
-        if nontrivial_affine:
-            ga = (ga + normal(p + "self_attn.grep_a", (1, H, 1, 1), 0.2, seed)).astype(np.float32)
-        sd[pre + p + "self_attn.grep_a"] = ga
-        # the table is one shared Parameter (backbone.py:100-103); state_dict lists it per layer
-        sd[pre + p + "self_attn.relative_attention_bias.weight"] = rel
+        if has_gate:
+            n(p + "self_attn.grep_linear.weight", (8, hd), 0.02 if not nontrivial_affine else 0.1)
+            bias(p + "self_attn.grep_linear.bias", 8, 0.1)
+            ga = np.ones((1, H, 1, 1), np.float32)
+            if nontrivial_affine:
+                ga = (ga + normal(p + "self_attn.grep_a", (1, H, 1, 1), 0.2, seed)).astype(np.float32)
+            sd[pre + p + "self_attn.grep_a"] = ga
+        if has_rel:
+            # the table is one shared Parameter (backbone.py:100-103); state_dict lists it per layer
+            sd[pre + p + "self_attn.relative_attention_bias.weight"] = rel
         aff(p + "self_attn_layer_norm.weight", E, True); aff(p + "self_attn_layer_norm.bias", E, False)
-        n(p + "fc1.weight", (F, E), math.sqrt(2.0 / (E + F)) * beta); bias(p + "fc1.bias", F)
+        if glu:      # GLU_Linear: one Linear(E, 2F); value half first, gate half second (modules.py:150-171)
+            n(p + "fc1.linear.weight", (2 * F, E), math.sqrt(2.0 / (E + F)) * beta); bias(p + "fc1.linear.bias", 2 * F)
+        else:
+            n(p + "fc1.weight", (F, E), math.sqrt(2.0 / (E + F)) * beta); bias(p + "fc1.bias", F)
         n(p + "fc2.weight", (E, F), math.sqrt(2.0 / (E + F)) * beta); bias(p + "fc2.bias", E)
         aff(p + "final_layer_norm.weight", E, True); aff(p + "final_layer_norm.bias", E, False)
     if include_predictor and bool(cfg.get("finetuned_model", False)):

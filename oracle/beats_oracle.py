@@ -221,6 +221,30 @@ def gelu_erf(x: np.ndarray) -> np.ndarray:
     return t
 
 
+def ffn_hidden(x: np.ndarray, p: Mapping[str, np.ndarray], pre: str, activation: str) -> np.ndarray:
+    """``activation_fn(fc1(x))`` for the activations ``get_activation_fn`` knows (modules.py:203-237), or the gated linear unit that
+    replaces fc1 when ``activation_fn == "glu"`` (``GLU_Linear(E, F, "swish")``, backbone.py:296-297; modules.py:155-171: one Linear to
+    2F, the first F columns times swish of the second F)."""
+    if activation == "glu":
+        y = linear(x, p[pre + "fc1.linear.weight"], p[pre + "fc1.linear.bias"])
+        F = y.shape[-1] // 2
+        g = y[..., F:]
+        return (y[..., :F] * (g / (np.float32(1.0) + np.exp(-g)))).astype(np.float32)
+    y = linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"])
+    if activation == "gelu":
+        return gelu_erf(y)
+    if activation == "relu":
+        return np.maximum(y, np.float32(0.0))
+    if activation in ("gelu_accurate", "gelu_fast"):      # modules.py:177-188
+        a = np.float32(math.sqrt(2.0 / math.pi))
+        return (np.float32(0.5) * y * (np.float32(1.0) + np.tanh(a * (y + np.float32(0.044715) * y * y * y)))).astype(np.float32)
+    if activation == "tanh":
+        return np.tanh(y).astype(np.float32)
+    if activation == "linear":
+        return y
+    raise RuntimeError(f"--activation-fn {activation} not supported")      # modules.py:237
+
+
 def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray]) -> np.ndarray:
     y = x.astype(np.float32, copy=False) @ w.T.astype(np.float32, copy=False)
     if b is not None:
@@ -349,7 +373,9 @@ def beats_forward(wav: np.ndarray, sd: Mapping[str, np.ndarray], cfg: Mapping[st
     E = int(cfg["encoder_embed_dim"]); H = int(cfg["encoder_attention_heads"]); L = int(cfg["encoder_layers"])
     D = int(cfg["embed_dim"]); P = int(cfg["input_patch_size"]); G = int(cfg["conv_pos_groups"])
     alpha = np.float32(math.pow(2.0 * L, 0.25)) if bool(cfg.get("deep_norm", True)) else np.float32(1.0)
-    assert not bool(cfg.get("layer_norm_first", False)), "oracle restates the post-LN (deep_norm) branch only"
+    pre_ln = bool(cfg.get("layer_norm_first", False))
+    assert not (pre_ln and bool(cfg.get("deep_norm", True))), "deep_norm and layer_norm_first exclude each other (beats.py:275)"
+    activation = str(cfg.get("activation_fn", "gelu"))
     taps: Dict[str, np.ndarray] = {}
 
     fb = beats_preprocess(wav, cfg)                                   # [B,frames,mel]
@@ -380,7 +406,8 @@ def beats_forward(wav: np.ndarray, sd: Mapping[str, np.ndarray], cfg: Mapping[st
                           p["encoder.pos_conv.0.parametrizations.weight.original1"])
     xc = pos_conv(x, wpc, p["encoder.pos_conv.0.bias"], G)                             # backbone.py:172-173
     x = x + xc                                                                         # backbone.py:174
-    x = layer_norm(x, p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])    # backbone.py:176-177
+    if not pre_ln:
+        x = layer_norm(x, p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])    # backbone.py:176-177
     if return_stages:
         taps["stage.pos_conv"] = xc; taps["stage.enc_in"] = x
 
@@ -390,16 +417,29 @@ def beats_forward(wav: np.ndarray, sd: Mapping[str, np.ndarray], cfg: Mapping[st
                                  int(cfg["num_buckets"]), int(cfg["max_distance"]))
     for i in range(L):
         pre = f"encoder.layers.{i}."
+        if pre_ln:                                                                      # backbone.py:328-348 (no DeepNorm scale here)
+            xn = layer_norm(x, p[pre + "self_attn_layer_norm.weight"], p[pre + "self_attn_layer_norm.bias"])
+            a = attention(xn, p, pre + "self_attn.", H, bias_hTT, bool(cfg.get("gru_rel_pos", True)), mask)
+            x = x + a
+            xn = layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
+            y = linear(ffn_hidden(xn, p, pre, activation), p[pre + "fc2.weight"], p[pre + "fc2.bias"])
+            taps[f"backbone.encoder.layers.{i}.fc2"] = y.copy()
+            x = x + y
+            if return_stages:
+                taps[f"stage.attn{i}"] = a; taps[f"stage.layer{i}"] = x
+            continue
         a = attention(x, p, pre + "self_attn.", H, bias_hTT, bool(cfg.get("gru_rel_pos", True)), mask)
         x = x * alpha + a                                                               # backbone.py:360
         x = layer_norm(x, p[pre + "self_attn_layer_norm.weight"], p[pre + "self_attn_layer_norm.bias"])
-        h = gelu_erf(linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"]))             # backbone.py:368
+        h = ffn_hidden(x, p, pre, activation)                                           # backbone.py:365-368
         y = linear(h, p[pre + "fc2.weight"], p[pre + "fc2.bias"])                       # backbone.py:370 (hook tap)
         taps[f"backbone.encoder.layers.{i}.fc2"] = y.copy()
         x = x * alpha + y                                                               # backbone.py:372
         x = layer_norm(x, p[pre + "final_layer_norm.weight"], p[pre + "final_layer_norm.bias"])
         if return_stages:
             taps[f"stage.attn{i}"] = a; taps[f"stage.layer{i}"] = x
+    if pre_ln:      # TransformerEncoder.forward, which BEATs.extract_features calls (beats.py:362-365), normalises after the stack
+        x = layer_norm(x, p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])    # backbone.py:146-147
     return x, taps
 
 

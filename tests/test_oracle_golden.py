@@ -181,3 +181,24 @@ def test_stft_oracle_matches_torch_stft():
     assert (np.diff(peaks) >= 0).all() and peaks[0] >= 0 and peaks[-1] <= 400
     y = O.audio_processor(x, n_fft=800, hop=160)
     assert y.shape == (2, 128, 101) and abs(float(y[0].min())) < 1e-7 and abs(float(y[0].max()) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("variant", sorted(synth.BEATS_VARIANTS))
+def test_config_space_variants(golden_dir, variant):
+    """BEATsConfig options no official checkpoint uses (pre-LN blocks, the other FFN activations, the gated linear unit, a
+    patch-embedding bias, no / ungated relative position bias, no post_extract_proj): the oracle against the real reference's outputs
+    (tests/golden/make_variant_goldens.py) on the small configurations of synth.BEATS_VARIANTS."""
+    g = np.load(f"{golden_dir}/variants.npz")
+    cfg = synth.BEATS_VARIANTS[variant]
+    sd = synth.beats_state_dict(cfg, seed=3)
+    x = synth.noise_clips(2, 32000, seed=13)
+    f, taps = O.beats_forward(x, sd, cfg)
+    assert rel_l2(f[:, ::3], g[f"{variant}.features_tok3"]) < 1e-5
+    assert rel_l2(O.pooled(f), g[f"{variant}.pooled"]) < 1e-5
+    for i in range(int(cfg["encoder_layers"])):
+        t = taps[f"backbone.encoder.layers.{i}.fc2"]
+        assert rel_l2(t[:, ::6], g[f"{variant}.fc2.{i}_tok6"]) < 1e-5
+        assert rel_l2(t.mean(1), g[f"{variant}.fc2.{i}_mean"]) < 2e-5
+    pm = np.zeros((2, 32000), bool); pm[1, 16000:] = True
+    fm, _ = O.beats_forward(x, sd, cfg, padding_mask=pm)
+    assert rel_l2(fm[:, ::3], g[f"{variant}.features_masked_tok3"]) < 1e-5
