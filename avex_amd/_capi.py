@@ -52,7 +52,12 @@ class BeatsConfig(C.Structure):
                 ("deep_norm", C.c_int32), ("num_mel_bins", C.c_int32), ("sample_frequency", C.c_float),
                 ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float), ("fbank_mean", C.c_float),
                 ("fbank_std", C.c_float), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32),
-                ("residual_dtype", C.c_int32)]
+                ("residual_dtype", C.c_int32), ("layer_norm_first", C.c_int32), ("activation_fn", C.c_int32),
+                ("conv_bias", C.c_int32)]
+
+
+# activation_fn codes of BeatsConfig (AVEXHIP_FFN_* in include/avexhip.h), keyed by get_activation_fn's names (modules.py:203-237)
+FFN_CODES = {"gelu": 0, "relu": 1, "gelu_accurate": 2, "gelu_fast": 2, "tanh": 3, "linear": 4, "glu": 5}
 
 
 class EatConfig(C.Structure):

@@ -80,12 +80,20 @@ class _SelfAttn(nn.Module):
             self.grep_linear = nn.Linear(E // H, 8)
 
 
+class _GLULinear(nn.Module):
+    """Holder giving ``fc1.linear.weight / .bias`` of the reference's ``GLU_Linear(E, F, "swish")`` (modules.py:150-153)."""
+
+    def __init__(self, E: int, F: int) -> None:
+        super().__init__()
+        self.linear = nn.Linear(E, 2 * F)
+
+
 class _Layer(nn.Module):
-    def __init__(self, E: int, F: int, H: int, table: Optional[nn.Embedding], gru: bool) -> None:
+    def __init__(self, E: int, F: int, H: int, table: Optional[nn.Embedding], gru: bool, glu: bool = False) -> None:
         super().__init__()
         self.self_attn = _SelfAttn(E, H, table, gru)
         self.self_attn_layer_norm = nn.LayerNorm(E)
-        self.fc1 = nn.Linear(E, F)
+        self.fc1 = _GLULinear(E, F) if glu else nn.Linear(E, F)      # backbone.py:296-299
         self.fc2 = nn.Linear(F, E)
         self.final_layer_norm = nn.LayerNorm(E)
 
@@ -105,7 +113,7 @@ class _Encoder(nn.Module):
         E, F, H = int(cfg["encoder_embed_dim"]), int(cfg["encoder_ffn_embed_dim"]), int(cfg["encoder_attention_heads"])
         self.pos_conv = nn.Sequential(_Parametrized(E, E // int(cfg["conv_pos_groups"]), int(cfg["conv_pos"])))
         table = nn.Embedding(int(cfg["num_buckets"]), H) if cfg.get("relative_position_embedding", True) else None
-        self.layers = nn.ModuleList([_Layer(E, F, H, table, bool(cfg.get("gru_rel_pos", True)))
+        self.layers = nn.ModuleList([_Layer(E, F, H, table, bool(cfg.get("gru_rel_pos", True)), str(cfg.get("activation_fn", "gelu")) == "glu")
                                      for _ in range(int(cfg["encoder_layers"]))])
         self.layer_norm = nn.LayerNorm(E)
 

@@ -207,7 +207,8 @@ struct avexhip_beats : avxh::HandleBase {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float alpha = 1.f;
     avexhip_fbank_plan* fb = nullptr;
-    void* w_patch = nullptr;
+    void* w_patch = nullptr; float* b_patch = nullptr;      // b_patch: conv_bias=True (beats.py:263-269), else NULL
+    bool pre_ln = false; int act = 1; bool glu = false;     // layer_norm_first / activation_fn of the config (CoreCfg)
     float* ln0_w = nullptr; float* ln0_b = nullptr;
     void* w_post = nullptr; float* b_post = nullptr;
     void* w_pc = nullptr; float* b_pc = nullptr;
@@ -220,6 +221,7 @@ struct avexhip_beats : avxh::HandleBase {
     CoreCfg core() const {
         CoreCfg c;
         c.E = E; c.F = F; c.H = H; c.L = L; c.alpha = alpha; c.eps = 1e-5f; c.hook_site = 0; c.fast = fast; c.fold = ln_fold;
+        c.act = act; c.glu = glu; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
         return c;
     }
     ~avexhip_beats() override {
@@ -274,6 +276,7 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
     }
 
     RC(dev_half(h, tb, "patch_embedding.weight", (int64_t)D * P * P, &h->w_patch));
+    if (c.conv_bias) RC(dev_f32(h, tb, "patch_embedding.bias", D, &h->b_patch));
     RC(dev_f32(h, tb, "layer_norm.weight", D, &h->ln0_w));
     RC(dev_f32(h, tb, "layer_norm.bias", D, &h->ln0_b));
     if (D != E || tb.find("post_extract_proj.weight")) {
@@ -475,7 +478,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         const bool hook0 = (hook_mask & 1u) != 0;
         avx::GemmArgs g;
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-        g.A = w.patches; g.lda = P * P; g.W = h->w_patch; g.ldw = P * P; g.M = M; g.N = D; g.K = P * P;
+        g.A = w.patches; g.lda = P * P; g.W = h->w_patch; g.ldw = P * P; g.M = M; g.N = D; g.K = P * P; g.bias = h->b_patch;
         if (fast) { g.out_half = w.h0; g.ldh = D; } else { g.out_f32 = w.f0; g.ldo = D; }
         prof.begin("gemm.patch_embed", 2.0 * Md * D * P * P);
         RC(avx::gemm(g, dt, cs));
@@ -507,11 +510,13 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         prof.begin("posconv", 2.0 * Md * E * (E / h->cfg.conv_pos_groups) * h->cfg.conv_pos);
         RC(avx::posconv(w.core.xh, fast ? nullptr : x32, h->w_pc, h->b_pc, Bc, Tt, E, h->cfg.conv_pos_groups, h->cfg.conv_pos, pre32, preh, dt, cs));
         prof.end();
-        prof.begin("layernorm", 0.0);
-        RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.core.xh, E, dt, cs));
-        prof.end();
+        if (!h->pre_ln) {      // pre-LN models normalise after the stack instead (backbone.py:146-147, 176-177); their stream stays in pre32 / preh
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(pre32, preh, E, h->lnE_w, h->lnE_b, 1e-5f, M, E, fast ? nullptr : x32, E, w.core.xh, E, dt, cs));
+            prof.end();
+        }
 
-        // 4. transformer layers (post-LN DeepNorm branch, backbone.py:350-375): avxh::run_layers; hook i + 1 = layer i's raw fc2 output
+        // 4. transformer layers (backbone.py:328-375, post-LN / DeepNorm or pre-LN): avxh::run_layers; hook i + 1 = layer i's raw fc2 output
         CoreIo io;
         io.Bc = Bc; io.Tt = Tt; io.c0 = (size_t)c0; io.bias_tab = bias_tab; io.pad = pad; io.hook_mask = hook_mask; io.hook_bit0 = 1;
         io.hook_out = hook_out; io.hook_pooled = hook_pooled; io.features_out = features_out; io.pooled_out = pooled_out;
@@ -566,6 +571,14 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
         avexhip_set_error("beats_create: positional conv must be k=128 with 48 channels/group (k=%d groups=%d)", c.conv_pos, c.conv_pos_groups);
         return nullptr;
     }
+    if (c.activation_fn < AVEXHIP_FFN_GELU || c.activation_fn > AVEXHIP_FFN_GLU) {
+        avexhip_set_error("beats_create: unknown activation_fn code %d", c.activation_fn);
+        return nullptr;
+    }
+    if (c.layer_norm_first && c.deep_norm) {      // the reference asserts the same (beats.py:275)
+        avexhip_set_error("beats_create: deep_norm and layer_norm_first exclude each other");
+        return nullptr;
+    }
     if (c.encoder_layers < 0 || c.encoder_layers > 31) {
         avexhip_set_error("beats_create: encoder_layers=%d out of range", c.encoder_layers);
         return nullptr;
@@ -586,7 +599,17 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
         // The encoder's LayerNorms are folded into the GEMM epilogues around them (GemmArgs) unless AVEX_AMD_LN_FOLD=0: 24 LayerNorm
         // launches and 9 GB of traffic per 256-clip step disappear, +2.7 % (9 367 -> 9 623 clips/s alternating inside one process,
         // profiles/r03a_ln_fold.txt) and one rounding of the residual stream less per sublayer.
-        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && !(e && atoi(e) == 0);
+        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && !(e && atoi(e) == 0) &&
+                     !c.layer_norm_first && c.activation_fn == AVEXHIP_FFN_GELU;      // the fold is built for post-LN blocks with a GELU FFN
+    }
+    h->pre_ln = c.layer_norm_first != 0;
+    h->glu = c.activation_fn == AVEXHIP_FFN_GLU;
+    switch (c.activation_fn) {      // GemmArgs::gelu codes
+        case AVEXHIP_FFN_GELU: h->act = 1; break;
+        case AVEXHIP_FFN_RELU: h->act = 3; break;
+        case AVEXHIP_FFN_GELU_TANH: h->act = 4; break;
+        case AVEXHIP_FFN_TANH: h->act = 5; break;
+        default: h->act = 0; break;      // linear; glu applies its own gate after fc1
     }
     {
         // Independent chunks of a batch can overlap on several HIP streams: one chunk's HBM-bound kernels

@@ -150,6 +150,24 @@ static __device__ __forceinline__ f32x4 silu4(f32x4 v) {
     return (f32x4){a[0], a[1], b[0], b[1]};
 }
 static __device__ __forceinline__ f32x4 act4(f32x4 v, int act) { return act == 2 ? silu4(v) : gelu_erf4(v); }
+// every activation code of GemmArgs::gelu (the generic epilogues; the streaming kernel's fast epilogue takes 1 and 2 only):
+// 3 = ReLU, 4 = tanh-form GELU (the reference's gelu_accurate, modules.py:177-188), 5 = tanh
+static __device__ __forceinline__ float tanh_fast(float x) {      // 1 - 2 / (1 + e^{2x}); saturates cleanly at +-1
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+static __device__ __forceinline__ f32x4 act4_any(f32x4 v, int act) {
+    if (act <= 2) return act4(v, act);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];
+        if (act == 3) r[e] = __builtin_fmaxf(x, 0.f);
+        else if (act == 4) r[e] = 0.5f * x * (1.0f + tanh_fast(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+        else r[e] = tanh_fast(x);
+    }
+    return r;
+}
 
 // x[0] + x[1] as ONE plain v_add_f32 the compiler cannot merge with a neighbour into a packed add with swapped halves
 // (v_pk_add_f32 ... op_sel:[0,1] is wrong beside MFMA work on gfx950, avex_amd/isa_lint.py).
@@ -278,6 +296,9 @@ int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, fl
 int token_embed_ln(const void* patches, const float* pos, const float* cls, const float* w, const float* b, float eps, int B, int Tp, int C,
                    void* out_half, float* out_f32, int dtype, hipStream_t s);
 // rows with pad[m] != 0 set to zero in the fp32 and / or the operand-type copy (either may be NULL)
+// out[m][f] = in[m][f] * swish(in[m][F + f]) for a [M, 2F] half matrix: the second half of the reference's GLU_Linear(E, F, "swish")
+// (modules.py:155-171); values that leave the f16 range count into *ovf (may be NULL)
+int glu_swish(const void* in, int64_t M, int F, void* out, unsigned int* ovf, int dtype, hipStream_t s);
 int zero_rows(float* x32, int64_t ld32, void* x_half, int64_t ldh, int M, int C, const uint8_t* pad, hipStream_t s);
 // final LayerNorm + mean over tokens in one pass (half rows in, [B, C] fp32 out); C % 8 == 0, C <= 768
 int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int B, int T, int C, float* out, int dtype,

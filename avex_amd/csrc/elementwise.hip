@@ -387,6 +387,30 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ x32,
     }
 }
 
+// GLU_Linear's gate (modules.py:155-171, glu_type "swish"): out[m][f] = y[m][f] * swish(y[m][F + f]); 8 elements per thread
+template <typename T>
+__global__ __launch_bounds__(256) void glu_swish_kernel(const T* __restrict__ in, int64_t M, int F, T* __restrict__ out, unsigned int* __restrict__ ovf) {
+    typedef typename Half<T>::v8 v8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int f8 = F >> 3;
+    float mx = 0.f;
+    if (idx < M * f8) {
+        const int64_t m = idx / f8;
+        const int f = (int)(idx - m * f8) * 8;
+        const v8 a = *(const v8*)(in + m * 2 * F + f), g = *(const v8*)(in + m * 2 * F + F + f);
+        v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gv = (float)g[e];
+            const float r = (float)a[e] * (gv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gv)));
+            ovf_see<T>(mx, r, 0.f);
+            o[e] = Half<T>::from(r);
+        }
+        *(v8*)(out + m * F + f) = o;
+    }
+    ovf_commit<T>(ovf, mx);
+}
+
 // s[n] = sum_k float(W[n][k]) of a half matrix (fp32 accumulate): the column-sum vector of a LayerNorm-folded weight
 template <typename T>
 __global__ __launch_bounds__(256) void row_sum_half_kernel(const T* __restrict__ w, int N, int K, float* __restrict__ out) {
@@ -556,6 +580,19 @@ int token_embed_ln(const void* patches, const float* pos, const float* cls, cons
         hipLaunchKernelGGL(token_embed_ln_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)patches, pos, cls, w, b, eps, Tp, C, rows, (__bf16*)out_half, out_f32);
     else {
         avexhip_set_error("token_embed_ln: unknown dtype %d", dtype);
+        return AVEXHIP_ERR_INVALID;
+    }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int glu_swish(const void* in, int64_t M, int F, void* out, unsigned int* ovf, int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && out && M > 0 && F > 0 && F % 8 == 0, "glu_swish: bad arguments (M=%lld F=%d)", (long long)M, F);
+    const dim3 grid((unsigned)((M * (F / 8) + 255) / 256));
+    if (dtype == AVEXHIP_F16) hipLaunchKernelGGL(glu_swish_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)in, M, F, (_Float16*)out, ovf);
+    else if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(glu_swish_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)in, M, F, (__bf16*)out, ovf);
+    else {
+        avexhip_set_error("glu_swish: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;
     }
     AVX_LAUNCH_CHECK();

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
                 const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v = r * alpha + v;
             }
-            if (p.gelu) v = act4(v, p.gelu);
+            if (p.gelu) v = act4_any(v, p.gelu);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
                 ovf_see4<T>(ovf_mx, v);
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                                     v1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[4 + e], st.x, st.y), lg1[e], lb1[e]) + a1[e];
                                 }
                             }
-                            if (p.gelu) { v0 = act4(v0, p.gelu); v1 = act4(v1, p.gelu); }
+                            if (p.gelu) { v0 = act4_any(v0, p.gelu); v1 = act4_any(v1, p.gelu); }
                             if (p.out_f32) {
                                 st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0, p.nt);
                                 st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1, p.nt);
@@ -804,7 +804,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         const char* fgen = getenv("AVEX_AMD_GEMM_GENERIC");
         const bool force_generic = fgen && atoi(fgen) != 0;     // tests: cross-check of the fast epilogues
         const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero && !force_generic;
-        const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out;
+        const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out && a.gelu <= 2;      // the fast epilogue knows GELU and SiLU only
         const bool fast_resid = plain_out && (a.resid_half || a.lnr_y) && !a.gelu && !a.ln_rows;
         if (fast_half) return a.ln_rows ? launch256<T, 1, 1>(a5, grid, s) : launch256<T, 1, 0>(a5, grid, s);
         if (fast_resid) {

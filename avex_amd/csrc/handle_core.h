@@ -296,7 +296,11 @@ struct CoreCfg {
     float alpha = 1.f, eps = 1e-5f;
     int hook_site = 0;            // 0: fc2's raw output, 1: the attention output projection's raw output
     bool fast = false;            // residual stream / pre-LN sums in the operand type
-    bool fold = false;            // fast mode: the LayerNorms between the GEMMs folded into their epilogues
+    bool fold = false;            // fast mode: the LayerNorms between the GEMMs folded into their epilogues (post-LN, GELU / SiLU FFN only)
+    int act = 1;                  // GemmArgs::gelu code of the FFN activation (0 none, 1 erf GELU, 2 SiLU, 3 ReLU, 4 tanh GELU, 5 tanh)
+    bool glu = false;             // fc1 is the reference's GLU_Linear(E, F, "swish"): one Linear to 2F, then value * swish(gate) (backbone.py:296-297)
+    bool pre_ln = false;          // pre-LN blocks (backbone.py:328-348): x += attn(LN1 x); x += ffn(LN2 x); `final_ln` after the stack (:146-147)
+    const float* final_ln_w = nullptr; const float* final_ln_b = nullptr;
 };
 
 // upload layer i (and, with the fold, its LayerNorm-folded copies; layer i - 1 must have been built)
@@ -336,8 +340,9 @@ inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, con
     }
     RC(dev_f32(h, tb, fmt_name(nm.ln1, i, ".weight"), E, &ly.ln1_w));
     RC(dev_f32(h, tb, fmt_name(nm.ln1, i, ".bias"), E, &ly.ln1_b));
-    RC(dev_half(h, tb, fmt_name(nm.fc1, i, ".weight"), (int64_t)F * E, &ly.w_fc1));
-    RC(dev_f32(h, tb, fmt_name(nm.fc1, i, ".bias"), F, &ly.b_fc1));
+    const int F1 = c.glu ? 2 * F : F;      // GLU_Linear keeps its Linear(E, 2F) under ".linear"
+    RC(dev_half(h, tb, fmt_name(nm.fc1, i, c.glu ? ".linear.weight" : ".weight"), (int64_t)F1 * E, &ly.w_fc1));
+    RC(dev_f32(h, tb, fmt_name(nm.fc1, i, c.glu ? ".linear.bias" : ".bias"), F1, &ly.b_fc1));
     RC(dev_half(h, tb, fmt_name(nm.fc2, i, ".weight"), (int64_t)E * F, &ly.w_fc2));
     RC(dev_f32(h, tb, fmt_name(nm.fc2, i, ".bias"), E, &ly.b_fc2));
     RC(dev_f32(h, tb, fmt_name(nm.ln2, i, ".weight"), E, &ly.ln2_w));
@@ -371,6 +376,7 @@ inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, con
 // ---------------------------------------------------------------------------------------------
 struct CoreWs {
     float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
+    char* hh2;                // GLU: fc1's [M, 2F] output before the gate
     float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
     float* r1; float* r2;     // ... reduced to (rstd, -mu rstd) per row by avx::ln_rowstats
 };
@@ -386,6 +392,7 @@ inline CoreWs carve_core(const CoreCfg& c, size_t M, Take&& take) {
     w.qkv = (char*)take(M * 3 * c.E * 2);
     w.ah = (char*)take(M * c.E * 2);
     w.hh = (char*)take(M * c.F * 2);
+    w.hh2 = (char*)take(c.glu ? M * c.F * 4 : 256);
     w.raw = (float*)take(M * c.E * 4);
     w.st1 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
     w.st2 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
@@ -408,12 +415,107 @@ struct CoreIo {
     float* final_f32 = nullptr;           // out: where the fp32 features of this chunk were written (caller's buffer or w.x), NULL if nowhere
 };
 
+// fc1 (+ activation) of a prepared GemmArgs `g` (A, W, bias, fold fields set; N = F, output w.hh): plain, or the gated linear unit
+inline int ffn_hidden(HandleBase* h, const CoreCfg& c, const CoreWs& w, avx::GemmArgs& g, int M, Prof& prof, hipStream_t cs) {
+    const double flops = 2.0 * (double)M * (c.glu ? 2 * c.F : c.F) * c.E;
+    int rc;
+    if (c.glu) { g.N = 2 * c.F; g.gelu = 0; g.out_half = w.hh2; g.ldh = 2 * c.F; }
+    prof.begin("gemm.fc1", flops);
+    rc = avx::gemm(g, h->dtype, cs);
+    prof.end();
+    if (rc != AVEXHIP_OK || !c.glu) return rc;
+    prof.begin("glu", 0.0);
+    rc = avx::glu_swish(w.hh2, M, c.F, w.hh, h->d_ovf, h->dtype, cs);
+    prof.end();
+    return rc;
+}
+
+// Pre-LN blocks (backbone.py:328-348).  The un-normalised stream starts in w.pre (fp32 residual stream) / w.preh (fast) -- where the
+// positional convolution left x + pos_conv(x) -- and is back there after every layer; each LayerNorm writes the GEMM operand to w.ah.
+inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<Layer>& layers, const CoreWs& w, CoreIo& io, Prof& prof, hipStream_t cs) {
+    const int E = c.E, F = c.F, H = c.H, L = c.L, dt = h->dtype, Bc = io.Bc, Tt = io.Tt;
+    const int M = Bc * Tt;
+    const double Md = (double)M;
+    const bool fast = c.fast;
+    float* s0_32 = fast ? nullptr : w.pre;  void* s0_h = fast ? w.preh : nullptr;      // stream at layer boundaries
+    float* s1_32 = fast ? nullptr : w.x;    void* s1_h = fast ? w.xh : nullptr;        // stream after the attention block
+    int rc;
+#define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
+    avx::GemmArgs g;
+    io.final_f32 = nullptr;
+    for (int i = 0; i < L; ++i) {
+        const Layer& ly = layers[i];
+        const bool hooked = (io.hook_mask >> (io.hook_bit0 + i)) & 1u;
+        float* tap = nullptr;
+        if (hooked) tap = io.hook_pooled ? w.raw : io.hook_out[io.hook_bit0 + i] + io.c0 * Tt * E;
+        prof.begin("layernorm", 0.0);
+        RC(avx::layernorm(s0_32, s0_h, E, ly.ln1_w, ly.ln1_b, c.eps, M, E, nullptr, E, w.ah, E, dt, cs));
+        prof.end();
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.ah; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
+        g.out_half = w.qkv; g.ldh = 3 * E;
+        prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
+        RC(avx::attention(w.qkv, Bc, Tt, H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, dt, cs, h->q_log2e ? 1 : 0));
+        prof.end();
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = c.alpha;
+        if (fast) { g.resid_half = s0_h; g.ldrh = E; g.out_half = s1_h; g.ldh = E; }
+        else { g.resid = s0_32; g.ldr = E; g.out_f32 = s1_32; g.ldo = E; }
+        if (hooked && c.hook_site == 1) { g.out_raw = tap; g.ldraw = E; }
+        prof.begin("gemm.out_proj", 2.0 * Md * E * E);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        if (hooked && c.hook_site == 1 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        prof.begin("layernorm", 0.0);
+        RC(avx::layernorm(s1_32, s1_h, E, ly.ln2_w, ly.ln2_b, c.eps, M, E, nullptr, E, w.ah, E, dt, cs));
+        prof.end();
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.ah; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = c.act;
+        g.out_half = w.hh; g.ldh = F;
+        RC(ffn_hidden(h, c, w, g, M, prof, cs));
+        memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
+        g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
+        if (fast) { g.resid_half = s1_h; g.ldrh = E; g.out_half = s0_h; g.ldh = E; }
+        else { g.resid = s1_32; g.ldr = E; g.out_f32 = s0_32; g.ldo = E; }
+        if (hooked && c.hook_site == 0) { g.out_raw = tap; g.ldraw = E; }
+        prof.begin("gemm.fc2", 2.0 * Md * E * F);
+        RC(avx::gemm(g, dt, cs));
+        prof.end();
+        if (hooked && c.hook_site == 0 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+    }
+    if (L > 0 && (io.features_out || io.pooled_out)) {      // the encoder's LayerNorm after the stack (backbone.py:146-147)
+        const bool fused_pool = io.pooled_out && !io.features_out && fast && E % 8 == 0 && E <= 768 && Bc >= 32;
+        if (fused_pool) {
+            prof.begin("layernorm+mean_pool", 0.0);
+            RC(avx::layernorm_pool(s0_h, E, c.final_ln_w, c.final_ln_b, c.eps, Bc, Tt, E, io.pooled_out + io.c0 * E, dt, cs));
+            prof.end();
+        } else {
+            float* xo = io.features_out ? io.features_out + io.c0 * Tt * E : w.x;
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(s0_32, s0_h, E, c.final_ln_w, c.final_ln_b, c.eps, M, E, xo, E, nullptr, E, dt, cs));
+            prof.end();
+            io.final_f32 = xo;
+            if (io.pooled_out) {
+                prof.begin("mean_pool", 0.0);
+                RC(avx::mean_pool(xo, Bc, Tt, E, nullptr, io.pooled_out + io.c0 * E, cs));
+                prof.end();
+            }
+        }
+    }
+#undef RC
+    return AVEXHIP_OK;
+}
+
 // x (the encoder input after its own LayerNorm) is in w.xh (fast) / w.x + w.xh (fp32 residual stream); runs the L layers and the outputs
 inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>& layers, const CoreWs& w, CoreIo& io, Prof& prof, hipStream_t cs) {
     const int E = c.E, F = c.F, H = c.H, L = c.L, dt = h->dtype, Bc = io.Bc, Tt = io.Tt;
     const int M = Bc * Tt;
     const double Md = (double)M;
     const bool fast = c.fast;
+    if (c.pre_ln) return run_layers_pre_ln(h, c, layers, w, io, prof, cs);
     float* x32 = w.x;
     float* pre32 = fast ? nullptr : w.pre;
     void* preh = fast ? w.preh : nullptr;
@@ -468,12 +570,10 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             prof.end();
         }
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-        g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = 1;
+        g.A = w.xh; g.lda = E; g.W = ly.w_fc1; g.ldw = E; g.M = M; g.N = F; g.K = E; g.bias = ly.b_fc1; g.gelu = c.act;
         g.out_half = w.hh; g.ldh = F;
         if (fold) { g.A = preh; g.W = ly.w_fc1_f; g.bias = ly.b_fc1_f; g.ln_rows = w.r1; g.ln_s = ly.s_fc1; }
-        prof.begin("gemm.fc1", 2.0 * Md * F * E);
-        RC(avx::gemm(g, dt, cs));
-        prof.end();
+        RC(ffn_hidden(h, c, w, g, M, prof, cs));
         const bool last = i == L - 1;
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;

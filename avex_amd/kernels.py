@@ -556,13 +556,15 @@ RESIDUAL_CODES = {"f32": 0, "fp32": 0, "float32": 0, "half": 1, "f16": 1, "bf16"
 
 def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0,
                       residual="half") -> BeatsConfig:
-    if bool(cfg.get("layer_norm_first", False)):
-        raise AvexHipError("layer_norm_first=True (pre-LN) BEATs variants are not built; only the post-LN/DeepNorm branch")
-    if str(cfg.get("activation_fn", "gelu")) != "gelu":
-        raise AvexHipError(f"activation_fn={cfg.get('activation_fn')!r} is not built; only exact-erf gelu")
-    if bool(cfg.get("conv_bias", False)):
-        raise AvexHipError("conv_bias=True patch embedding is not built")
+    act = str(cfg.get("activation_fn", "gelu"))
+    if act not in _capi.FFN_CODES:
+        raise RuntimeError(f"--activation-fn {act} not supported")      # the reference's own error (modules.py:237)
+    if bool(cfg.get("layer_norm_first", False)) and bool(cfg.get("deep_norm", True)):
+        raise AssertionError("deep_norm and layer_norm_first exclude each other (beats.py:275)")
     c = BeatsConfig()
+    c.layer_norm_first = int(bool(cfg.get("layer_norm_first", False)))
+    c.activation_fn = _capi.FFN_CODES[act]
+    c.conv_bias = int(bool(cfg.get("conv_bias", False)))
     for f in _CFG_FIELDS:
         setattr(c, f, int(cfg[f]))
     if not bool(cfg.get("relative_position_embedding", True)):

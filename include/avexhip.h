@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 5
+#define AVEXHIP_ABI_VERSION 6
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -216,7 +216,8 @@ typedef struct {
     const float* bias;
     const float* resid; int64_t ldr; float alpha;   /* fp32 residual, or ... */
     const void*  resid_half; int64_t ldrh;          /* ... residual in the operand type (resid == NULL) */
-    int32_t gelu;                      /* activation after bias (+ residual): 0 none, 1 exact-erf GELU, 2 SiLU */
+    int32_t gelu;                      /* activation after bias (+ residual): 0 none, 1 exact-erf GELU, 2 SiLU, 3 ReLU,
+                                          4 tanh-form GELU (modules.py:177-188), 5 tanh */
     float* out_f32;  int64_t ldo;
     void*  out_half; int64_t ldh;
     float* out_raw;  int64_t ldraw;
@@ -336,7 +337,21 @@ typedef struct {
                                         error 4e-4); 1: kept in the operand type (1.5e-3 frame level, pooled
                                         unchanged at 2.8e-4, ~25 % less HBM traffic).  Hook taps and the
                                         features output are fp32 either way. */
+    /* ABI 6: the rest of BEATsConfig's architecture switches (beats.py:181-196); zero = the official checkpoints' values */
+    int32_t layer_norm_first;        /* 0: post-LN blocks (backbone.py:350-375); 1: pre-LN blocks + LayerNorm after the stack
+                                        (backbone.py:328-348, 146-147); excludes deep_norm (beats.py:275) */
+    int32_t activation_fn;           /* AVEXHIP_FFN_* below (modules.py:203-237) */
+    int32_t conv_bias;               /* 1: the patch embedding has a bias ("patch_embedding.bias", beats.py:263-269) */
 } avexhip_beats_config;
+
+/* activation_fn of the config: get_activation_fn's names (modules.py:203-237).  GLU = fc1 replaced by GLU_Linear(E, F, "swish")
+ * (backbone.py:296-297): weights "fc1.linear.weight" [2F, E] / "fc1.linear.bias" [2F], hidden = y[:, :F] * swish(y[:, F:]). */
+#define AVEXHIP_FFN_GELU 0       /* "gelu": exact erf form (default) */
+#define AVEXHIP_FFN_RELU 1       /* "relu" */
+#define AVEXHIP_FFN_GELU_TANH 2  /* "gelu_accurate" / "gelu_fast": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) */
+#define AVEXHIP_FFN_TANH 3       /* "tanh" */
+#define AVEXHIP_FFN_LINEAR 4     /* "linear" */
+#define AVEXHIP_FFN_GLU 5        /* "glu" */
 
 /* Weight table entry: reference state-dict key ("backbone." prefix optional), fp32 data
  * (host or device pointer), element count.  (avex/models/utils/load.py:521-570 ingest.) */

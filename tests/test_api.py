@@ -184,8 +184,13 @@ def test_padding_mask_geometry(beats_cpu):
 
 
 def test_unsupported_variants_fail_loudly():
-    with pytest.raises(AvexHipError):
-        avex_amd.beats_model.Model(device="cpu", init_config=dict(synth.BEATS_BASE_CFG, layer_norm_first=True, deep_norm=False))
+    # the reference's own refusals, with its exception types: an activation get_activation_fn does not know (modules.py:237) and
+    # deep_norm together with layer_norm_first (beats.py:275).  Pre-LN, the other activations, glu and conv_bias are built (ABI 6).
+    with pytest.raises(RuntimeError):
+        avex_amd.beats_model.Model(device="cpu", init_config=dict(synth.BEATS_BASE_CFG, activation_fn="swish"))
+    with pytest.raises(AssertionError):
+        avex_amd.beats_model.Model(device="cpu", init_config=dict(synth.BEATS_BASE_CFG, layer_norm_first=True, deep_norm=True))
+    avex_amd.beats_model.Model(device="cpu", init_config=dict(synth.BEATS_BASE_CFG, layer_norm_first=True, deep_norm=False))
     with pytest.raises(FileNotFoundError):
         avex_amd.beats_model.Model(device="cpu", pretrained=True)
 

@@ -211,3 +211,24 @@ def test_efficientnet_model_on_gpu(built_lib, tmp_path):
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+@pytest.mark.parametrize("variant", ["preln_relu_convbias", "postln_glu_nogate"])
+def test_config_space_variants_through_the_model_class(built_lib, golden_dir, variant):
+    """A BEATsConfig the official checkpoints do not use, through the plugin class: init_config -> parameter tree with the reference's
+    key names (fc1.linear.* for glu, patch_embedding.bias) -> load_state_dict -> forward / hooks, against the real reference's outputs
+    (tests/golden/make_variant_goldens.py)."""
+    gv = np.load(f"{golden_dir}/variants.npz")
+    cfg = synth.BEATS_VARIANTS[variant]
+    m = avex_amd.beats_model.Model(device="cuda", init_config=cfg, return_features_only=True).eval()
+    sd = {k: torch.from_numpy(v) for k, v in synth.beats_state_dict(cfg, seed=3).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {"backbone.fbank.window", "backbone.fbank.mel_fb"}
+    x = torch.from_numpy(synth.noise_clips(2, 32000, seed=13)).cuda()
+    f = m(x)
+    assert rel_l2(f.mean(1).cpu().numpy(), gv[f"{variant}.pooled"]) < TOL
+    assert rel_l2(f[:, ::3].cpu().numpy(), gv[f"{variant}.features_tok3"]) < 4 * TOL
+    assert m.register_hooks_for_layers(["last_layer"]) == ["backbone.encoder.layers.1.fc2"]
+    e = m.extract_embeddings(x, aggregation="mean")
+    assert rel_l2(e.cpu().numpy(), gv[f"{variant}.fc2.1_mean"]) < 2 * TOL
+    m.deregister_all_hooks()

@@ -284,3 +284,47 @@ def test_bias_table_cache_is_bounded_and_eviction_is_invisible(built_lib, base_s
     again = enc.forward(x0, want_features=False, want_pooled=True)["pooled"]
     assert torch.equal(first, again)
     enc.close()
+
+
+@pytest.mark.parametrize("mode", ["f16-f32", "f16-half", "bf16-half"])
+@pytest.mark.parametrize("variant", sorted(synth.BEATS_VARIANTS))
+def test_config_space_variants(built_lib, golden_dir, variant, mode):
+    """BEATsConfig options no official checkpoint uses (beats.py:181-196): pre-LN blocks with the LayerNorm after the stack, ReLU / tanh-form
+    GELU / tanh / linear FFNs, the gated linear unit, a patch-embedding bias, no / ungated relative position bias, no post_extract_proj.
+    The HIP handle against the REAL reference's outputs (tests/golden/make_variant_goldens.py; the oracle is pinned to the same file in
+    tests/test_oracle_golden.py), features, pooled, every hook tap and the half-padded batch."""
+    from avex_amd import kernels as K
+    dt, res = mode.split("-")
+    g = np.load(f"{golden_dir}/variants.npz")
+    cfg = synth.BEATS_VARIANTS[variant]
+    sd = synth.beats_state_dict(cfg, seed=3)
+    L = int(cfg["encoder_layers"])
+    has_post = int(cfg["embed_dim"]) != int(cfg["encoder_embed_dim"])
+    enc = K.BeatsEncoder(cfg, sd, operand_dtype=dt, residual=res)
+    try:
+        x = torch.from_numpy(synth.noise_clips(2, 32000, seed=13)).cuda()
+        hooks = list(range(1, L + 1))
+        r = enc.forward(x, hook_layers=hooks, want_features=True, want_pooled=True)
+        tol = POOLED_TOL[dt]
+        feats = r["features"].cpu().numpy()
+        assert feats.shape == (2, 96, int(cfg["encoder_embed_dim"]))
+        assert rel_l2(r["pooled"].cpu().numpy(), g[f"{variant}.pooled"]) < tol
+        assert rel_l2(feats[:, ::3], g[f"{variant}.features_tok3"]) < 4 * tol
+        for i in range(L):
+            tap = r["hooks"][i + 1].cpu().numpy()
+            assert rel_l2(tap.mean(1), g[f"{variant}.fc2.{i}_mean"]) < 2 * tol
+            assert rel_l2(tap[:, ::6], g[f"{variant}.fc2.{i}_tok6"]) < 4 * tol
+        if not has_post:
+            with pytest.raises(K.AvexHipError):
+                enc.forward(x, hook_layers=[0], want_pooled=True)
+        pm = np.zeros((2, 32000), bool); pm[1, 16000:] = True
+        frames = 1 + (32000 - 400) // 160
+        fpad = O.forward_padding_mask(96, O.forward_padding_mask(frames, pm))
+        rm = enc.forward(x, want_features=True, frame_pad=torch.from_numpy(fpad))
+        assert rel_l2(rm["features"].cpu().numpy()[:, ::3], g[f"{variant}.features_masked_tok3"]) < 4 * tol
+        # pooled-only path at a batch the fused LayerNorm + mean kernel takes (>= 32 clips): every clip equals its single-clip run
+        xb = x[:1].repeat(33, 1)
+        pb = enc.forward(xb, want_pooled=True)["pooled"].cpu().numpy()
+        assert rel_l2(pb[-1:], g[f"{variant}.pooled"][:1]) < tol
+    finally:
+        enc.close()
