@@ -140,6 +140,11 @@ SYMBOLS = {
                                         C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "avexhip_beats_forward_fbank": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_uint32, C.POINTER(_P), C.c_int,
                                               _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_beats_graph_capture": (_P, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_uint32, C.POINTER(_P),
+                                         C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_beats_graph_launch": (C.c_int, [_P, _P]),
+    "avexhip_beats_graph_nodes": (C.c_int, [_P]),
+    "avexhip_beats_graph_destroy": (None, [_P]),
     "avexhip_beats_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
     "avexhip_beats_overflow_reset": (C.c_int, [_P, _P]),
     "avexhip_beats_set_profiling": (C.c_int, [_P, C.c_int]),

@@ -202,6 +202,7 @@ struct avexhip_beats : avxh::HandleBase {
     bool fast = false;   // residual stream / pre-LN sums in the operand type
     bool ln_fold = false;  // fast mode: LayerNorms between the GEMMs folded into their epilogues
     int nstreams = 1;    // chunks of one forward run concurrently on this many streams (caller's + side streams)
+    bool capturing = false;    // a forward being recorded into a hipGraph: one lane, no lazily created objects
     bool fe_in_lane = true;    // frontend of a chunk on the chunk's own lane stream (AVEX_AMD_FRONTEND_IN_LANE=0: all frontends before the fork)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -413,7 +414,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total * (size_t)lanes);
         return AVEXHIP_ERR_WORKSPACE;
     }
-    if (h->profiling) lanes = 1;   // per-kernel event timing needs the kernels alone on the device
+    if (h->profiling || h->capturing) lanes = 1;   // per-kernel event timing needs the kernels alone on the device; a captured forward is one stream
     float* bias_tab = nullptr;
     int rc = bias_tab_for(h, Tt, &bias_tab);
     if (rc != AVEXHIP_OK) return rc;
@@ -682,6 +683,83 @@ extern "C" int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank,
     return forward_impl(h, nullptr, fbank, B, 0, 0, frames, frame_pad, hook_mask, hook_out, hook_pooled, features_out, pooled_out,
                         workspace, ws_bytes, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// A forward recorded as a hipGraph.  At small batch the path is launch-bound (about 95 kernels of a few microseconds each for one
+// clip); replaying the recorded graph submits them in one call.
+// ---------------------------------------------------------------------------------------------
+struct avexhip_beats_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    size_t nodes = 0;
+    ~avexhip_beats_graph() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+};
+
+extern "C" avexhip_beats_graph* avexhip_beats_graph_capture(avexhip_beats* h, const float* wav, int B, int64_t T, int64_t wav_stride,
+                                                            const uint8_t* frame_pad, uint32_t hook_mask, float* const* hook_out, int hook_pooled,
+                                                            float* features_out, float* pooled_out, void* workspace, size_t ws_bytes, void* stream) {
+    if (!h || !wav || B <= 0 || T <= 0) {
+        avexhip_set_error("beats_graph_capture: null handle / input or empty batch");
+        return nullptr;
+    }
+    if (h->profiling) {
+        avexhip_set_error("beats_graph_capture: the handle is in profiling mode (events cannot be recorded into a graph)");
+        return nullptr;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) {
+        avexhip_set_error("beats_graph_capture: the default (NULL) stream cannot be captured; pass a stream created with hipStreamCreate");
+        return nullptr;
+    }
+    if (wav_stride <= 0) wav_stride = T;
+    const int frames = avexhip_fbank_num_frames(h->fb, T);
+    // 1. an ordinary forward first: everything created lazily (the bias table of this token count, per-kernel LDS attributes, the
+    //    compute-unit count) exists afterwards, so the recorded pass allocates nothing
+    h->capturing = true;
+    int rc = forward_impl(h, wav, nullptr, B, T, wav_stride, frames, frame_pad, hook_mask, hook_out, hook_pooled, features_out, pooled_out,
+                          workspace, ws_bytes, s);
+    if (rc == AVEXHIP_OK && hipStreamSynchronize(s) != hipSuccess) { avexhip_set_error("beats_graph_capture: the warm-up forward failed"); rc = AVEXHIP_ERR_HIP; }
+    if (rc != AVEXHIP_OK) { h->capturing = false; return nullptr; }
+    // 2. the same forward again, recorded
+    avexhip_beats_graph* g = new avexhip_beats_graph();
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        avexhip_set_error("beats_graph_capture: hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+        h->capturing = false;
+        delete g;
+        return nullptr;
+    }
+    rc = forward_impl(h, wav, nullptr, B, T, wav_stride, frames, frame_pad, hook_mask, hook_out, hook_pooled, features_out, pooled_out,
+                      workspace, ws_bytes, s);
+    e = hipStreamEndCapture(s, &g->graph);      // always ends the capture, also after an error inside it
+    h->capturing = false;
+    if (rc != AVEXHIP_OK || e != hipSuccess || !g->graph) {
+        if (rc == AVEXHIP_OK) avexhip_set_error("beats_graph_capture: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        delete g;
+        return nullptr;
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        avexhip_set_error("beats_graph_capture: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        delete g;
+        return nullptr;
+    }
+    (void)hipGraphGetNodes(g->graph, nullptr, &g->nodes);
+    return g;
+}
+
+extern "C" int avexhip_beats_graph_launch(avexhip_beats_graph* g, void* stream) {
+    AVX_REQUIRE(g && g->exec, "beats_graph_launch: null graph");
+    AVX_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return AVEXHIP_OK;
+}
+
+extern "C" int avexhip_beats_graph_nodes(const avexhip_beats_graph* g) { return g ? (int)g->nodes : 0; }
+
+extern "C" void avexhip_beats_graph_destroy(avexhip_beats_graph* g) { delete g; }
 
 extern "C" int avexhip_beats_overflow_count(avexhip_beats* h, uint32_t* events, void* sync_stream, int synchronize) {
     AVX_REQUIRE(h && events, "overflow_count: null argument");

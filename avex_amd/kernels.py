@@ -618,6 +618,61 @@ def handle_profile(fn, h) -> List[Tuple[str, float, float]]:
     return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
 
 
+class BeatsGraph:
+    """A recorded forward of a ``BeatsEncoder`` at one input shape.  ``wav`` (and ``frame_pad`` when asked for) are the graph's static
+    inputs: write the next batch INTO them (``g.wav.copy_(x)``), call ``replay()``, read ``features`` / ``pooled`` / ``hooks[i]`` --
+    the same tensors every time, overwritten by the next replay.  Replays are ordered on the current stream like any kernel."""
+
+    def __init__(self, enc: "BeatsEncoder", B: int, T: int, hook_layers, hook_pooled, want_features, want_pooled, with_frame_pad, dev) -> None:
+        self._enc = enc          # keeps the handle alive
+        Tt = enc.num_tokens(T)
+        if B <= 0 or Tt <= 0:
+            raise AvexHipError(f"input too short: {T} samples give {Tt} tokens")
+        self.tokens = Tt
+        self.wav = torch.zeros((B, T), dtype=torch.float32, device=dev)
+        self.frame_pad = torch.zeros((B, Tt), dtype=torch.uint8, device=dev) if with_frame_pad else None
+        need = int(lib().avexhip_beats_workspace_bytes(enc._h, B, T))
+        self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)      # the graph's own: the encoder's may be reallocated
+        self.hooks: Dict[int, torch.Tensor] = {}
+        self._ptrs = (C.c_void_p * (enc.L + 1))()
+        mask = 0
+        for i in sorted(set(int(x) for x in hook_layers)):
+            if not 0 <= i <= enc.L:
+                raise ValueError(f"hook layer {i} out of range 0..{enc.L}")
+            self.hooks[i] = torch.empty((B, enc.E) if hook_pooled else (B, Tt, enc.E), dtype=torch.float32, device=dev)
+            self._ptrs[i] = int(self.hooks[i].data_ptr())
+            mask |= 1 << i
+        self.features = torch.empty((B, Tt, enc.E), dtype=torch.float32, device=dev) if want_features else None
+        self.pooled = torch.empty((B, enc.E), dtype=torch.float32, device=dev) if want_pooled else None
+        # the default stream cannot be captured: record on a side stream that follows / is followed by the current one
+        side = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._g = lib().avexhip_beats_graph_capture(enc._h, _ptr(self.wav), B, T, T, _ptr(self.frame_pad), mask, self._ptrs, int(hook_pooled),
+                                                        _ptr(self.features), _ptr(self.pooled), _ptr(self._ws), self._ws.numel(), _stream())
+        cur.wait_stream(side)
+        if not self._g:
+            raise AvexHipError(f"beats_graph_capture failed: {_capi.last_error()}")
+        self.nodes = int(lib().avexhip_beats_graph_nodes(self._g))
+
+    def replay(self) -> "BeatsGraph":
+        check(lib().avexhip_beats_graph_launch(self._g, _stream()), "beats_graph_launch")
+        return self
+
+    def close(self) -> None:
+        if getattr(self, "_g", None):
+            torch.cuda.synchronize()
+            lib().avexhip_beats_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class BeatsEncoder:
     """Owns an ``avexhip_beats`` handle built from an fp32 state dict (torch tensors or numpy arrays,
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
@@ -710,6 +765,15 @@ class BeatsEncoder:
                                                   want_pooled=want_pooled, frame_pad=frame_pad)
                 warnings.warn(msg, RuntimeWarning, stacklevel=2)
         return {"features": feats, "pooled": pooled, "hooks": hooks, "tokens": Tt}
+
+    def capture(self, batch: int, samples: int, *, hook_layers: Sequence[int] = (), hook_pooled: bool = False,
+                want_features: bool = True, want_pooled: bool = False, with_frame_pad: bool = False,
+                device: Optional[torch.device] = None) -> "BeatsGraph":
+        """Record the forward for ``[batch, samples]`` inputs as a hipGraph (``avexhip_beats_graph_capture``) with its own static input,
+        output and workspace tensors; see ``BeatsGraph``.  For small batches, where the ~95 launches of a forward cost more than the
+        kernels: one clip 1.7 ms -> see profiles/."""
+        return BeatsGraph(self, batch, samples, hook_layers, hook_pooled, want_features, want_pooled, with_frame_pad,
+                          device or torch.device("cuda", torch.cuda.current_device()))
 
     def overflow_events(self, sync: bool = True) -> int:
         """The handle's sticky range-alarm count (0 = no f16 conversion ever clipped); ``sync`` waits for the current stream first."""

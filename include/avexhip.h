@@ -387,6 +387,22 @@ int avexhip_beats_forward_fbank(avexhip_beats* h, const float* fbank_dev, int B,
                                 int hook_pooled, float* features_out, float* pooled_out,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* A forward recorded as a hipGraph (ABI 6).  At small batch the path is launch-bound (about 95 kernels of a few microseconds each for
+ * one clip); graph_capture runs the forward described by its arguments once (so that nothing is created lazily afterwards), records
+ * the same forward from `stream` (not the NULL stream) with hipStreamBeginCapture / EndCapture and instantiates it; graph_launch
+ * replays it on any stream.
+ * Every pointer is baked into the graph: the caller keeps wav_dev, the outputs, frame_pad and the workspace alive at the same
+ * addresses and refills wav_dev in place between launches.  The handle must not be in profiling mode; the recorded forward runs on
+ * one stream whatever AVEX_AMD_STREAMS says.  The range alarm's host mirror is part of the graph.  Returns NULL on error. */
+typedef struct avexhip_beats_graph avexhip_beats_graph;
+avexhip_beats_graph* avexhip_beats_graph_capture(avexhip_beats* h, const float* wav_dev, int B, int64_t T, int64_t wav_stride,
+                                                 const uint8_t* frame_pad, uint32_t hook_mask, float* const* hook_out,
+                                                 int hook_pooled, float* features_out, float* pooled_out, void* workspace,
+                                                 size_t workspace_bytes, void* stream);
+int avexhip_beats_graph_launch(avexhip_beats_graph* g, void* stream);
+int avexhip_beats_graph_nodes(const avexhip_beats_graph* g);      /* kernel / copy nodes recorded */
+void avexhip_beats_graph_destroy(avexhip_beats_graph* g);
+
 /* Per-stage timing of the most recent forward on this handle is available when the handle was put
  * in profiling mode (HIP events on the launch stream; forces a stream sync at the end of forward).
  * names/ms arrays are library-owned and valid until the next forward. */

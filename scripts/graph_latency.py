@@ -1,30 +1,56 @@
 #!/usr/bin/env python3
-"""Small-batch latency with the forward captured in a HIP graph (torch.cuda.CUDAGraph stream capture of the C-ABI launches)."""
+"""Small batches are launch-bound: the eager forward (one C call, ~95 kernel launches) against the same forward replayed from a
+hipGraph (BeatsEncoder.capture), milliseconds per call, 10 s clips, pooled output only."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from avex_amd import synth, kernels as K
+
+
+def timeit(fn, n):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
 cfg = synth.BEATS_BASE_CFG
 enc = K.BeatsEncoder(cfg, synth.beats_state_dict(cfg, seed=0), operand_dtype="f16", residual="half")
-for B in (1, 4, 16):
+print("batch | eager ms/call  clips/s | graph ms/call  clips/s | nodes | speed-up | latency of ONE synchronous call: eager, graph (ms)")
+for B in (1, 2, 4, 8, 16, 32, 64):
     wav = (0.1 * torch.randn(B, 160000)).cuda()
-    for _ in range(3): ref = enc.forward(wav, want_features=False, want_pooled=True)["pooled"].clone()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        enc.forward(wav, want_features=False, want_pooled=True)
-    torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
-        out = enc.forward(wav, want_features=False, want_pooled=True)["pooled"]
-    g.replay(); torch.cuda.synchronize()
-    ok = torch.equal(out, ref)
-    t0 = time.perf_counter(); n = 50
-    for _ in range(n): g.replay()
-    torch.cuda.synchronize(); dg = (time.perf_counter() - t0) / n
-    t0 = time.perf_counter()
-    for _ in range(n): enc.forward(wav, want_features=False, want_pooled=True)
-    torch.cuda.synchronize(); de = (time.perf_counter() - t0) / n
-    print(f"batch {B:2d}: eager {1e3*de:.2f} ms, graph replay {1e3*dg:.2f} ms, identical output: {ok}")
+    g = enc.capture(B, 160000, want_features=False, want_pooled=True)
+    g.wav.copy_(wav)
+    te = timeit(lambda: enc.forward(wav, want_features=False, want_pooled=True), 50)
+    tg = timeit(lambda: g.replay(), 50)
+
+    def sync_call(fn):
+        ts = []
+        for _ in range(20):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+    le = sync_call(lambda: enc.forward(wav, want_features=False, want_pooled=True))
+    lg = sync_call(lambda: g.replay())
+
+    def host_cost(fn):      # time the submitting thread spends inside the call (device idle before, not waited for after)
+        ts = []
+        for _ in range(20):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        return sorted(ts)[len(ts) // 2]
+    he = host_cost(lambda: enc.forward(wav, want_features=False, want_pooled=True))
+    hg = host_cost(lambda: g.replay())
+    print(f"{B:5d} | {1e3*te:8.3f} {B/te:9.0f} | {1e3*tg:8.3f} {B/tg:9.0f} | {g.nodes:5d} | {te/tg:5.2f}x | {1e3*le:.3f} {1e3*lg:.3f} | host thread inside the call: {1e3*he:.3f} {1e3*hg:.3f} ms")
+    g.close()
