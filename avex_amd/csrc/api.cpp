@@ -201,6 +201,7 @@ struct avexhip_beats : avxh::HandleBase {
     int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 256;
     bool fast = false;   // residual stream / pre-LN sums in the operand type
     bool ln_fold = false;  // fast mode: LayerNorms between the GEMMs folded into their epilogues
+    int ln_fold_min_rows = 0;   // ... for chunks of at least this many rows (avxh::fold_policy)
     int nstreams = 1;    // chunks of one forward run concurrently on this many streams (caller's + side streams)
     bool capturing = false;    // a forward being recorded into a hipGraph: one lane, no lazily created objects
     bool fe_in_lane = true;    // frontend of a chunk on the chunk's own lane stream (AVEX_AMD_FRONTEND_IN_LANE=0: all frontends before the fork)
@@ -222,7 +223,7 @@ struct avexhip_beats : avxh::HandleBase {
     CoreCfg core() const {
         CoreCfg c;
         c.E = E; c.F = F; c.H = H; c.L = L; c.alpha = alpha; c.eps = 1e-5f; c.hook_site = 0; c.fast = fast; c.fold = ln_fold;
-        c.act = act; c.glu = glu; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
+        c.fold_min_rows = ln_fold_min_rows; c.act = act; c.glu = glu; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
         return c;
     }
     ~avexhip_beats() override {
@@ -596,12 +597,11 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     h->fast = c.residual_dtype != 0;
     {
-        const char* e = getenv("AVEX_AMD_LN_FOLD");
         // The encoder's LayerNorms are folded into the GEMM epilogues around them (GemmArgs) unless AVEX_AMD_LN_FOLD=0: 24 LayerNorm
         // launches and 9 GB of traffic per 256-clip step disappear, +2.7 % (9 367 -> 9 623 clips/s alternating inside one process,
-        // profiles/r03a_ln_fold.txt) and one rounding of the residual stream less per sublayer.
-        h->ln_fold = h->fast && c.encoder_embed_dim % 256 == 0 && c.encoder_ffn_embed_dim % 256 == 0 && !(e && atoi(e) == 0) &&
-                     !c.layer_norm_first && c.activation_fn == AVEXHIP_FFN_GELU;      // the fold is built for post-LN blocks with a GELU FFN
+        // profiles/r03a_ln_fold.txt) and one rounding of the residual stream less per sublayer.  Built for post-LN blocks with a GELU FFN.
+        avxh::fold_policy(h->fast, c.encoder_embed_dim, c.encoder_ffn_embed_dim, &h->ln_fold, &h->ln_fold_min_rows);
+        if (c.layer_norm_first || c.activation_fn != AVEXHIP_FFN_GELU) h->ln_fold = false;
     }
     h->pre_ln = c.layer_norm_first != 0;
     h->glu = c.activation_fn == AVEXHIP_FFN_GLU;

@@ -45,10 +45,6 @@ int chunk_for(int max_chunk_clips, int B, int Tt) {
     return B < cap ? B : cap;
 }
 
-bool fold_enabled(bool fast, int E, int F) {
-    const char* e = getenv("AVEX_AMD_LN_FOLD");
-    return fast && E % 256 == 0 && F % 256 == 0 && !(e && atoi(e) == 0);
-}
 
 void hann_window(int win, std::vector<float>& w) {      // torch.hann_window(win, periodic=False), the kaldi "hanning" window
     w.resize(win);
@@ -181,7 +177,7 @@ extern "C" avexhip_eat* avexhip_eat_create(const avexhip_eat_config* cfg, const 
     h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.depth;
     h->core.alpha = 1.0f; h->core.eps = c.norm_eps > 0.f ? c.norm_eps : 1e-6f; h->core.hook_site = 1;
     h->core.fast = c.residual_dtype != 0;
-    h->core.fold = fold_enabled(h->core.fast, c.embed_dim, c.ffn_dim);
+    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
     h->P = c.patch_size;
     h->n_patches = (c.target_length / 16) * (c.n_mels / 16);
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
@@ -431,7 +427,7 @@ extern "C" avexhip_aves* avexhip_aves_create(const avexhip_aves_config* cfg, con
     h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.num_layers;
     h->core.alpha = 1.0f; h->core.eps = 1e-5f; h->core.hook_site = 0;
     h->core.fast = c.residual_dtype != 0;
-    h->core.fold = fold_enabled(h->core.fast, c.embed_dim, c.ffn_dim);
+    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 64;       // layer 0 of the extractor holds 32 MB per 10 s clip
     if (h->init_alarm() != AVEXHIP_OK || aves_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
     return h;
