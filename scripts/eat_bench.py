@@ -19,3 +19,8 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 fl = 2 * 512 * 256 * 768 + 12 * (2 * 513 * 768 * (2304 + 768 + 3072 + 3072) + 4 * 513 * 513 * 768)
 print(f"EAT-base B={B} x 5 s: {1e3*dt:.1f} ms/step, {B/dt:.0f} clips/s, {B*fl/dt/1e12:.0f} TFLOP/s ({fl/1e9:.1f} GFLOP/clip); "
       f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB; out {tuple(out.shape)}")
+enc.set_profiling(True)
+step()
+torch.cuda.synchronize()
+print("stages (ms, serialised HIP events): " + "  ".join(f"{n} {ms:.3f}" for n, ms, _ in enc.last_profile()))
+enc.set_profiling(False)
