@@ -58,7 +58,11 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     g.resid_half = a->resid_half; g.ldrh = a->ldrh;
     g.out_f32 = a->out_f32; g.ldo = a->ldo; g.out_half = a->out_half; g.ldh = a->ldh;
     g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
+    g.pool_part = a->pool_part; g.pool_T = a->pool_rows;
     return avx::gemm(g, dtype, (hipStream_t)stream);
+}
+extern "C" int avexhip_pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, void* stream) {
+    return avx::pool_reduce(part, B, T, N, out, ldo, (hipStream_t)stream);
 }
 extern "C" int avexhip_ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, void* stream) {
     return avx::ln_rowstats(stats, M, nseg, eps, rows, (hipStream_t)stream);

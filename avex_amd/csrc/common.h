@@ -272,6 +272,11 @@ struct GemmArgs {
     int lnr_prefolded;        // lnr_gamma holds alpha * gamma and lnr_beta holds alpha * beta + bias (what the kernel takes; avx::lnr_fold makes them).
                               // avx::gemm folds per launch when the flag is clear; callers that launch the same fold repeatedly keep the vectors
     float* stats_out;         // [M][N/64][2] or NULL
+    // Mean-pooled hook tap without the tap: the rows are clips of pool_T (>= 64) consecutive rows; each 64-row block writes the column
+    // sums of acc + bias (what out_raw would hold) over its rows, split at the one clip boundary it can contain:
+    // pool_part[block][slot][N], slot 0 = the clip of the block's first row, slot 1 = the next clip.  avx::pool_reduce adds a clip's
+    // blocks in order and divides by pool_T.  256-tile kernel, generic epilogue.
+    float* pool_part; int pool_T;
     // sticky range alarm: the number of (lane, launch) pairs that rounded at least one |value| > 65504 to an f16 output is added
     // here (one atomic per wave at most, at the end of the kernel); NULL = not counted.  bf16 outputs cannot overflow.
     unsigned int* ovf;
@@ -281,6 +286,8 @@ struct GemmArgs {
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // fp32 NHWC rows [B * HW, ld] -> NCHW [B, C, HW], optionally undoing a folded BatchNorm: (x - shift[c]) / scale[c] (effnet.hip)
 int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s);
+// GemmArgs::pool_part [ceil(M / 64)][2][N] -> out[b][n] = mean over clip b's T rows (b < B, M = B * T), blocks added in order
+int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s);
 // partial statistics [M][nseg][2] (GemmArgs::stats_out) -> [M][2] (rstd, -mu * rstd), summed in segment order (deterministic)
 int ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, hipStream_t s);
 // ga = alpha * gamma, bb = bias + alpha * beta: the column vectors a residual-side fold takes (GemmArgs::lnr_prefolded)

@@ -438,6 +438,19 @@ __global__ __launch_bounds__(256) void ln_rowstats_kernel(const float* __restric
     ((float2*)rows)[m] = make_float2(rstd, -mu * rstd);
 }
 
+// GemmArgs::pool_part -> per-clip means: one thread per (clip, column); a clip's 64-row blocks are added in increasing order
+__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int B, int T, int N, float* __restrict__ out, int64_t ldo) {
+    const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (n >= N) return;
+    const int64_t r0 = (int64_t)b * T, r1 = r0 + T - 1;
+    float acc = 0.f;
+    for (int64_t rb = r0 >> 6; rb <= (r1 >> 6); ++rb) {
+        const int64_t first_clip = (rb * 64) / T;       // the clip of the block's first row owns slot 0
+        acc += part[(rb * 2 + (first_clip == b ? 0 : 1)) * N + n];
+    }
+    out[(int64_t)b * ldo + n] = acc * (1.0f / (float)T);
+}
+
 // column vectors of a residual-side LayerNorm fold: ga = alpha * gamma, bb = bias + alpha * beta (GemmArgs::lnr_prefolded)
 __global__ __launch_bounds__(256) void lnr_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias, float alpha,
                                                         int N, float* __restrict__ ga, float* __restrict__ bb) {
@@ -582,6 +595,13 @@ int token_embed_ln(const void* patches, const float* pos, const float* cls, cons
         avexhip_set_error("token_embed_ln: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;
     }
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s) {
+    AVX_REQUIRE(part && out && B > 0 && T >= 64 && N > 0, "pool_reduce: bad arguments (B=%d T=%d N=%d)", B, T, N);
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, part, B, T, N, out, ldo);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }

@@ -667,6 +667,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
                 f32x4 ls0 = b0, ls1 = b0, lg0 = b0, lg1 = b0, lb0 = b0, lb1 = b0;     // folded-LayerNorm column vectors (see GemmArgs)
+                // pool_part: column sums of the raw tap over this wave's 64 rows, split at the one clip boundary a 64-row block can hold
+                f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = pa0, pb0 = pa0, pb1 = pa0;
+                const int pool_rb = (em0 + wn * 64) >> 6;
+                const int pool_bnd = p.pool_part ? (pool_rb * 64 / p.pool_T + 1) * p.pool_T : 0;      // first row of the block's second clip
                 if (p.ln_rows) { ls0 = *(const f32x4*)(p.ln_s + nb); ls1 = *(const f32x4*)(p.ln_s + nb + 4); }
                 if (p.lnr_y) {      // (the launcher has folded alpha into gamma and alpha * beta into the bias: GemmArgs::lnr_prefolded)
                     lg0 = *(const f32x4*)(p.lnr_gamma + nb); lg1 = *(const f32x4*)(p.lnr_gamma + nb + 4);
@@ -702,6 +706,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                             if (p.out_raw) {
                                 st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0, p.nt);
                                 st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1, p.nt);
+                            }
+                            if (p.pool_part) {
+                                if (m < pool_bnd) { pa0 += v0; pa1 += v1; } else { pb0 += v0; pb1 += v1; }
                             }
                             if (p.resid) {
                                 const f32x4 r0 = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + nb);
@@ -745,6 +752,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                if (p.pool_part) {
+                    // the 8 lanes with the same (lane & 7) hold the same 8 columns of different rows: add them in a fixed order
+                    // (xor 8, 16, 32), then lanes 0..7 write the block's two slots
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int sh = 8; sh <= 32; sh <<= 1) {
+                            pa0[e] += __shfl_xor(pa0[e], sh, 64); pa1[e] += __shfl_xor(pa1[e], sh, 64);
+                            pb0[e] += __shfl_xor(pb0[e], sh, 64); pb1[e] += __shfl_xor(pb1[e], sh, 64);
+                        }
+                    }
+                    if (er == 0 && pool_rb * 64 < p.M) {
+                        float* dst = p.pool_part + ((int64_t)pool_rb * 2) * p.N + nb;
+                        *(f32x4*)dst = pa0; *(f32x4*)(dst + 4) = pa1;
+                        *(f32x4*)(dst + p.N) = pb0; *(f32x4*)(dst + p.N + 4) = pb1;
+                    }
+                }
             }
         }
         ovf_lanes |= ovf_mask<T>(ovf_mx);
@@ -786,6 +810,11 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         AVX_REQUIRE(a.variant == 0 || a.variant == 2 || a.variant == 5, "gemm: folded LayerNorm is built for the 256-tile kernel only");
         variant = 5;
     }
+    if (a.pool_part) {
+        AVX_REQUIRE(a.pool_T >= 64, "gemm: pool_part needs clips of at least 64 rows (got %d)", a.pool_T);
+        AVX_REQUIRE((a.variant == 0 || a.variant == 2 || a.variant == 5) && a.N % T2 == 0 && a.K >= 2 * BK, "gemm: pool_part is built for the 256-tile kernel only");
+        variant = 5;
+    }
     if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
     if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 5 : 3;
     if (variant == 2) variant = 5;
@@ -803,7 +832,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         if (const char* fg = getenv("AVEX_AMD_GEMM_GRID")) { const int g = atoi(fg); if (g >= 8) grid = (g / 8) * 8; }   // tests: force many tiles per workgroup
         const char* fgen = getenv("AVEX_AMD_GEMM_GENERIC");
         const bool force_generic = fgen && atoi(fgen) != 0;     // tests: cross-check of the fast epilogues
-        const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.resid && !a.row_zero && !force_generic;
+        const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.pool_part && !a.resid && !a.row_zero && !force_generic;
         const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out && a.gelu <= 2;      // the fast epilogue knows GELU and SiLU only
         const bool fast_resid = plain_out && (a.resid_half || a.lnr_y) && !a.gelu && !a.ln_rows;
         if (fast_half) return a.ln_rows ? launch256<T, 1, 1>(a5, grid, s) : launch256<T, 1, 0>(a5, grid, s);

@@ -390,6 +390,7 @@ inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, con
 struct CoreWs {
     float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
     char* hh2;                // GLU: fc1's [M, 2F] output before the gate
+    float* pool;              // mean-pooled hook taps: per-block column sums [ceil(M / 64)][2][E] (GemmArgs::pool_part)
     float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
     float* r1; float* r2;     // ... reduced to (rstd, -mu rstd) per row by avx::ln_rowstats
 };
@@ -406,6 +407,7 @@ inline CoreWs carve_core(const CoreCfg& c, size_t M, Take&& take) {
     w.ah = (char*)take(M * c.E * 2);
     w.hh = (char*)take(M * c.F * 2);
     w.hh2 = (char*)take(c.glu ? M * c.F * 4 : 256);
+    w.pool = (float*)take(((M + 63) / 64) * 2 * (size_t)c.E * 4);
     w.raw = (float*)take(M * c.E * 4);
     w.st1 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
     w.st2 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
@@ -427,6 +429,31 @@ struct CoreIo {
     float* pooled_out = nullptr;          // caller's [B, E] (mean over the Tt tokens) or NULL
     float* final_f32 = nullptr;           // out: where the fp32 features of this chunk were written (caller's buffer or w.x), NULL if nowhere
 };
+
+// A hooked GEMM: the raw tap goes to the caller's [B, T, E] buffer, or -- mean-pooled taps of clips with >= 64 tokens on the 256-tile
+// kernel -- never exists: the epilogue leaves per-block column sums and tap_finish reduces them to [B, E].  Shorter clips / narrow
+// outputs write the tap to scratch and pool it from there.
+struct Tap {
+    bool hooked = false, fused = false;
+    float* out = nullptr;      // caller's buffer for this chunk
+};
+inline Tap tap_begin(const CoreCfg& c, const CoreWs& w, const CoreIo& io, int layer, avx::GemmArgs& g) {
+    Tap t;
+    t.hooked = (io.hook_mask >> (io.hook_bit0 + layer)) & 1u;
+    if (!t.hooked) return t;
+    const size_t per_clip = io.hook_pooled ? (size_t)c.E : (size_t)io.Tt * c.E;
+    t.out = io.hook_out[io.hook_bit0 + layer] + io.c0 * per_clip;
+    static const bool no_fuse = getenv("AVEX_AMD_POOL_FUSE") && atoi(getenv("AVEX_AMD_POOL_FUSE")) == 0;
+    t.fused = io.hook_pooled && io.Tt >= 64 && c.E % 256 == 0 && g.K >= 128 && !no_fuse;
+    if (t.fused) { g.pool_part = w.pool; g.pool_T = io.Tt; }
+    else { g.out_raw = io.hook_pooled ? w.raw : t.out; g.ldraw = c.E; }
+    return t;
+}
+inline int tap_finish(const Tap& t, const CoreCfg& c, const CoreWs& w, const CoreIo& io, hipStream_t cs) {
+    if (!t.hooked || !io.hook_pooled) return AVEXHIP_OK;
+    if (t.fused) return avx::pool_reduce(w.pool, io.Bc, io.Tt, c.E, t.out, c.E, cs);
+    return avx::mean_pool(w.raw, io.Bc, io.Tt, c.E, nullptr, t.out, cs);
+}
 
 // fc1 (+ activation) of a prepared GemmArgs `g` (A, W, bias, fold fields set; N = F, output w.hh): plain, or the gated linear unit
 inline int ffn_hidden(HandleBase* h, const CoreCfg& c, const CoreWs& w, avx::GemmArgs& g, int M, Prof& prof, hipStream_t cs) {
@@ -458,9 +485,6 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
     io.final_f32 = nullptr;
     for (int i = 0; i < L; ++i) {
         const Layer& ly = layers[i];
-        const bool hooked = (io.hook_mask >> (io.hook_bit0 + i)) & 1u;
-        float* tap = nullptr;
-        if (hooked) tap = io.hook_pooled ? w.raw : io.hook_out[io.hook_bit0 + i] + io.c0 * Tt * E;
         prof.begin("layernorm", 0.0);
         RC(avx::layernorm(s0_32, s0_h, E, ly.ln1_w, ly.ln1_b, c.eps, M, E, nullptr, E, w.ah, E, dt, cs));
         prof.end();
@@ -477,11 +501,12 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = c.alpha;
         if (fast) { g.resid_half = s0_h; g.ldrh = E; g.out_half = s1_h; g.ldh = E; }
         else { g.resid = s0_32; g.ldr = E; g.out_f32 = s1_32; g.ldo = E; }
-        if (hooked && c.hook_site == 1) { g.out_raw = tap; g.ldraw = E; }
+        Tap tap_o;
+        if (c.hook_site == 1) tap_o = tap_begin(c, w, io, i, g);
         prof.begin("gemm.out_proj", 2.0 * Md * E * E);
         RC(avx::gemm(g, dt, cs));
         prof.end();
-        if (hooked && c.hook_site == 1 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        RC(tap_finish(tap_o, c, w, io, cs));
         prof.begin("layernorm", 0.0);
         RC(avx::layernorm(s1_32, s1_h, E, ly.ln2_w, ly.ln2_b, c.eps, M, E, nullptr, E, w.ah, E, dt, cs));
         prof.end();
@@ -493,11 +518,12 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
         if (fast) { g.resid_half = s1_h; g.ldrh = E; g.out_half = s0_h; g.ldh = E; }
         else { g.resid = s1_32; g.ldr = E; g.out_f32 = s0_32; g.ldo = E; }
-        if (hooked && c.hook_site == 0) { g.out_raw = tap; g.ldraw = E; }
+        Tap tap_f;
+        if (c.hook_site == 0) tap_f = tap_begin(c, w, io, i, g);
         prof.begin("gemm.fc2", 2.0 * Md * E * F);
         RC(avx::gemm(g, dt, cs));
         prof.end();
-        if (hooked && c.hook_site == 0 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        RC(tap_finish(tap_f, c, w, io, cs));
     }
     if (L > 0 && (io.features_out || io.pooled_out)) {      // the encoder's LayerNorm after the stack (backbone.py:146-147)
         const bool fused_pool = io.pooled_out && !io.features_out && fast && E % 8 == 0 && E <= 768 && Bc >= 32;
@@ -544,9 +570,6 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
     for (int i = 0; i < L; ++i) {
         const Layer& ly = layers[i];
         const bool raw_in = fold && i > 0;      // xh holds y2 of layer i-1 (raw) instead of its LayerNorm
-        const bool hooked = (io.hook_mask >> (io.hook_bit0 + i)) & 1u;
-        float* tap = nullptr;
-        if (hooked) tap = io.hook_pooled ? w.raw : io.hook_out[io.hook_bit0 + i] + io.c0 * Tt * E;
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.xh; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
         g.out_half = w.qkv; g.ldh = 3 * E;
@@ -568,11 +591,12 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
                 g.lnr_y = w.xh; g.ldy = E; g.lnr_rows = w.r2; g.lnr_gamma = ly.ga_o; g.lnr_beta = ly.bb_o; g.lnr_prefolded = 1;
             }
         }
-        if (hooked && c.hook_site == 1) { g.out_raw = tap; g.ldraw = E; }
+        Tap tap_o;
+        if (c.hook_site == 1) tap_o = tap_begin(c, w, io, i, g);
         prof.begin("gemm.out_proj", 2.0 * Md * E * E);
         RC(avx::gemm(g, dt, cs));
         prof.end();
-        if (hooked && c.hook_site == 1 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        RC(tap_finish(tap_o, c, w, io, cs));
         if (fold) {
             prof.begin("ln_rowstats", 0.0);
             RC(avx::ln_rowstats(w.st1, M, nseg, c.eps, w.r1, cs));
@@ -597,11 +621,12 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             g.lnr_y = preh; g.ldy = E; g.lnr_rows = w.r1; g.lnr_gamma = ly.ga_fc2; g.lnr_beta = ly.bb_fc2; g.lnr_prefolded = 1;
             g.out_half = w.xh; g.stats_out = !last ? w.st2 : nullptr;      // the last layer's y2 goes to a LayerNorm kernel that takes its own statistics
         }
-        if (hooked && c.hook_site == 0) { g.out_raw = tap; g.ldraw = E; }
+        Tap tap_f;
+        if (c.hook_site == 0) tap_f = tap_begin(c, w, io, i, g);
         prof.begin("gemm.fc2", 2.0 * Md * E * F);
         RC(avx::gemm(g, dt, cs));
         prof.end();
-        if (hooked && c.hook_site == 0 && io.hook_pooled) RC(avx::mean_pool(w.raw, Bc, Tt, E, nullptr, io.hook_out[io.hook_bit0 + i] + io.c0 * E, cs));
+        RC(tap_finish(tap_f, c, w, io, cs));
         if (fold && !last) {
             prof.begin("ln_rowstats", 0.0);
             RC(avx::ln_rowstats(w.st2, M, nseg, c.eps, w.r2, cs));

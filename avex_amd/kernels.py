@@ -383,11 +383,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
          lnr_y: Optional[torch.Tensor] = None, lnr_rows: Optional[torch.Tensor] = None,
          lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False,
          lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0,
-         overflow: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0) -> Dict[str, torch.Tensor]:
     """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_rows``/``ln_s`` fold a
     LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual (the ``*_rows`` tensors come from
     :func:`ln_rowstats`), ``stats_out`` returns the per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"``;
-    ``overflow`` is an optional ``uint32``/``int32`` device scalar the f16 range alarm adds to (include/avexhip.h)."""
+    ``overflow`` is an optional ``uint32``/``int32`` device scalar the f16 range alarm adds to (include/avexhip.h); ``pool_rows`` = T
+    treats the rows as clips of T rows and returns under ``"pooled"`` the per-clip mean of the raw output (bias added, before residual /
+    activation) without materialising it (``pool_part`` + ``avexhip_pool_reduce``)."""
     _need_cuda(a, w)
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise ValueError("a and w must both be float16 or bfloat16")
@@ -435,10 +437,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
         if overflow.numel() != 1 or overflow.element_size() != 4 or not overflow.is_cuda:
             raise ValueError("overflow must be a 4-byte device scalar")
         args.overflow_count = _ptr(overflow)
+    part = None
+    if pool_rows:
+        if M % pool_rows:
+            raise ValueError("pool_rows must divide the number of rows")
+        part = torch.full(((M + 63) // 64, 2, N), float("nan"), dtype=torch.float32, device=a.device)      # NaN: an unwritten slot that is read shows
+        args.pool_part, args.pool_rows = _ptr(part), int(pool_rows)
     if stats_out:
         res["stats"] = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=a.device)
         args.stats_out = _ptr(res["stats"])
     check(lib().avexhip_gemm(C.byref(args), code, _stream()), "gemm")
+    if part is not None:
+        res["pooled"] = torch.empty((M // pool_rows, N), dtype=torch.float32, device=a.device)
+        check(lib().avexhip_pool_reduce(_ptr(part), M // pool_rows, int(pool_rows), N, _ptr(res["pooled"]), N, _stream()), "pool_reduce")
     return res
 
 

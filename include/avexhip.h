@@ -241,8 +241,15 @@ typedef struct {
      * counter the number of lanes that rounded at least one |value| > 65504 to an f16 output (a lower bound of the number of
      * clipped elements; 0 = nothing clipped).  bf16 outputs cannot overflow and never count. */
     uint32_t* overflow_count;
+    /* ABI 6.  A mean-pooled hook tap without the tap (256-tile kernel): the M rows are clips of pool_rows (>= 64) consecutive rows;
+     * every 64-row block writes the column sums of acc + bias -- what out_raw would hold -- over its rows, split at the one clip
+     * boundary it can contain: pool_part[ceil(M / 64)][2][N] fp32 (slot 0 = the clip of the block's first row).
+     * avexhip_pool_reduce adds each clip's blocks in order and divides by pool_rows.  NULL = off. */
+    float* pool_part; int32_t pool_rows;
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
+/* pool_part as written through avexhip_gemm_args.pool_part -> out[b, n] = mean over clip b's T rows of the raw GEMM output (bit-reproducible). */
+int avexhip_pool_reduce(const float* part_dev, int B, int T, int N, float* out_dev, int64_t ldo, void* stream);
 /* stats [M][nseg][2] as written through avexhip_gemm_args.stats_out (nseg = row width / 64, even) -> rows [M][2] =
  * (rstd, -mean * rstd) with rstd = 1 / sqrt(var + eps); segments are added in order (bit-reproducible).  `rows` must be
  * readable up to M rounded up to an even number of rows. */

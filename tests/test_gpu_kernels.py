@@ -138,6 +138,43 @@ def test_gemm_persistent_walk_and_epilogues_agree(built_lib, dtype, shape, monke
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,grid", [(5, 496, 0), (3, 64, 0), (7, 100, 16), (2, 513, 0), (9, 65, 8), (1, 300, 0)])
+def test_gemm_pooled_tap(built_lib, dtype, B, T, grid, monkeypatch):
+    """A mean-pooled hook tap without the tap (avexhip_gemm_args.pool_part + avexhip_pool_reduce): per-clip means of acc + bias over
+    clips of T rows, from per-64-row-block column sums split at the clip boundary.  Clip lengths that put the boundary everywhere in a
+    block (64: never inside; 65, 100, 300, 496, 513), several tiles per workgroup, a residual and an f16 output alongside (the pooled
+    value is the raw tap, before the residual), against the mean of the materialised tap and an fp64 product."""
+    from avex_amd import kernels as K
+    if grid:
+        monkeypatch.setenv("AVEX_AMD_GEMM_GRID", str(grid))
+    N, Kd = 512, 256
+    M = B * T
+    a = round_half(synth.normal(f"plA{M}", (M, Kd), 1.0), dtype)
+    w = round_half(synth.normal("plW", (N, Kd), 0.06), dtype)
+    bias = synth.normal("plb", (N,), 0.3)
+    res = round_half(synth.normal(f"plR{M}", (M, N), 1.0), dtype)
+    td = _tdt(dtype)
+    r = K.gemm(_dev(a, td), _dev(w, td), bias=_dev(bias), resid_half=_dev(res, td), alpha=2.0, out_f32=False, out_half=True, pool_rows=T)
+    raw = K.gemm(_dev(a, td), _dev(w, td), bias=_dev(bias), resid_half=_dev(res, td), alpha=2.0, out_f32=False, out_half=True, out_raw=True)
+    assert torch.equal(r["half"], raw["half"])                          # the ordinary outputs do not notice
+    pooled = r["pooled"].cpu().numpy()
+    assert pooled.shape == (B, N) and np.isfinite(pooled).all()
+    assert rel_l2(pooled, raw["raw"].cpu().numpy().reshape(B, T, N).mean(1)) < 2e-6
+    want = (a.astype(np.float64) @ w.astype(np.float64).T + bias).reshape(B, T, N).mean(1)
+    assert rel_l2(pooled, want) < 1e-5
+    r2 = K.gemm(_dev(a, td), _dev(w, td), bias=_dev(bias), resid_half=_dev(res, td), alpha=2.0, out_f32=False, out_half=True, pool_rows=T)
+    assert torch.equal(r2["pooled"], r["pooled"])                       # blocks are added in a fixed order: reproducible bits
+
+
+def test_gemm_pooled_tap_refuses_short_clips(built_lib):
+    from avex_amd import kernels as K
+    from avex_amd._capi import AvexHipError
+    a = torch.zeros((128, 256), dtype=torch.float16, device="cuda"); w = torch.zeros((256, 256), dtype=torch.float16, device="cuda")
+    with pytest.raises(AvexHipError):
+        K.gemm(a, w, out_f32=False, out_half=True, pool_rows=32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M", [700, 1536, 1539])
 def test_gemm_folded_layernorm(built_lib, dtype, M, monkeypatch):
     """LayerNorm folded into the GEMMs around it (include/avexhip.h, avexhip_gemm_args): the producer writes raw rows y and
