@@ -985,74 +985,120 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 }
 
 // The last few query rows of a long clip (T = 512 n + r, r <= 32: EAT's 513 tokens, a 10.4 s BEATs clip): a whole query block of
-// the streamed kernel for them would cost as much as 512 rows.  One wave per (clip, head, row) instead: scores over all keys with
-// the lanes on the keys (K rows from L2), softmax through LDS, then the lanes on the 64 output dimensions.  Same arithmetic as the
-// main kernel (base-2 softmax, gate * bias, key mask), fp32 throughout except the operands and the stored output.
-template <typename T>
+// the streamed kernel for them would cost as much as 512 rows.  One wave per (clip, head, group of RW rows) instead: scores over all keys
+// with the lanes on the keys (every K row is read once for the RW rows), softmax through LDS, then the lanes on the 64 output dimensions
+// (every V row read once for the RW rows).  Same arithmetic as the main kernel (base-2 softmax, gate * bias, key mask), fp32 throughout
+// except the operands and the stored output.  RW = 1 is the single-row form (EAT's class-token row).
+template <typename T, int RW>
 __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict__ qkv, int Tn, int H, int T0, int R, const float* __restrict__ bias_tab,
                                                             const float* __restrict__ grep_w, const float* __restrict__ grep_b, const float* __restrict__ grep_a,
                                                             const uint8_t* __restrict__ key_pad, T* __restrict__ out, int q_log2e) {
-    extern __shared__ float sc[];                            // [Tn] scores, then probabilities; + 64 floats of q
-    float* qs = sc + Tn;
+    extern __shared__ float sc[];                            // [RW][Tn] scores, then probabilities; + [RW][64] floats of q + RW gates
+    float* qs = sc + RW * Tn;
     const int lane = threadIdx.x;
-    const int r = blockIdx.x % R, h = (blockIdx.x / R) % H, b = blockIdx.x / (R * H);
-    const int i = T0 + r;
+    const int G = (R + RW - 1) / RW;
+    const int grp = blockIdx.x % G, h = (blockIdx.x / G) % H, b = blockIdx.x / (G * H);
     const int E = H * 64;
     const int64_t ld = 3 * (int64_t)E;
     const T* base = qkv + (int64_t)b * Tn * ld + h * 64;
     const float NEG_INF = -__builtin_inff();
-    const float qv = (float)base[(int64_t)i * ld + lane];
-    qs[lane] = qv;
-    float gate = 1.f;
-    if (grep_w) {
-        const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;
-        const float wa = ((grep_w[0 * 64 + lane] + grep_w[1 * 64 + lane]) + (grep_w[2 * 64 + lane] + grep_w[3 * 64 + lane])) * ginv;
-        const float wb = ((grep_w[4 * 64 + lane] + grep_w[5 * 64 + lane]) + (grep_w[6 * 64 + lane] + grep_w[7 * 64 + lane])) * ginv;
-        const float sa = wave_sum(qv * wa) + ((grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]));
-        const float sb = wave_sum(qv * wb) + ((grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]));
-        const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
-        gate = ga * (gb * grep_a[h] - 1.f) + 2.f;
+    int ir[RW];                                              // query rows of this wave; rows past the end repeat the last one (computed, not stored)
+    float gate[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int i = T0 + grp * RW + r;
+        ir[r] = i < T0 + R ? i : T0 + R - 1;
+        const float qv = (float)base[(int64_t)ir[r] * ld + lane];
+        qs[r * 64 + lane] = qv;
+        gate[r] = 1.f;
+        if (grep_w) {
+            const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;
+            const float wa = ((grep_w[0 * 64 + lane] + grep_w[1 * 64 + lane]) + (grep_w[2 * 64 + lane] + grep_w[3 * 64 + lane])) * ginv;
+            const float wb = ((grep_w[4 * 64 + lane] + grep_w[5 * 64 + lane]) + (grep_w[6 * 64 + lane] + grep_w[7 * 64 + lane])) * ginv;
+            const float sa = wave_sum(qv * wa) + ((grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]));
+            const float sb = wave_sum(qv * wb) + ((grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]));
+            const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
+            gate[r] = ga * (gb * grep_a[h] - 1.f) + 2.f;
+        }
+        if (RW > 1 && lane == 0) qs[RW * 64 + r] = gate[r];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const float cs = q_log2e ? 0.125f : 0.125f * 1.4426950408889634f;
-    float mx = NEG_INF;
+    // scores: the lane's K row is converted once (64 registers) and meets the RW query rows one after the other; q is read from LDS as
+    // broadcast 16-byte vectors (kept there on purpose: in registers it would be 64 RW values per lane)
+#pragma unroll 1
     for (int j = lane; j < Tn; j += 64) {
         typedef typename Half<T>::v8 v8;
         const T* krow = base + (int64_t)j * ld + E;
-        float d = 0.f;
+        float kf[64];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const v8 kv = *(const v8*)(krow + 8 * c);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)kv[e], qs[8 * c + e], d);
+            for (int e = 0; e < 8; ++e) kf[8 * c + e] = (float)kv[e];
         }
-        float sv = d * cs;
-        if (bias_tab) sv = __builtin_fmaf(gate, bias_tab[(int64_t)h * (2 * Tn - 1) + (j - i) + (Tn - 1)] * 1.4426950408889634f, sv);
-        if (key_pad && key_pad[(int64_t)b * Tn + j]) sv = NEG_INF;
-        sc[j] = sv;
-        mx = fmaxf(mx, sv);
+        const bool padded = key_pad && key_pad[(int64_t)b * Tn + j];
+#pragma unroll 1
+        for (int r = 0; r < RW; ++r) {
+            const f32x4* q4 = (const f32x4*)(qs + r * 64);
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 q = q4[c];
+                d = __builtin_fmaf(kf[4 * c], q[0], d); d = __builtin_fmaf(kf[4 * c + 1], q[1], d);
+                d = __builtin_fmaf(kf[4 * c + 2], q[2], d); d = __builtin_fmaf(kf[4 * c + 3], q[3], d);
+            }
+            float sv = d * cs;
+            const int i = T0 + grp * RW + r < T0 + R ? T0 + grp * RW + r : T0 + R - 1;
+            const float gt = RW == 1 ? gate[0] : qs[RW * 64 + r];
+            if (bias_tab) sv = __builtin_fmaf(gt, bias_tab[(int64_t)h * (2 * Tn - 1) + (j - i) + (Tn - 1)] * 1.4426950408889634f, sv);
+            if (padded) sv = NEG_INF;
+            sc[r * Tn + j] = sv;
+        }
     }
-    mx = wave_max(mx);
-    if (mx == NEG_INF) mx = 0.f;                             // every key masked: all probabilities 0 (the division below gives NaN like the reference)
-    float l = 0.f;
-    for (int j = lane; j < Tn; j += 64) {
-        const float pj = __builtin_amdgcn_exp2f(sc[j] - mx);
-        sc[j] = (float)(T)pj;                                 // the numerator uses P rounded to the operand type, the row sum does not -- as in the main kernel
-        l += pj;
+    float l[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float mxr = NEG_INF;
+        for (int j = lane; j < Tn; j += 64) mxr = fmaxf(mxr, sc[r * Tn + j]);
+        mxr = wave_max(mxr);
+        if (mxr == NEG_INF) mxr = 0.f;                       // every key masked: all probabilities 0 (the division below gives NaN like the reference)
+        float lr = 0.f;
+        for (int j = lane; j < Tn; j += 64) {
+            const float pj = __builtin_amdgcn_exp2f(sc[r * Tn + j] - mxr);
+            sc[r * Tn + j] = (float)(T)pj;                   // the numerator uses P rounded to the operand type, the row sum does not -- as in the main kernel
+            lr += pj;
+        }
+        l[r] = wave_sum(lr);
     }
-    l = wave_sum(l);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const T* vcol = base + 2 * E + lane;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    // four partial sums per row over j mod 4, combined as ((0 + 1) + (2 + 3)): the single-row form's order, for every RW
+    float o[RW][4];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) { o[r][0] = 0.f; o[r][1] = 0.f; o[r][2] = 0.f; o[r][3] = 0.f; }
     int j = 0;
-    for (; j + 4 <= Tn; j += 4) {
-        o0 = __builtin_fmaf(sc[j], (float)vcol[(int64_t)j * ld], o0);
-        o1 = __builtin_fmaf(sc[j + 1], (float)vcol[(int64_t)(j + 1) * ld], o1);
-        o2 = __builtin_fmaf(sc[j + 2], (float)vcol[(int64_t)(j + 2) * ld], o2);
-        o3 = __builtin_fmaf(sc[j + 3], (float)vcol[(int64_t)(j + 3) * ld], o3);
+#pragma unroll 4
+    for (; j + 4 <= Tn; j += 4) {      // (16 V loads in flight per lane: one load per trip made the loop latency-bound)
+        const float v0 = (float)vcol[(int64_t)j * ld], v1 = (float)vcol[(int64_t)(j + 1) * ld];
+        const float v2 = (float)vcol[(int64_t)(j + 2) * ld], v3 = (float)vcol[(int64_t)(j + 3) * ld];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            o[r][0] = __builtin_fmaf(sc[r * Tn + j], v0, o[r][0]);
+            o[r][1] = __builtin_fmaf(sc[r * Tn + j + 1], v1, o[r][1]);
+            o[r][2] = __builtin_fmaf(sc[r * Tn + j + 2], v2, o[r][2]);
+            o[r][3] = __builtin_fmaf(sc[r * Tn + j + 3], v3, o[r][3]);
+        }
     }
-    for (; j < Tn; ++j) o0 = __builtin_fmaf(sc[j], (float)vcol[(int64_t)j * ld], o0);
-    out[((int64_t)b * Tn + i) * E + h * 64 + lane] = Half<T>::from(((o0 + o1) + (o2 + o3)) / l);
+    for (; j < Tn; ++j) {
+        const float v0 = (float)vcol[(int64_t)j * ld];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) o[r][0] = __builtin_fmaf(sc[r * Tn + j], v0, o[r][0]);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        if (T0 + grp * RW + r < T0 + R)
+            out[((int64_t)b * Tn + ir[r]) * E + h * 64 + lane] = Half<T>::from(((o[r][0] + o[r][1]) + (o[r][2] + o[r][3])) / l[r]);
 }
 
 template <typename T>
@@ -1067,9 +1113,13 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
         int n_wg = n_cu;
         if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }   // tests: several units per workgroup
-        // a last query block of at most 32 rows goes to the tail kernel (one wave per row) instead of a whole 512-row block
+        // A last query block of one or two rows (EAT's class token: 513 = 512 + 1) goes to the tail kernel instead of a further query block
+        // of the streamed kernel.  Only that: in a short last block the waves without query rows skip their tiles, so the block is cheap
+        // -- measured at 3 072 (clip, head) items (scripts/att_513.py): 513 tokens 0.441 ms with the tail, 0.491 without; 520 tokens
+        // 0.532 / 0.485; 544 tokens 0.949 / 0.491 (and 1.79 ms with round 2's one-row-per-wave tail up to 32 rows).
         const int rem = Tn % 512;
-        const bool use_tail = Tn > TMAX && rem > 0 && rem <= 32 && !getenv("AVEX_AMD_ATT_NO_TAIL");
+        const int tail_max = getenv("AVEX_AMD_ATT_TAIL_ROWS") ? atoi(getenv("AVEX_AMD_ATT_TAIL_ROWS")) : 2;      // (tests raise it to 32)
+        const bool use_tail = Tn > TMAX && rem > 0 && rem <= tail_max && rem <= 32 && !getenv("AVEX_AMD_ATT_NO_TAIL");
         const int nqb_main = Tn > TMAX ? (use_tail ? Tn / 512 : (Tn + 511) / 512) : 1;
         AVX_REQUIRE((int64_t)B * H * nqb_main < (1ll << 31), "attention: too many (item, query block) units");
         const int n_units = B * H * nqb_main;            // (clip, head, query block of 512) units, dealt to the workgroups in consecutive runs
@@ -1088,10 +1138,16 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
             AVX_LAUNCH_CHECK();
             if (use_tail) {
                 AVX_REQUIRE((int64_t)B * H * rem < (1ll << 31), "attention: too many tail rows");
-                const size_t lds = sizeof(float) * ((size_t)Tn + 64);
-                AVX_ENSURE_LDS(attention_tail_kernel<T>, 160 * 1024);
-                hipLaunchKernelGGL(attention_tail_kernel<T>, dim3(B * H * rem), dim3(64), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b,
-                                   grep_a, key_pad, (T*)out, q_log2e);
+                // rows per wave: as many as the tail has (up to 8) and as fit the LDS (RW x (Tn + 64) floats)
+                int rw = rem >= 8 ? 8 : (rem >= 4 ? 4 : (rem >= 2 ? 2 : 1));
+                while (rw > 1 && sizeof(float) * (size_t)rw * ((size_t)Tn + 65) > 150 * 1024) rw >>= 1;
+                const size_t lds = sizeof(float) * (size_t)rw * ((size_t)Tn + 65);
+                const dim3 tgrid((unsigned)(B * H * ((rem + rw - 1) / rw)));
+#define AVX_TAIL(RWV) do { AVX_ENSURE_LDS((attention_tail_kernel<T, RWV>), 160 * 1024); \
+                hipLaunchKernelGGL((attention_tail_kernel<T, RWV>), tgrid, dim3(64), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b, \
+                                   grep_a, key_pad, (T*)out, q_log2e); } while (0)
+                if (rw == 8) AVX_TAIL(8); else if (rw == 4) AVX_TAIL(4); else if (rw == 2) AVX_TAIL(2); else AVX_TAIL(1);
+#undef AVX_TAIL
             }
         } else if (bias_tab) {
             AVX_ENSURE_LDS((attention2_kernel<T, false, true>), ATT2_LDS);

@@ -429,7 +429,11 @@ def test_attention_long_clips(built_lib, T, grid, monkeypatch):
     ref = _attention_ref(qkv, B, T, H, None, None, None, None)
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
     if 0 < T % 512 <= 32:
-        # a last query block of at most 32 rows runs in the one-wave-per-row tail kernel: same rows through the streamed kernel instead
+        # a last query block of at most 8 rows (32 when asked) runs in the one-wave-per-row tail kernel: same rows through the streamed kernel instead
+        monkeypatch.setenv("AVEX_AMD_ATT_TAIL_ROWS", "32")
+        out = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None)
+        assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
+        monkeypatch.delenv("AVEX_AMD_ATT_TAIL_ROWS")
         monkeypatch.setenv("AVEX_AMD_ATT_NO_TAIL", "1")
         out2 = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None)
         monkeypatch.delenv("AVEX_AMD_ATT_NO_TAIL")
