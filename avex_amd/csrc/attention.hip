@@ -297,6 +297,12 @@ constexpr int A2_WIN_BYTES = 4 * A2_WLD * 4;              // 12 416
 constexpr int A2L_KADD_OFF = A2_TAB_OFF + 2 * A2_WIN_BYTES;
 constexpr int A2L_GW_OFF = A2L_KADD_OFF + 2 * 256 * 4;
 constexpr int ATT2L_LDS = A2L_GW_OFF + GW_BYTES;
+// ... and for the nine-tile last phase (no bias table): 288 keys per buffer, no windows
+constexpr int A2X_KBUF = 9 * 4096;                        // 36 864
+constexpr int A2X_HALF = 2 * A2X_KBUF;                    // 73 728
+constexpr int A2X_KADD_OFF = 2 * A2X_HALF;
+constexpr int A2X_GW_OFF = A2X_KADD_OFF + 2 * 288 * 4;
+constexpr int ATT2X_LDS = A2X_GW_OFF + GW_BYTES;
 constexpr float A2_THR = 8.f;
 #if defined(ATT_STAMPS) && ATT_STAMPS
 __device__ unsigned long long g_att_stamps[64 * 8 * 32 * 8];   // [block < 64][wave][phase < 32][7 x s_memtime, s_memrealtime]
@@ -326,7 +332,10 @@ static __device__ __forceinline__ void a2_dma16(const void* src, const char* lds
 #ifndef ATT_BIAS_REUSE
 #define ATT_BIAS_REUSE 1      // 0: A/B build, each query tile reads its bias vectors from LDS (round 2's form; tiles 256 rows apart)
 #endif
-template <typename T, bool LONG, bool BIAS>      // BIAS false: no relative-position table (EAT, wav2vec2): the S accumulators start at -m alone
+// XT (long clips without a bias table only): a LAST key block of 257 .. 288 keys runs as one phase of NINE key tiles instead of a ninth
+// tile's worth of keys getting a phase of their own (EAT: 513 keys = 256 + 257).  The buffers grow to 288 keys; the LDS the bias windows
+// would take is free without a table.
+template <typename T, bool LONG, bool BIAS, bool XT = false>      // BIAS false: no relative-position table (EAT, wav2vec2): the S accumulators start at -m alone
 __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block, int nqb_main,
                                                         const float* __restrict__ bias_tab,
                                                         const float* __restrict__ grep_w,
@@ -339,9 +348,14 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     constexpr int NQ = 2, NW = 8, NT = 512;              // 8 waves, two 32-query tiles each (tile wave + 8 u)
+    static_assert(!XT || (LONG && !BIAS && ATT_IL), "the nine-tile last phase is built for long clips without a bias table (whose windows' LDS it takes)");
+    constexpr int NKT = XT ? 9 : 8;                      // key tiles a phase buffer holds
+    constexpr int KBUF = XT ? A2X_KBUF : A2_KBUF;        // bytes of K per buffer (V follows)
+    constexpr int HALF = XT ? A2X_HALF : A2_HALF;        // bytes per buffer
+    constexpr int KSLOT = XT ? 288 : 256;                // key-mask entries per phase (LONG)
     float* tab = (float*)(smem + A2_TAB_OFF);
-    float* kadd = (float*)(smem + (LONG ? A2L_KADD_OFF : A2_KADD_OFF));
-    float* gw = (float*)(smem + (LONG ? A2L_GW_OFF : A2_GW_OFF));
+    float* kadd = (float*)(smem + (XT ? A2X_KADD_OFF : (LONG ? A2L_KADD_OFF : A2_KADD_OFF)));
+    float* gw = (float*)(smem + (XT ? A2X_GW_OFF : (LONG ? A2L_GW_OFF : A2_GW_OFF)));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     const int E = H * 64;
     const int64_t ld = 3 * (int64_t)E;
     const float NEG_INF = -__builtin_inff();
-    const int nh = LONG ? (Tn + 255) >> 8 : (Tn > 256 ? 2 : 1);      // key blocks of 256 per query block
+    const int nh = XT ? Tn >> 8 : (LONG ? (Tn + 255) >> 8 : (Tn > 256 ? 2 : 1));      // key blocks of 256 per query block (XT: the last one takes the 1 .. 32 keys beyond)
     const int np = (w1 - w0) * nh;
     const int nkt = (Tn + 31) >> 5;
     const int hh = lane >> 5, r32 = lane & 31;
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
 
     auto issue_next = [&](int ph) __attribute__((always_inline)) {      // DMA for phase ph = (h_ld, b_ld, half_ld), then advance
         const T* base = qkv + (int64_t)b_ld * Tn * ld + h_ld * 64;
-        char* buf = smem + (ph & 1) * A2_HALF;
+        char* buf = smem + (ph & 1) * HALF;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ri = 4 * wave + u;                                   // 8-key group inside the half
@@ -394,7 +408,20 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             int vkey = half_ld * 256 + 8 * ri + ((lane >> 2) & 7);
             vkey = vkey < Tn ? vkey : Tn - 1;
             const int ch = 4 * (lane >> 5) + (lane & 3);
-            a2_dma16(base + (int64_t)vkey * ld + 2 * E + ch * 8, buf + A2_KBUF + ri * 1024);
+            a2_dma16(base + (int64_t)vkey * ld + 2 * E + ch * 8, buf + KBUF + ri * 1024);
+        }
+        if (XT && half_ld == nh - 1 && wave < 4) {                         // the ninth key tile: four more 8-key groups, one per wave 0 .. 3
+            // (the counted waits of the phase loop count operations YOUNGER than the DMA -- Q loads, output stores -- so a wave may issue more)
+            const int ri = 32 + wave;
+            const int kl = 8 * ri + (lane >> 3);
+            int key = half_ld * 256 + kl;
+            key = key < Tn ? key : Tn - 1;
+            const int chunk = (lane & 7) ^ ((kl >> 1) & 7);
+            a2_dma16(base + (int64_t)key * ld + E + chunk * 8, buf + ri * 1024);
+            int vkey = half_ld * 256 + 8 * ri + ((lane >> 2) & 7);
+            vkey = vkey < Tn ? vkey : Tn - 1;
+            const int ch = 4 * (lane >> 5) + (lane & 3);
+            a2_dma16(base + (int64_t)vkey * ld + 2 * E + ch * 8, buf + KBUF + ri * 1024);
         }
         if (++half_ld == nh) { half_ld = 0; if (++qb_ld == nqb) { qb_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } } }
     };
@@ -410,11 +437,11 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             for (int sft = 0; sft < 4; ++sft)
                 if (r - sft >= 0) win[sft * A2_WLD + (r - sft)] = v;
         }
-        if (tid < 256) {
+        if (tid < KSLOT) {
             const int j = half_ld * 256 + tid;
             bool ok = j < Tn;
             if (ok && key_pad) ok = key_pad[(int64_t)b_ld * Tn + j] == 0;
-            kadd[(ph & 1) * 256 + tid] = ok ? 0.f : NEG_INF;
+            kadd[(ph & 1) * KSLOT + tid] = ok ? 0.f : NEG_INF;
         }
     };
     auto write_kadd = [&](int slot, int b) __attribute__((always_inline)) {
@@ -523,7 +550,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         __builtin_amdgcn_s_barrier();
         AVX_PT(2)
         AVX_PT(3)
-        bool vm_young = LONG;                            // a global load younger than the previous item's output stores is pending
+        bool vm_young = LONG && (BIAS || key_pad != nullptr);      // a global load younger than the previous item's output stores is pending (long clips: the next window's bias row / key mask)
         if (half == 0) {
             if (!LONG && h_cur != h_tab) {               // workgroup-uniform
                 vm_young = true;
@@ -601,9 +628,10 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
         if (ph + 1 < np && dbg != 3) issue_next(ph + 1);
         AVX_PT(4)
         if (has_q) {
-            const char* Kb = smem + (ph & 1) * A2_HALF;
-            const float* kad = LONG ? kadd + (ph & 1) * 256 - half * 256 : kadd + item_par * TMAX;   // indexed by the global key
-            int kt_end = nkt - half * 8 < 8 ? nkt - half * 8 : 8;
+            const char* Kb = smem + (ph & 1) * HALF;
+            const float* kad = LONG ? kadd + (ph & 1) * KSLOT - half * 256 : kadd + item_par * TMAX;   // indexed by the global key
+            const int kt_lim = (XT && last_half) ? 9 : 8;
+            int kt_end = nkt - half * 8 < kt_lim ? nkt - half * 8 : kt_lim;
             if (dbg == 1) kt_end = 0;
             if (dbg == 2) kt_end = 1;
             // per-phase address registers; everything inside the 8 unrolled key tiles is base + immediate
@@ -622,7 +650,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                     tp[u] = tab + (tb & 3) * TAB_LD + (tb & ~3);
                 }
             }
-            const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + A2_KBUF + v_lane);
+            const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + KBUF + v_lane);
 
             v8 kf[4];
 #pragma unroll
@@ -747,7 +775,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                         vf[s2][dh] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 f32x4 t4n[4];
-                if (ktl + 1 < 8) {
+                if (ktl + 1 < NKT) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
                     if (has_bias) {
@@ -778,20 +806,20 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 // stage 4
                 if (has_bias) {
                     o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
-                    if (ktl + 1 < 8) { acc_start(0, 0, t4n[0]); acc_start(0, 1, t4n[1]); }
+                    if (ktl + 1 < NKT) { acc_start(0, 0, t4n[0]); acc_start(0, 1, t4n[1]); }
                     AVX_FENCE();
                     o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
-                    if (ktl + 1 < 8) { acc_start(0, 2, t4n[2]); acc_start(0, 3, t4n[3]); }
+                    if (ktl + 1 < NKT) { acc_start(0, 2, t4n[2]); acc_start(0, 3, t4n[3]); }
                     AVX_FENCE();
                     o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
-                    if (!ATT_BIAS_REUSE && ktl + 1 < 8) {
+                    if (!ATT_BIAS_REUSE && ktl + 1 < NKT) {
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) tcur[g4] = *(const f32x4*)(tp[1] + (ktl + 1) * 32 + 8 * g4);      // A/B build: tile 1's values from LDS as before
                     }
-                    if (ktl + 1 < 8) { acc_start(1, 0, tcur[0]); acc_start(1, 1, tcur[1]); }       // tile 1 at key tile k + 1 = tile 0's values at key tile k
+                    if (ktl + 1 < NKT) { acc_start(1, 0, tcur[0]); acc_start(1, 1, tcur[1]); }       // tile 1 at key tile k + 1 = tile 0's values at key tile k
                     AVX_FENCE();
                     o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
-                    if (ktl + 1 < 8) {
+                    if (ktl + 1 < NKT) {
                         acc_start(1, 2, tcur[2]); acc_start(1, 3, tcur[3]);
                         if (ATT_BIAS_REUSE) {
 #pragma unroll
@@ -802,15 +830,15 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 } else {
                     o0[1] = mfma32(vf[0][0], pf[1][0], o0[1]);
                     o1[1] = mfma32(vf[0][1], pf[1][0], o1[1]);
-                    if (ktl + 1 < 8) acc_plain(0);
+                    if (ktl + 1 < NKT) acc_plain(0);
                     AVX_FENCE();
                     o0[1] = mfma32(vf[1][0], pf[1][1], o0[1]);
                     o1[1] = mfma32(vf[1][1], pf[1][1], o1[1]);
-                    if (ktl + 1 < 8) acc_plain(1);
+                    if (ktl + 1 < NKT) acc_plain(1);
                     AVX_FENCE();
                 }
                 AVX_TS(6)
-                if (ktl + 1 < 8 && masked_at(ktl + 1)) { mask_acc(0, ktl + 1); mask_acc(1, ktl + 1); }
+                if (ktl + 1 < NKT && masked_at(ktl + 1)) { mask_acc(0, ktl + 1); mask_acc(1, ktl + 1); }
 #if ATT_STAMPS
                 if (ktl == 3 && ph == 6 && blockIdx.x < 64 && lane == 0) {
                     unsigned long long* d = g_att_stamps + (((size_t)blockIdx.x * 8 + wave) * 32 + 31) * 8;
@@ -909,7 +937,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
                 };
                 auto next_k = [&]() __attribute__((always_inline)) {
                     // the K fragment is dead once both chains are issued: the next tile's goes into the same registers now
-                    if (ktl + 1 < 8) {
+                    if (ktl + 1 < NKT) {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) kf[s] = *(const v8*)(kp[s] + (ktl + 1) * 4096);
                     }
@@ -946,6 +974,7 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             if (5 < kt_end) tile(a_ic<5>{});
             if (6 < kt_end) tile(a_ic<6>{});
             if (7 < kt_end) tile(a_ic<7>{});
+            if constexpr (XT) { if (8 < kt_end) tile(a_ic<8>{}); }
         }
         AVX_PT(5)
         if (last_half) {
@@ -954,9 +983,20 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
             int hn = h_cur, bn = b_cur, qn = qb_cur + 1;
             if (qn == nqb) { qn = 0; if (++bn == Bc) { bn = 0; ++hn; } }
             if (LONG) {
+                // the next block's Q loads go out BEFORE this block's stores (as below), from row indices computed aside: the stores are
+                // then the youngest operations and drain under the next tiles instead of in front of the boundary's counted wait
+                if (more_items) {
+                    const T* nbase = qkv + (int64_t)bn * Tn * ld + hn * 64;
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        int qin = qn * 512 + (ATT_BIAS_REUSE ? (NQ * wave + u) : (wave + NW * u)) * 32 + r32;
+                        qin = qin < Tn ? qin : Tn - 1;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) qf[u][s4] = *(const v8*)(nbase + (int64_t)qin * ld + 16 * s4 + 8 * hh);
+                    }
+                }
                 store_item(h_cur, b_cur);                // its row indices are this block's: before set_qblock
                 set_qblock(qn);
-                if (more_items) load_q(hn, bn);
             } else {
                 if (more_items) load_q(hn, bn);
                 store_item(h_cur, b_cur);
@@ -984,33 +1024,33 @@ __global__ __launch_bounds__(512) void attention2_kernel(const T* __restrict__ q
     }
 }
 
-// The last few query rows of a long clip (T = 512 n + r, r <= 32: EAT's 513 tokens, a 10.4 s BEATs clip): a whole query block of
-// the streamed kernel for them would cost as much as 512 rows.  One wave per (clip, head, group of RW rows) instead: scores over all keys
-// with the lanes on the keys (every K row is read once for the RW rows), softmax through LDS, then the lanes on the 64 output dimensions
-// (every V row read once for the RW rows).  Same arithmetic as the main kernel (base-2 softmax, gate * bias, key mask), fp32 throughout
-// except the operands and the stored output.  RW = 1 is the single-row form (EAT's class-token row).
+// The last few query rows of a long clip (T = 512 n + r; in practice EAT's class-token row, 513 = 512 + 1): a further query block of
+// the streamed kernel for them costs more than this.  One workgroup of four waves per (clip, head, group of RW rows): scores over all
+// keys with the threads on the keys (every K row is read once for the RW rows), softmax through LDS, then each wave takes a quarter of
+// the keys with its lanes on the 64 output dimensions (every V row read once for the RW rows) and the four partial outputs are added in
+// wave order.  Same arithmetic as the main kernel (base-2 softmax, gate * bias, key mask), fp32 throughout except the operands and the
+// stored output.  (One wave per row, round 2's form, was a chain of ~140 dependent memory round trips: 0.1 ms at 3 072 rows.)
 template <typename T, int RW>
-__global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict__ qkv, int Tn, int H, int T0, int R, const float* __restrict__ bias_tab,
-                                                            const float* __restrict__ grep_w, const float* __restrict__ grep_b, const float* __restrict__ grep_a,
-                                                            const uint8_t* __restrict__ key_pad, T* __restrict__ out, int q_log2e) {
-    extern __shared__ float sc[];                            // [RW][Tn] scores, then probabilities; + [RW][64] floats of q + RW gates
+__global__ __launch_bounds__(256) void attention_tail_kernel(const T* __restrict__ qkv, int Tn, int H, int T0, int R, const float* __restrict__ bias_tab,
+                                                             const float* __restrict__ grep_w, const float* __restrict__ grep_b, const float* __restrict__ grep_a,
+                                                             const uint8_t* __restrict__ key_pad, T* __restrict__ out, int q_log2e) {
+    extern __shared__ float sc[];                            // [RW][Tn] scores, then probabilities; [RW][64] q; [RW] gates; [4][RW][64] partials
     float* qs = sc + RW * Tn;
-    const int lane = threadIdx.x;
+    float* gates = qs + RW * 64;
+    float* part = gates + RW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = (R + RW - 1) / RW;
     const int grp = blockIdx.x % G, h = (blockIdx.x / G) % H, b = blockIdx.x / (G * H);
     const int E = H * 64;
     const int64_t ld = 3 * (int64_t)E;
     const T* base = qkv + (int64_t)b * Tn * ld + h * 64;
     const float NEG_INF = -__builtin_inff();
-    int ir[RW];                                              // query rows of this wave; rows past the end repeat the last one (computed, not stored)
-    float gate[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int i = T0 + grp * RW + r;
-        ir[r] = i < T0 + R ? i : T0 + R - 1;
-        const float qv = (float)base[(int64_t)ir[r] * ld + lane];
+    auto row_of = [&](int r) { const int i = T0 + grp * RW + r; return i < T0 + R ? i : T0 + R - 1; };   // rows past the end repeat the last one (computed, not stored)
+    // wave w loads q rows w, w + 4, ... and makes their gates
+    for (int r = wave; r < RW; r += 4) {
+        const float qv = (float)base[(int64_t)row_of(r) * ld + lane];
         qs[r * 64 + lane] = qv;
-        gate[r] = 1.f;
+        float gate = 1.f;
         if (grep_w) {
             const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;
             const float wa = ((grep_w[0 * 64 + lane] + grep_w[1 * 64 + lane]) + (grep_w[2 * 64 + lane] + grep_w[3 * 64 + lane])) * ginv;
@@ -1018,16 +1058,16 @@ __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict_
             const float sa = wave_sum(qv * wa) + ((grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]));
             const float sb = wave_sum(qv * wb) + ((grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]));
             const float ga = 1.f / (1.f + __expf(-sa)), gb = 1.f / (1.f + __expf(-sb));
-            gate[r] = ga * (gb * grep_a[h] - 1.f) + 2.f;
+            gate = ga * (gb * grep_a[h] - 1.f) + 2.f;
         }
-        if (RW > 1 && lane == 0) qs[RW * 64 + r] = gate[r];
+        if (lane == 0) gates[r] = gate;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     const float cs = q_log2e ? 0.125f : 0.125f * 1.4426950408889634f;
-    // scores: the lane's K row is converted once (64 registers) and meets the RW query rows one after the other; q is read from LDS as
+    // scores: the thread's K row is converted once (64 registers) and meets the RW query rows one after the other; q is read from LDS as
     // broadcast 16-byte vectors (kept there on purpose: in registers it would be 64 RW values per lane)
 #pragma unroll 1
-    for (int j = lane; j < Tn; j += 64) {
+    for (int j = tid; j < Tn; j += 256) {
         typedef typename Half<T>::v8 v8;
         const T* krow = base + (int64_t)j * ld + E;
         float kf[64];
@@ -1049,37 +1089,49 @@ __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict_
                 d = __builtin_fmaf(kf[4 * c + 2], q[2], d); d = __builtin_fmaf(kf[4 * c + 3], q[3], d);
             }
             float sv = d * cs;
-            const int i = T0 + grp * RW + r < T0 + R ? T0 + grp * RW + r : T0 + R - 1;
-            const float gt = RW == 1 ? gate[0] : qs[RW * 64 + r];
-            if (bias_tab) sv = __builtin_fmaf(gt, bias_tab[(int64_t)h * (2 * Tn - 1) + (j - i) + (Tn - 1)] * 1.4426950408889634f, sv);
+            if (bias_tab) sv = __builtin_fmaf(gates[r], bias_tab[(int64_t)h * (2 * Tn - 1) + (j - row_of(r)) + (Tn - 1)] * 1.4426950408889634f, sv);
             if (padded) sv = NEG_INF;
             sc[r * Tn + j] = sv;
         }
     }
+    __syncthreads();
+    // softmax: row maxima and sums over the four waves through `part`
     float l[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         float mxr = NEG_INF;
-        for (int j = lane; j < Tn; j += 64) mxr = fmaxf(mxr, sc[r * Tn + j]);
+        for (int j = tid; j < Tn; j += 256) mxr = fmaxf(mxr, sc[r * Tn + j]);
         mxr = wave_max(mxr);
+        if (lane == 0) part[r * 4 + wave] = mxr;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float mxr = fmaxf(fmaxf(part[r * 4], part[r * 4 + 1]), fmaxf(part[r * 4 + 2], part[r * 4 + 3]));
         if (mxr == NEG_INF) mxr = 0.f;                       // every key masked: all probabilities 0 (the division below gives NaN like the reference)
         float lr = 0.f;
-        for (int j = lane; j < Tn; j += 64) {
+        for (int j = tid; j < Tn; j += 256) {
             const float pj = __builtin_amdgcn_exp2f(sc[r * Tn + j] - mxr);
             sc[r * Tn + j] = (float)(T)pj;                   // the numerator uses P rounded to the operand type, the row sum does not -- as in the main kernel
             lr += pj;
         }
-        l[r] = wave_sum(lr);
+        lr = wave_sum(lr);
+        if (lane == 0) part[RW * 4 + r * 4 + wave] = lr;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RW; ++r) l[r] = (part[RW * 4 + r * 4] + part[RW * 4 + r * 4 + 1]) + (part[RW * 4 + r * 4 + 2] + part[RW * 4 + r * 4 + 3]);
+    __syncthreads();                                         // `part` is reused for the partial outputs
+    // P V: wave w takes keys [w Tq, (w + 1) Tq), lanes on the output dimension
+    const int Tq = (Tn + 3) >> 2;
+    const int j0 = wave * Tq, j1 = (j0 + Tq) < Tn ? (j0 + Tq) : Tn;
     const T* vcol = base + 2 * E + lane;
-    // four partial sums per row over j mod 4, combined as ((0 + 1) + (2 + 3)): the single-row form's order, for every RW
     float o[RW][4];
 #pragma unroll
     for (int r = 0; r < RW; ++r) { o[r][0] = 0.f; o[r][1] = 0.f; o[r][2] = 0.f; o[r][3] = 0.f; }
-    int j = 0;
+    int j = j0;
 #pragma unroll 4
-    for (; j + 4 <= Tn; j += 4) {      // (16 V loads in flight per lane: one load per trip made the loop latency-bound)
+    for (; j + 4 <= j1; j += 4) {      // (16 V loads in flight per lane: one load per trip made the loop latency-bound)
         const float v0 = (float)vcol[(int64_t)j * ld], v1 = (float)vcol[(int64_t)(j + 1) * ld];
         const float v2 = (float)vcol[(int64_t)(j + 2) * ld], v3 = (float)vcol[(int64_t)(j + 3) * ld];
 #pragma unroll
@@ -1090,15 +1142,20 @@ __global__ __launch_bounds__(64) void attention_tail_kernel(const T* __restrict_
             o[r][3] = __builtin_fmaf(sc[r * Tn + j + 3], v3, o[r][3]);
         }
     }
-    for (; j < Tn; ++j) {
+    for (; j < j1; ++j) {
         const float v0 = (float)vcol[(int64_t)j * ld];
 #pragma unroll
         for (int r = 0; r < RW; ++r) o[r][0] = __builtin_fmaf(sc[r * Tn + j], v0, o[r][0]);
     }
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
-        if (T0 + grp * RW + r < T0 + R)
-            out[((int64_t)b * Tn + ir[r]) * E + h * 64 + lane] = Half<T>::from(((o[r][0] + o[r][1]) + (o[r][2] + o[r][3])) / l[r]);
+    for (int r = 0; r < RW; ++r) part[(wave * RW + r) * 64 + lane] = (o[r][0] + o[r][1]) + (o[r][2] + o[r][3]);
+    __syncthreads();
+    for (int r = wave; r < RW; r += 4) {
+        if (T0 + grp * RW + r < T0 + R) {
+            const float acc = (part[(0 * RW + r) * 64 + lane] + part[(1 * RW + r) * 64 + lane]) + (part[(2 * RW + r) * 64 + lane] + part[(3 * RW + r) * 64 + lane]);
+            out[((int64_t)b * Tn + row_of(r)) * E + h * 64 + lane] = Half<T>::from(acc / l[r]);
+        }
+    }
 }
 
 template <typename T>
@@ -1130,6 +1187,11 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
                 AVX_ENSURE_LDS((attention2_kernel<T, true, true>), ATT2L_LDS);
                 hipLaunchKernelGGL((attention2_kernel<T, true, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
                                    grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
+            } else if (Tn % 256 >= 1 && Tn % 256 <= 32 && !getenv("AVEX_AMD_ATT_NO_XT")) {
+                // the 1 .. 32 keys beyond a multiple of 256 ride in the last full key block's phase as a ninth key tile (EAT: 513 keys)
+                AVX_ENSURE_LDS((attention2_kernel<T, true, false, true>), ATT2X_LDS);
+                hipLaunchKernelGGL((attention2_kernel<T, true, false, true>), dim3(grid), dim3(512), ATT2X_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
+                                   grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
             } else {
                 AVX_ENSURE_LDS((attention2_kernel<T, true, false>), ATT2L_LDS);
                 hipLaunchKernelGGL((attention2_kernel<T, true, false>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
@@ -1140,11 +1202,11 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
                 AVX_REQUIRE((int64_t)B * H * rem < (1ll << 31), "attention: too many tail rows");
                 // rows per wave: as many as the tail has (up to 8) and as fit the LDS (RW x (Tn + 64) floats)
                 int rw = rem >= 8 ? 8 : (rem >= 4 ? 4 : (rem >= 2 ? 2 : 1));
-                while (rw > 1 && sizeof(float) * (size_t)rw * ((size_t)Tn + 65) > 150 * 1024) rw >>= 1;
-                const size_t lds = sizeof(float) * (size_t)rw * ((size_t)Tn + 65);
+                while (rw > 1 && sizeof(float) * (size_t)rw * ((size_t)Tn + 65 + 256) > 150 * 1024) rw >>= 1;
+                const size_t lds = sizeof(float) * (size_t)rw * ((size_t)Tn + 65 + 256);      // scores, q, gate, four partial output rows
                 const dim3 tgrid((unsigned)(B * H * ((rem + rw - 1) / rw)));
 #define AVX_TAIL(RWV) do { AVX_ENSURE_LDS((attention_tail_kernel<T, RWV>), 160 * 1024); \
-                hipLaunchKernelGGL((attention_tail_kernel<T, RWV>), tgrid, dim3(64), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b, \
+                hipLaunchKernelGGL((attention_tail_kernel<T, RWV>), tgrid, dim3(256), lds, s, (const T*)qkv, Tn, H, Tn - rem, rem, bias_tab, grep_w, grep_b, \
                                    grep_a, key_pad, (T*)out, q_log2e); } while (0)
                 if (rw == 8) AVX_TAIL(8); else if (rw == 4) AVX_TAIL(4); else if (rw == 2) AVX_TAIL(2); else AVX_TAIL(1);
 #undef AVX_TAIL

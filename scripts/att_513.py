@@ -35,6 +35,7 @@ run(496)
 run(512)
 run(513)
 run(513, {"AVEX_AMD_ATT_NO_TAIL": "1"})
+run(513, {"AVEX_AMD_ATT_NO_XT": "1"})
 run(520)
 run(520, {"AVEX_AMD_ATT_NO_TAIL": "1"})
 run(544)
