@@ -277,6 +277,9 @@ struct GemmArgs {
     // pool_part[block][slot][N], slot 0 = the clip of the block's first row, slot 1 = the next clip.  avx::pool_reduce adds a clip's
     // blocks in order and divides by pool_T.  256-tile kernel, generic epilogue.
     float* pool_part; int pool_T;
+    // 0, or the number of leading output columns that exist in memory (a multiple of 4, < N): the product is computed for N (a multiple of
+    // the tile width, W and bias padded by the caller) but rows of every output / residual are only n_store wide.  128-tile kernels.
+    int n_store;
     // sticky range alarm: the number of (lane, launch) pairs that rounded at least one |value| > 65504 to an f16 output is added
     // here (one atomic per wave at most, at the end of the kernel); NULL = not counted.  bf16 outputs cannot overflow.
     unsigned int* ovf;

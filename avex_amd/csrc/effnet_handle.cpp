@@ -29,6 +29,10 @@ using avxh::Table;
 namespace {
 
 inline int pad128(int c) { return ((c + 127) / 128) * 128; }
+// channels of an activation tensor in memory: 64 for the narrow block outputs of the first stages (16, 24, 40 channels at the largest
+// spatial sizes: padded to 128 they were 3 - 8x their size), else a multiple of 128.  GEMM outputs narrower than the 128-column tile
+// are computed at pad128 and stored through GemmArgs::n_store.
+inline int padc(int c) { return c <= 64 ? 64 : pad128(c); }
 
 struct Block {
     int k = 3, stride = 1, cin = 0, cexp = 0, cout = 0, cs = 0;     // cs: squeeze width
@@ -134,7 +138,7 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
             const int d = b.has_expand ? 1 : 0;
             if (b.has_expand) {
                 RC(pointwise(h, tb, p + "0.0", p + "0.1", b.cexp, b.cin, cp, &b.w_exp, &b.b_exp, nullptr, nullptr));
-                cp = pad128(b.cexp);
+                cp = padc(b.cexp);
             }
             b.cp_exp = cp;
             {   // depthwise k x k + BN: [k*k, cp]
@@ -159,7 +163,7 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
             std::vector<float> scp, shp;
             RC(pointwise(h, tb, p + std::to_string(d + 2) + ".0", p + std::to_string(d + 2) + ".1", b.cout, b.cexp, cp, &b.w_proj, &b.b_proj, &scp, &shp));
             RC(upload_f32(h, scp, &b.proj_scale)); RC(upload_f32(h, shp, &b.proj_shift));
-            cp = pad128(b.cout);
+            cp = padc(b.cout);
             b.cp_out = cp;
             if (b.tap) ++h->n_taps;
             h->blocks.push_back(b);
@@ -307,8 +311,8 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             if (b.has_expand) {
                 const int o = (in_buf + 1) & 3;
                 memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-                g.A = w.act[in_buf]; g.lda = b.cp_in; g.W = b.w_exp; g.ldw = b.cp_in; g.M = M_in; g.N = b.cp_exp; g.K = b.cp_in; g.bias = b.b_exp; g.gelu = 2;
-                g.out_half = w.act[o]; g.ldh = b.cp_exp;
+                g.A = w.act[in_buf]; g.lda = b.cp_in; g.W = b.w_exp; g.ldw = b.cp_in; g.M = M_in; g.N = pad128(b.cexp); g.K = b.cp_in; g.bias = b.b_exp; g.gelu = 2;
+                g.out_half = w.act[o]; g.ldh = b.cp_exp; g.n_store = b.cp_exp < g.N ? b.cp_exp : 0;
                 prof.begin("gemm.expand", 2.0 * M_in * (double)b.cexp * b.cin);
                 RC(avx::gemm(g, dt, s));
                 prof.end();
@@ -326,7 +330,8 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             const int out = (in_buf + 3) & 3;
             const bool hooked = b.tap && ((hook_mask >> (tap + 1)) & 1u);
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
-            g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = b.cp_out; g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
+            g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = pad128(b.cout); g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
+            g.n_store = b.cp_out < g.N ? b.cp_out : 0;
             if (b.residual) { g.resid_half = w.act[in_buf]; g.ldrh = b.cp_in; }
             g.out_half = w.act[out]; g.ldh = b.cp_out;
             if (hooked) { g.out_raw = w.raw; g.ldraw = b.cp_out; }

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wr * 64 + i * 16 + (lane >> 4) * 4;
+            if (p.n_store > 0 && n >= p.n_store) continue;      // columns computed for the tile shape only (rows of the outputs are n_store wide)
             f32x4 v = acc[i][j];
             if (p.bias) v += *(const f32x4*)(p.bias + n);
             if (zero_row) v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -809,6 +810,10 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
                     "gemm: lnr_y needs lnr_rows / gamma / beta / bias and no other residual");
         AVX_REQUIRE(a.variant == 0 || a.variant == 2 || a.variant == 5, "gemm: folded LayerNorm is built for the 256-tile kernel only");
         variant = 5;
+    }
+    if (a.n_store > 0 && a.n_store < a.N) {      // narrow outputs: the 128-tile kernels only
+        AVX_REQUIRE(a.n_store % 4 == 0 && !a.ln_rows && !a.lnr_y && !a.stats_out && !a.pool_part, "gemm: n_store=%d needs a multiple of 4 and no folded LayerNorm / pooled tap", a.n_store);
+        if (variant == 0 || variant == 2 || variant == 5) variant = 3;
     }
     if (a.pool_part) {
         AVX_REQUIRE(a.pool_T >= 64, "gemm: pool_part needs clips of at least 64 rows (got %d)", a.pool_T);
