@@ -332,6 +332,7 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = pad128(b.cout); g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
             g.n_store = b.cp_out < g.N ? b.cp_out : 0;
+            if (b.cp_out == 64 && M2 >= 32768 && !hooked) { g.N = 64; g.n_store = 0; }      // the skinny streaming kernel computes 64 columns as such
             if (b.residual) { g.resid_half = w.act[in_buf]; g.ldrh = b.cp_in; }
             g.out_half = w.act[out]; g.ldh = b.cp_out;
             if (hooked) { g.out_raw = w.raw; g.ldraw = b.cp_out; }

@@ -796,8 +796,155 @@ static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
     return AVEXHIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skinny streaming product (variant 7): a long thin activation matrix against a small weight matrix -- EfficientNet's 1 x 1 convolutions
+// at the early stages (8.2 M rows, K = 64, N = 128): HBM-bound.  The tile-per-workgroup kernels re-stage a 16 KB weight block through the
+// LDS for every 128 rows (1.9 TB/s measured).  Here the WHOLE W [N, K] (<= 64 KiB) is put in LDS once per workgroup and the rows of A
+// stream from global memory straight into MFMA operand registers: lane l of a 16-row tile reads the 16 bytes A[row l % 16][32 ks + 8 (l / 16) ..]
+// -- exactly the B-operand layout of v_mfma_f32_16x16x32 -- so there is no LDS staging of A, no barrier and no transpose in the loop; with W
+// as the A operand a lane ends up with four consecutive output columns of one row (8-byte stores).  One wave = 32 rows x N per trip.
+// NT = N / 16, KS = K / 32 are compile-time (register arrays).  Epilogue: bias, activation, half residual, n_store; half output only.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NT, int KS>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Half<T>::v8 v8;
+    typedef typename Half<T>::v4 v4;
+    constexpr int N = NT * 16, K = KS * 32, KC = K / 8;      // KC 16-byte chunks per W row
+    constexpr int SW = KC >= 8 ? 7 : KC - 1;                 // chunk index XOR (row & SW): 16 consecutive rows at one chunk spread over the banks
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const T* W = (const T*)p.W;
+    const T* A = (const T*)p.A;
+    // W rows are PERMUTED on their way into the LDS so that a lane's accumulators of four MFMA tiles are 16 CONSECUTIVE output columns:
+    // LDS row (tile 4 t + q, row 4 g + r) holds W row n = 64 t + 16 g + 4 q + r.  A lane (g = lane / 16) then owns columns
+    // 64 t + 16 g .. + 15 of its output row -- two 16-byte stores -- and the four lanes of a row cover one whole 128-byte line.
+    for (int c = tid; c < N * KC; c += 256) {
+        const int n = c / KC, ch = c - n * KC;
+        const int row = (((n >> 6) * 4 + ((n >> 2) & 3)) << 4) + (((n >> 4) & 3) << 2) + (n & 3);
+        *(uint4*)(smem + ((row * KC + (ch ^ (row & SW))) << 4)) = *(const uint4*)(W + (int64_t)n * p.ldw + ch * 8);
+    }
+    __syncthreads();
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nst = p.n_store > 0 ? p.n_store : p.N;
+    const float alpha = p.alpha;
+    float ovf_mx = 0.f;
+    const int64_t nblk = ((int64_t)p.M + 31) >> 5;
+    const int64_t bstep = (int64_t)gridDim.x * 4;
+    auto load_rows = [&](int64_t blk, v8 (&dst)[KS][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            int64_t row = (blk << 5) + rt * 16 + lr;
+            row = row < p.M ? row : p.M - 1;
+            const T* ap = A + row * p.lda + lq * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dst[ks][rt] = *(const v8*)(ap + ks * 32);
+        }
+    };
+    constexpr bool PF = KS <= 4;                             // K <= 128: the next trip's rows are requested before this trip's MFMAs (2 x 16 KS registers)
+    v8 af[KS][2], an[KS][2];
+    int64_t blk0 = (int64_t)blockIdx.x * 4 + wid;
+    if (PF && blk0 < nblk) load_rows(blk0, an);
+    for (int64_t blk = blk0; blk < nblk; blk += bstep) {
+        const int64_t r0 = blk << 5;
+        // small W (<= 16 fragments = 64 registers): the compiler keeps the fragments in registers across the trips -- weights resident, no LDS
+        // read in the loop.  Larger: re-read from LDS every trip (hoisted they would be up to 256 registers and spill).
+        if constexpr (NT * KS > 16) asm volatile("" ::: "memory");
+        if constexpr (PF) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { af[ks][0] = an[ks][0]; af[ks][1] = an[ks][1]; }
+            load_rows(blk + bstep < nblk ? blk + bstep : blk, an);
+        } else {
+            load_rows(blk, af);
+        }
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nt][1] = acc[nt][0]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 16 + lr;
+                const v8 wf = *(const v8*)(smem + ((n * KC + ((ks * 4 + lq) ^ (n & SW))) << 4));
+                acc[nt][0] = mfma16(wf, af[ks][0], acc[nt][0]);
+                acc[nt][1] = mfma16(wf, af[ks][1], acc[nt][1]);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t m = r0 + rt * 16 + lr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int t = 0; t < NT / 4; ++t) {
+                const int n = t * 64 + lq * 16;                 // this lane's 16 consecutive columns
+                if (n >= nst) continue;
+                v8 rh[2];
+                if (p.resid_half) { rh[0] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n); rh[1] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n + 8); }
+                v8 h[2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = acc[4 * t + q][rt];
+                    if (p.bias) v += *(const f32x4*)(p.bias + n + 4 * q);
+                    if (p.resid_half) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)rh[q >> 1][4 * (q & 1) + e] * alpha + v[e];
+                    }
+                    if (p.gelu) v = act4_any(v, p.gelu);
+                    ovf_see4<T>(ovf_mx, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = Half<T>::from(v[e]);
+                }
+                *(v8*)((T*)p.out_half + m * p.ldh + n) = h[0];
+                *(v8*)((T*)p.out_half + m * p.ldh + n + 8) = h[1];
+            }
+        }
+    }
+    ovf_commit<T>(p.ovf, ovf_mx);
+}
+
+template <typename T, int NT, int KS>
+static int launch_skinny(const avx::GemmArgs& a, hipStream_t s) {
+    int n_cu = 256;
+    { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
+    const size_t lds = (size_t)NT * 16 * KS * 32 * 2;
+    AVX_ENSURE_LDS((gemm_skinny_kernel<T, NT, KS>), 64 * 1024);
+    const int64_t nblk = ((int64_t)a.M + 127) / 128;
+    int per_cu = (int)(128 * 1024 / (lds > 16384 ? lds : 16384));      // workgroups per CU the LDS (and ~100 registers per lane) allows
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = (int64_t)n_cu * per_cu;
+    grid = grid < nblk ? grid : nblk;
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, NT, KS>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+// does the skinny kernel take this product?  (half output only, no fp32 / raw outputs, no folded LayerNorm, no row mask)
+static bool skinny_ok(const avx::GemmArgs& a) {
+    if (!(a.K == 64 || a.K == 128 || a.K == 256) || !(a.N == 64 || a.N == 128 || a.N == 256) || a.N * a.K > 32768) return false;
+    if (!a.out_half || a.out_f32 || a.out_raw || a.resid || a.row_zero || a.ln_rows || a.lnr_y || a.stats_out || a.pool_part) return false;
+    if (a.lda % 8 || a.ldw % 8 || a.ldh % 8 || (a.resid_half && a.ldrh % 8) || (a.n_store > 0 && a.n_store % 16)) return false;
+    return true;
+}
+
+template <typename T>
+static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
+#define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) return launch_skinny<T, NTV, KSV>(a, s)
+    AVX_SK(4, 2); AVX_SK(4, 4); AVX_SK(4, 8); AVX_SK(8, 2); AVX_SK(8, 4); AVX_SK(8, 8); AVX_SK(16, 2); AVX_SK(16, 4);
+#undef AVX_SK
+    avexhip_set_error("gemm: no skinny instantiation for N=%d K=%d", a.N, a.K);
+    return AVEXHIP_ERR_INVALID;
+}
+
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
+    // variant 7 / auto for long thin products: the skinny streaming kernel (W resident in LDS, A rows straight into MFMA operands)
+    if (a.variant == 7) {
+        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K, N in {64, 128, 256} with N K <= 32768, half output only (N=%d K=%d)", a.N, a.K);
+        return launch_skinny_any<T>(a, s);
+    }
+    if (a.variant == 0 && a.M >= 32768 && skinny_ok(a) &&
+        (a.N % BN != 0 || (!(getenv("AVEX_AMD_GEMM_SKINNY") && atoi(getenv("AVEX_AMD_GEMM_SKINNY")) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"))))
+        return launch_skinny_any<T>(a, s);
     // variant: 0 = auto, 1 = 128-tile register staging, 3 = 128-tile LDS-DMA, 5 (or 2, its tile-per-workgroup ancestor's number) =
     // the 256-tile streaming kernel
     int variant = a.variant;
@@ -868,7 +1015,8 @@ namespace avx {
 int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     AVX_REQUIRE(a.A && a.W, "gemm: A and W must be non-null");
     AVX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-    AVX_REQUIRE(a.N % BN == 0, "gemm: N=%d must be a multiple of %d", a.N, BN);
+    AVX_REQUIRE(a.N % BN == 0 || (a.N == 64 && (a.variant == 7 || (a.variant == 0 && a.M >= 32768)) && skinny_ok(a)),
+                "gemm: N=%d must be a multiple of %d (64 columns: the skinny streaming kernel only, >= 32768 rows)", a.N, BN);
     AVX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     AVX_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
     AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw, "gemm: no output buffer");

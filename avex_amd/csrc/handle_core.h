@@ -297,7 +297,7 @@ struct CoreCfg {
     int hook_site = 0;            // 0: fc2's raw output, 1: the attention output projection's raw output
     bool fast = false;            // residual stream / pre-LN sums in the operand type
     bool fold = false;            // fast mode: the LayerNorms between the GEMMs folded into their epilogues (post-LN, GELU / SiLU FFN only)
-    int fold_min_rows = 0;        // ... for chunks of at least this many token rows (AVEX_AMD_LN_FOLD=auto: 1024; default 0 = always, so a
+    int fold_min_rows = 0;        // ... for chunks of at least this many token rows (default 1024; AVEX_AMD_LN_FOLD=1: 0 = always, so that a
                                   // clip's result never depends on the batch it came in)
     int act = 1;                  // GemmArgs::gelu code of the FFN activation (0 none, 1 erf GELU, 2 SiLU, 3 ReLU, 4 tanh GELU, 5 tanh)
     bool glu = false;             // fc1 is the reference's GLU_Linear(E, F, "swish"): one Linear to 2F, then value * swish(gate) (backbone.py:296-297)
@@ -305,13 +305,14 @@ struct CoreCfg {
     const float* final_ln_w = nullptr; const float* final_ln_b = nullptr;
 };
 
-// AVEX_AMD_LN_FOLD, read when a handle is created: unset / 1 = fold the encoder's LayerNorms into the GEMMs around them (dims permitting),
-// 0 = LayerNorm kernels, "auto" = fold only chunks of >= 1024 token rows.  Below that the fold's 256-tile streaming kernel has a handful
-// of tiles for 256 CUs and the 128-tile kernel is quicker (one 10 s clip: 2.17 -> 1.70 ms, profiles/r03d_small_batch.txt); the price
-// is that a clip's embedding then differs in its last bits between a 1-clip call and a 256-clip call (both within the parity bar).
+// AVEX_AMD_LN_FOLD, read when a handle is created.  Unset / "auto": the encoder's LayerNorms are folded into the GEMMs around them (dims
+// permitting) for chunks of >= 1024 token rows; smaller chunks run LayerNorm kernels.  Below that size the fold's 256-tile streaming kernel
+// has a handful of tiles for 256 CUs and the 128-tile kernel is quicker (one 10 s clip: 2.17 -> 1.70 ms, profiles/r03d_small_batch.txt).
+// "1": fold whatever the size -- a clip's embedding is then bit-identical whether it came alone or in a batch of 256 (with "auto" the two
+// differ in their last bits, both inside the parity bar).  "0": never fold.
 inline void fold_policy(bool fast, int E, int F, bool* fold, int* min_rows) {
     const char* e = getenv("AVEX_AMD_LN_FOLD");
-    const bool is_auto = e && (e[0] == 'a' || e[0] == 'A');
+    const bool is_auto = !e || e[0] == 'a' || e[0] == 'A';
     *fold = fast && E % 256 == 0 && F % 256 == 0 && !(e && !is_auto && atoi(e) == 0);
     *min_rows = is_auto ? 1024 : 0;
 }

@@ -23,16 +23,16 @@ def base_sd():
 
 
 @pytest.fixture(scope="module", params=["f16", "bf16", "f16-halfres", "bf16-halfres", "f16-halfres-nofold", "bf16-halfres-nofold",
-                                        "f16-halfres-plainq", "bf16-plainq", "f16-halfres-autofold"])
+                                        "f16-halfres-plainq", "bf16-plainq", "f16-halfres-alwaysfold", "bf16-halfres-alwaysfold"])
 def encoder(request, built_lib, base_sd):
     """f32 residual stream (generic GEMM epilogues), half residual stream (default: the LayerNorms folded into the streaming GEMM's
-    epilogues), half residual stream with LayerNorm kernels (AVEX_AMD_LN_FOLD=0), the fold for chunks of >= 1024 token rows only
-    (AVEX_AMD_LN_FOLD=auto: the single-clip cases below run unfolded, the 4-clip ones folded) and the attention fed with plain Q instead
-    of log2(e) Q (AVEX_AMD_Q_LOG2E=0); the knobs are read when the handle is created."""
+    epilogues for chunks of >= 1024 token rows: the single-clip cases below run unfolded, the 4-clip ones folded), half residual stream
+    with LayerNorm kernels (AVEX_AMD_LN_FOLD=0) or with the fold at every size (=1), and the attention fed with plain Q instead of
+    log2(e) Q (AVEX_AMD_Q_LOG2E=0); the knobs are read when the handle is created."""
     import os
     from avex_amd import kernels as K
     dt = request.param.split("-")[0]
-    knobs = {"AVEX_AMD_LN_FOLD": "0" if request.param.endswith("nofold") else ("auto" if request.param.endswith("autofold") else None),
+    knobs = {"AVEX_AMD_LN_FOLD": "0" if request.param.endswith("nofold") else ("1" if request.param.endswith("alwaysfold") else None),
              "AVEX_AMD_Q_LOG2E": "0" if request.param.endswith("plainq") else None}
     old = {k: os.environ.get(k) for k in knobs}
     for k, v in knobs.items():

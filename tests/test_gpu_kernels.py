@@ -166,6 +166,31 @@ def test_gemm_pooled_tap(built_lib, dtype, B, T, grid, monkeypatch):
     assert torch.equal(r2["pooled"], r["pooled"])                       # blocks are added in a fixed order: reproducible bits
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,Kd", [(128, 64), (64, 64), (64, 128), (128, 128), (256, 64), (64, 256), (128, 256), (256, 128)])
+def test_gemm_skinny_streaming(built_lib, dtype, N, Kd):
+    """The skinny streaming kernel (variant 7: the whole W in LDS, A rows straight into MFMA operand registers; EfficientNet's 1 x 1
+    convolutions at the early stages) against the 128-tile kernel: same MFMA, same K order, same epilogue order -> the same bits.  A row
+    count that is no multiple of 32, bias + half residual + SiLU, and the plain form; auto-selection from 32 768 rows."""
+    from avex_amd import kernels as K
+    M = 40000 + 13
+    td = _tdt(dtype)
+    a = _dev(round_half(synth.normal(f"skA{Kd}", (M, Kd), 1.0), dtype), td)
+    w = _dev(round_half(synth.normal(f"skW{N}{Kd}", (N, Kd), 0.1), dtype), td)
+    bias = _dev(synth.normal(f"skb{N}", (N,), 0.3))
+    res = _dev(round_half(synth.normal(f"skR{N}", (M, N), 1.0), dtype), td)
+    for kw in (dict(bias=bias, resid_half=res, alpha=0.5, silu=True), dict(bias=bias), dict()):
+        r7 = K.gemm(a, w, out_f32=False, out_half=True, variant=7, **kw)["half"]
+        r0 = K.gemm(a, w, out_f32=False, out_half=True, **kw)["half"]      # auto: M >= 32 768 takes the skinny kernel
+        assert torch.equal(r0, r7)
+        if N % 128 == 0:                                                    # (the 128-tile kernel needs whole 128-column tiles)
+            r3 = K.gemm(a, w, out_f32=False, out_half=True, variant=3, **kw)["half"]
+            assert torch.equal(r7, r3)
+    want = a[:2000].double() @ w.double().T
+    got = K.gemm(a, w, out_f32=False, out_half=True, variant=7)["half"][:2000].double()
+    assert float((got - want).norm() / want.norm()) < (2e-3 if dtype == "f16" else 1.2e-2)
+
+
 def test_gemm_pooled_tap_refuses_short_clips(built_lib):
     from avex_amd import kernels as K
     from avex_amd._capi import AvexHipError

@@ -114,10 +114,23 @@ def test_heavy_tailed_checkpoint(built_lib, clips, kind):
     e_bf = rel_l2(p, p_ref)
     print(f"[{kind}] bf16 / f32 residual: pooled rel-L2 {e_bf:.2e}, frame-level {rel_l2(f, f_ref):.2e}")
     assert e_bf < 8e-3
-    f, p, n_bfh, _ = _run(sd, clips, operand_dtype="bf16", residual="half")
-    assert n_bfh == 0 and np.isfinite(f).all()
-    print(f"[{kind}] bf16 / bf16 residual: pooled rel-L2 {rel_l2(p, p_ref):.2e}")
-    assert rel_l2(p, p_ref) < 6e-3              # measured 2.3e-3 / 2.6e-3 (the bf16 bar of tests/test_gpu_e2e.py)
+    # bf16 residual stream as well.  Two clips are below the fold's 1 024-row threshold: by default they run LayerNorm kernels, which round
+    # the stream twice per sublayer (the sum, then its LayerNorm) where the folded epilogues round it once -- with these outlier channels
+    # that is 1.2e-2 against 2.6e-3 ("hidden"); both are stated, the folded form keeps the bf16 bar of tests/test_gpu_e2e.py
+    import os
+    for fold, bar in (("1", 6e-3), (None, 2e-2)):
+        old = os.environ.pop("AVEX_AMD_LN_FOLD", None)
+        if fold is not None:
+            os.environ["AVEX_AMD_LN_FOLD"] = fold
+        try:
+            f, p, n_bfh, _ = _run(sd, clips, operand_dtype="bf16", residual="half")
+        finally:
+            os.environ.pop("AVEX_AMD_LN_FOLD", None)
+            if old is not None:
+                os.environ["AVEX_AMD_LN_FOLD"] = old
+        assert n_bfh == 0 and np.isfinite(f).all()
+        print(f"[{kind}] bf16 / bf16 residual, AVEX_AMD_LN_FOLD={fold or 'auto'}: pooled rel-L2 {rel_l2(p, p_ref):.2e}")
+        assert rel_l2(p, p_ref) < bar           # measured 2.3e-3 / 2.6e-3 folded, 2.4e-3 / 1.2e-2 with LayerNorm kernels
     # f16 operands with an fp32 residual stream: the pre-LayerNorm sums never pass through f16, so the "residual" outliers are harmless;
     # the "hidden" ones clip in fc1's own f16 output and the alarm must say so
     f, p, n_32, _ = _run(sd, clips, operand_dtype="f16", residual="f32", on_overflow="ignore")
