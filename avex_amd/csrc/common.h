@@ -280,6 +280,9 @@ struct GemmArgs {
     // 0, or the number of leading output columns that exist in memory (a multiple of 4, < N): the product is computed for N (a multiple of
     // the tile width, W and bias padded by the caller) but rows of every output / residual are only n_store wide.  128-tile kernels.
     int n_store;
+    // skinny kernel (variant 7): A[m][k] *= a_scale[(m / a_scale_rows) * a_scale_ld + k] (fp32 product rounded to the operand type) as the rows
+    // are loaded: a per-(clip, channel) rescale of the input without a pass of its own (EfficientNet's squeeze-excitation)
+    const float* a_scale; int a_scale_rows; int a_scale_ld;
     // sticky range alarm: the number of (lane, launch) pairs that rounded at least one |value| > 65504 to an f16 output is added
     // here (one atomic per wave at most, at the end of the kernel); NULL = not counted.  bf16 outputs cannot overflow.
     unsigned int* ovf;

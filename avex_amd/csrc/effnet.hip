@@ -237,12 +237,13 @@ extern "C" int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, in
 
 extern "C" int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, int Cs, const float* w1_dev, const float* b1_dev,
                                  const float* w2_dev, const float* b2_dev, float* scale_dev, void* x_dev, int dtype, void* stream) {
-    AVX_REQUIRE(pool_dev && w1_dev && b1_dev && w2_dev && b2_dev && scale_dev && x_dev, "effnet_se: null argument");
+    AVX_REQUIRE(pool_dev && w1_dev && b1_dev && w2_dev && b2_dev && scale_dev, "effnet_se: null argument");      // x_dev NULL: the scale vector only
     AVX_REQUIRE(B > 0 && hw > 0 && C > 0 && C <= 2048 && Cp >= C && Cp % 8 == 0 && Cs > 0 && Cs <= 512, "effnet_se: bad shape C=%d Cp=%d Cs=%d", C, Cp, Cs);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), 0, s, pool_dev, 1.0f / (float)hw, C, Cp, Cs, w1_dev, b1_dev, w2_dev, b2_dev, scale_dev);
     const dim3 grid(512, B);
-    if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(scale_channels_kernel<__bf16>, grid, dim3(256), 0, s, (__bf16*)x_dev, hw, Cp, scale_dev);
+    if (!x_dev) {}      // the caller applies the scale itself (GemmArgs::a_scale)
+    else if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(scale_channels_kernel<__bf16>, grid, dim3(256), 0, s, (__bf16*)x_dev, hw, Cp, scale_dev);
     else hipLaunchKernelGGL(scale_channels_kernel<_Float16>, grid, dim3(256), 0, s, (_Float16*)x_dev, hw, Cp, scale_dev);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;

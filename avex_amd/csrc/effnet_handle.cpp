@@ -323,16 +323,21 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             prof.begin("dwconv", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k);
             RC(avexhip_effnet_dwconv(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.pool, dt, s));
             prof.end();
-            prof.begin("se", 0.0);
-            RC(avexhip_effnet_se(w.pool, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, w.act[dw], dt, s));
-            prof.end();
             const int M2 = Bc * h2 * w2;
             const int out = (in_buf + 3) & 3;
             const bool hooked = b.tap && ((hook_mask >> (tap + 1)) & 1u);
+            // long thin projections run in the skinny streaming kernel, which applies the squeeze-excitation scale to its A rows as it loads
+            // them: the rescale pass over the expanded tensor (read + write) disappears
+            static const bool no_se_fold = getenv("AVEX_AMD_SE_FOLD") && atoi(getenv("AVEX_AMD_SE_FOLD")) == 0;
+            const bool se_fold = !no_se_fold && !hooked && M2 >= 32768 && (b.cp_exp == 64 || b.cp_exp == 128 || b.cp_exp == 256) && pad128(b.cout) * b.cp_exp <= 32768;
+            prof.begin("se", 0.0);
+            RC(avexhip_effnet_se(w.pool, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, se_fold ? nullptr : w.act[dw], dt, s));
+            prof.end();
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = pad128(b.cout); g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
             g.n_store = b.cp_out < g.N ? b.cp_out : 0;
             if (b.cp_out == 64 && M2 >= 32768 && !hooked) { g.N = 64; g.n_store = 0; }      // the skinny streaming kernel computes 64 columns as such
+            if (se_fold) { g.variant = 7; g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
             if (b.residual) { g.resid_half = w.act[in_buf]; g.ldrh = b.cp_in; }
             g.out_half = w.act[out]; g.ldh = b.cp_out;
             if (hooked) { g.out_raw = w.raw; g.ldraw = b.cp_out; }

@@ -806,7 +806,7 @@ static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
 // as the A operand a lane ends up with four consecutive output columns of one row (8-byte stores).  One wave = 32 rows x N per trip.
 // NT = N / 16, KS = K / 32 are compile-time (register arrays).  Epilogue: bias, activation, half residual, n_store; half output only.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NT, int KS>
+template <typename T, int NT, int KS, bool SCALE>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
@@ -857,6 +857,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
         } else {
             load_rows(blk, af);
         }
+        if constexpr (SCALE) {
+            // A rows scaled per (clip, input channel) on their way into the product: EfficientNet's squeeze-excitation rescale without its
+            // own pass over the expanded tensor.  Same arithmetic as scale_channels_kernel (fp32 product, rounded to the operand type).
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                int64_t row = r0 + rt * 16 + lr;
+                row = row < p.M ? row : p.M - 1;
+                const float* sp = p.a_scale + (row / p.a_scale_rows) * p.a_scale_ld + lq * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f32x4 s0 = *(const f32x4*)(sp + ks * 32), s1 = *(const f32x4*)(sp + ks * 32 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        af[ks][rt][e] = Half<T>::from((float)af[ks][rt][e] * s0[e]);
+                        af[ks][rt][4 + e] = Half<T>::from((float)af[ks][rt][4 + e] * s1[e]);
+                    }
+                }
+            }
+        }
         f32x4 acc[NT][2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nt][1] = acc[nt][0]; }
@@ -902,18 +921,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
     ovf_commit<T>(p.ovf, ovf_mx);
 }
 
-template <typename T, int NT, int KS>
+template <typename T, int NT, int KS, bool SCALE>
 static int launch_skinny(const avx::GemmArgs& a, hipStream_t s) {
     int n_cu = 256;
     { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
     const size_t lds = (size_t)NT * 16 * KS * 32 * 2;
-    AVX_ENSURE_LDS((gemm_skinny_kernel<T, NT, KS>), 64 * 1024);
+    AVX_ENSURE_LDS((gemm_skinny_kernel<T, NT, KS, SCALE>), 64 * 1024);
     const int64_t nblk = ((int64_t)a.M + 127) / 128;
     int per_cu = (int)(128 * 1024 / (lds > 16384 ? lds : 16384));      // workgroups per CU the LDS (and ~100 registers per lane) allows
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int64_t grid = (int64_t)n_cu * per_cu;
     grid = grid < nblk ? grid : nblk;
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, NT, KS>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, NT, KS, SCALE>), dim3((unsigned)grid), dim3(256), lds, s, a);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
@@ -928,7 +947,7 @@ static bool skinny_ok(const avx::GemmArgs& a) {
 
 template <typename T>
 static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
-#define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) return launch_skinny<T, NTV, KSV>(a, s)
+#define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) return a.a_scale ? launch_skinny<T, NTV, KSV, true>(a, s) : launch_skinny<T, NTV, KSV, false>(a, s)
     AVX_SK(4, 2); AVX_SK(4, 4); AVX_SK(4, 8); AVX_SK(8, 2); AVX_SK(8, 4); AVX_SK(8, 8); AVX_SK(16, 2); AVX_SK(16, 4);
 #undef AVX_SK
     avexhip_set_error("gemm: no skinny instantiation for N=%d K=%d", a.N, a.K);
@@ -938,6 +957,7 @@ static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
     // variant 7 / auto for long thin products: the skinny streaming kernel (W resident in LDS, A rows straight into MFMA operands)
+    AVX_REQUIRE(!a.a_scale || (a.variant == 7 && a.a_scale_rows > 0 && a.a_scale_ld >= a.K && a.a_scale_ld % 4 == 0), "gemm: a_scale is built for the skinny kernel (variant 7)");
     if (a.variant == 7) {
         AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K, N in {64, 128, 256} with N K <= 32768, half output only (N=%d K=%d)", a.N, a.K);
         return launch_skinny_any<T>(a, s);

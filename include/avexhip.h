@@ -115,14 +115,15 @@ int avexhip_melspec_forward(const avexhip_melspec_plan* plan, const float* wav_d
                             float* out_dev, int* minmax_dev, void* stream);
 
 /* EfficientNet-B0 building blocks that are not GEMMs (avex/models/efficientnet.py:55-66 -> torchvision efficientnet_b0).
- * Activations are NHWC half with channels padded to Cp (multiple of 128; padding channels stay zero); 1x1 convolutions
+ * Activations are NHWC half with channels padded to Cp (a multiple of 8; the handle uses 64 or multiples of 128; padding channels stay zero); 1x1 convolutions
  * are avexhip_gemm calls with BatchNorm folded into weight/bias and gelu = 2 (SiLU).
  *  stem:   img [B, H, W] fp32 (the mel image; the reference feeds three copies of it, efficientnet.py:133-135) ->
  *          Conv2d(3->32, 3x3, s2, p1) with channel-summed, BN-folded weights w [9, Cp] + bias [Cp] + SiLU -> [B, Ho, Wo, Cp];
  *          raw_dev (optional, fp32 [B, Ho, Wo, Cp]) receives the pre-activation values.
  *  dwconv: depthwise k x k (3 | 5), stride (1 | 2), padding (k-1)/2, w [k*k, Cp] BN-folded, + SiLU; pool_dev [B, Cp] fp32
  *          (optional) receives the per-clip channel sums of the output (squeeze of squeeze-excitation).
- *  se:     scale[b, c] = sigmoid(W2 silu(W1 (pool / hw) + b1) + b2), then x[b, :, c] *= scale[b, c] in place. */
+ *  se:     scale[b, c] = sigmoid(W2 silu(W1 (pool / hw) + b1) + b2), then x[b, :, c] *= scale[b, c] in place (x_dev NULL: the scale
+ *          vector only -- the EfficientNet handle applies it inside the projection that follows when that runs in the skinny kernel). */
 int avexhip_effnet_stem(const float* img_dev, int B, int H, int W, const float* w_dev, const float* bias_dev, int Cp,
                         void* out_dev, float* raw_dev, int dtype, void* stream);
 int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, int Cp, int k, int stride, const float* w_dev,
@@ -208,7 +209,7 @@ int avexhip_cast_half_to_f32(const void* in_dev, float* out_dev, int64_t n, int 
  *   if resid / resid_half:  acc' = resid[m,n] * alpha + acc'   (DeepNorm residual, backbone.py:360,372)
  *   if gelu:     acc' = gelu_erf(acc')                 (backbone.py:368)
  *   out_f32 / out_half (either may be NULL) receive acc'.
- * Requirements: N % 128 == 0, K % 64 == 0, all leading dims in elements, 16-byte aligned rows. */
+ * Requirements: N % 128 == 0 (64 with the skinny kernel), K % 64 == 0, all leading dims in elements, 16-byte aligned rows. */
 typedef struct {
     const void*  A;  int64_t lda;      /* [M, K] half */
     const void*  W;  int64_t ldw;      /* [N, K] half */
@@ -223,7 +224,10 @@ typedef struct {
     float* out_raw;  int64_t ldraw;
     int32_t variant;                   /* 0 = auto; 1 = 128-tile, register staging; 3 = 128-tile LDS-DMA;
                                           5 (or 2) = 256-tile half-tile LDS-DMA pipeline, persistent workgroups
-                                          (needs N % 256 == 0, K >= 128) */
+                                          (needs N % 256 == 0, K >= 128); 7 = skinny streaming kernel for long thin
+                                          products (K, N in {64, 128, 256}, N K <= 32768, half output, bias / activation /
+                                          half residual only; auto from 32 768 rows): the whole W in LDS, A rows straight
+                                          into MFMA operands */
     /* LayerNorm folded into the GEMMs around it (all NULL/0 = off; the 256-tile kernel only: N % 256 == 0, K >= 128).
      * A tensor y that is only consumed through LayerNorm (backbone.py:363,374: x = LN(residual * alpha + sublayer))
      * stays raw in the operand type.  The GEMM that produces it writes per-row partial statistics
