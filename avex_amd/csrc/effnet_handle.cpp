@@ -336,7 +336,8 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = pad128(b.cout); g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
             g.n_store = b.cp_out < g.N ? b.cp_out : 0;
-            if (b.cp_out == 64 && M2 >= 32768 && !hooked) { g.N = 64; g.n_store = 0; }      // the skinny streaming kernel computes 64 columns as such
+            const bool skinny_k = b.cp_exp == 64 || b.cp_exp == 128 || b.cp_exp == 256;
+            if (b.cp_out == 64 && M2 >= 32768 && !hooked && skinny_k) { g.N = 64; g.n_store = 0; }      // the skinny streaming kernel computes 64 columns as such
             if (se_fold) { g.variant = 7; g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
             if (b.residual) { g.resid_half = w.act[in_buf]; g.ldrh = b.cp_in; }
             g.out_half = w.act[out]; g.ldh = b.cp_out;
