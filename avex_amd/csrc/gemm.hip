@@ -876,45 +876,50 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                 }
             }
         }
-        f32x4 acc[NT][2];
+        // 128 output columns at a time (N = 256: two passes over the same A fragments): 64 accumulator registers instead of 128
+        constexpr int NTP = NT > 8 ? 8 : NT;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nt][1] = acc[nt][0]; }
+        for (int np = 0; np < NT; np += NTP) {
+            f32x4 acc[NTP][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+            for (int nt = 0; nt < NTP; ++nt) { acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nt][1] = acc[nt][0]; }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nt * 16 + lr;
-                const v8 wf = *(const v8*)(smem + ((n * KC + ((ks * 4 + lq) ^ (n & SW))) << 4));
-                acc[nt][0] = mfma16(wf, af[ks][0], acc[nt][0]);
-                acc[nt][1] = mfma16(wf, af[ks][1], acc[nt][1]);
-            }
-        }
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int64_t m = r0 + rt * 16 + lr;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int t = 0; t < NT / 4; ++t) {
-                const int n = t * 64 + lq * 16;                 // this lane's 16 consecutive columns
-                if (n >= nst) continue;
-                v8 rh[2];
-                if (p.resid_half) { rh[0] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n); rh[1] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n + 8); }
-                v8 h[2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = acc[4 * t + q][rt];
-                    if (p.bias) v += *(const f32x4*)(p.bias + n + 4 * q);
-                    if (p.resid_half) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (float)rh[q >> 1][4 * (q & 1) + e] * alpha + v[e];
-                    }
-                    if (p.gelu) v = act4_any(v, p.gelu);
-                    ovf_see4<T>(ovf_mx, v);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = Half<T>::from(v[e]);
+                for (int nt = 0; nt < NTP; ++nt) {
+                    const int n = (np + nt) * 16 + lr;
+                    const v8 wf = *(const v8*)(smem + ((n * KC + ((ks * 4 + lq) ^ (n & SW))) << 4));
+                    acc[nt][0] = mfma16(wf, af[ks][0], acc[nt][0]);
+                    acc[nt][1] = mfma16(wf, af[ks][1], acc[nt][1]);
                 }
-                *(v8*)((T*)p.out_half + m * p.ldh + n) = h[0];
-                *(v8*)((T*)p.out_half + m * p.ldh + n + 8) = h[1];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int64_t m = r0 + rt * 16 + lr;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int t = 0; t < NTP / 4; ++t) {
+                    const int n = (np / 4 + t) * 64 + lq * 16;      // this lane's 16 consecutive columns
+                    if (n >= nst) continue;
+                    v8 rh[2];
+                    if (p.resid_half) { rh[0] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n); rh[1] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n + 8); }
+                    v8 h[2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = acc[4 * t + q][rt];
+                        if (p.bias) v += *(const f32x4*)(p.bias + n + 4 * q);
+                        if (p.resid_half) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (float)rh[q >> 1][4 * (q & 1) + e] * alpha + v[e];
+                        }
+                        if (p.gelu) v = act4_any(v, p.gelu);
+                        ovf_see4<T>(ovf_mx, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = Half<T>::from(v[e]);
+                    }
+                    *(v8*)((T*)p.out_half + m * p.ldh + n) = h[0];
+                    *(v8*)((T*)p.out_half + m * p.ldh + n + 8) = h[1];
+                }
             }
         }
     }
