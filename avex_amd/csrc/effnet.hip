@@ -58,13 +58,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     *(v8*)(out + o) = h;
 }
 
+#ifndef DW_PIX
+#define DW_PIX 8      // 4: 13.5 ms per 256 clips, 8: 12.8, 12: 13.2, 16: 14.1 (fewer L2 reads per output against registers)
+#endif
 // one thread: 8 channels, PIX consecutive output pixels along x of one row; squeeze sums via atomics
 template <typename T, int KS, int ST>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
                                                      const float* __restrict__ w /*[KS*KS][Cp]*/, const float* __restrict__ bias,
                                                      T* __restrict__ out, float* __restrict__ pool /*[B][Cp]*/) {
     typedef typename Half<T>::v8 v8;
-    constexpr int PAD = (KS - 1) / 2, PIX = 4;
+    constexpr int PAD = (KS - 1) / 2, PIX = DW_PIX;
     const int cg = Cp >> 3;
     const int xg = (Wo + PIX - 1) / PIX;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -213,7 +216,7 @@ template <typename T>
 static int dw_launch(const void* in, int B, int H, int W, int Cp, int k, int st, const float* w, const float* bias, void* out, float* pool, hipStream_t s) {
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
-    const int64_t n = (int64_t)Ho * ((Wo + 3) / 4) * (Cp / 8);
+    const int64_t n = (int64_t)Ho * ((Wo + DW_PIX - 1) / DW_PIX) * (Cp / 8);
     const dim3 grid((unsigned)((n + 255) / 256), B);
     if (pool) AVX_HIP_CHECK(hipMemsetAsync(pool, 0, sizeof(float) * (size_t)B * Cp, s));
 #define AVX_DW(KS, ST) hipLaunchKernelGGL((dwconv_kernel<T, KS, ST>), grid, dim3(256), 0, s, (const T*)in, H, W, Ho, Wo, Cp, w, bias, (T*)out, pool)
