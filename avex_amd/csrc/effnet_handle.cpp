@@ -244,7 +244,7 @@ extern "C" avexhip_effnet* avexhip_effnet_create(const avexhip_effnet_config* cf
     h->cfg = c;
     if (!(h->cfg.bn_eps > 0.f)) h->cfg.bn_eps = 1e-5f;
     h->dtype = c.operand_dtype;
-    h->c0 = c.stem_channels; h->cp0 = ((c.stem_channels + 63) / 64) * 64; h->head = c.head_channels;
+    h->c0 = c.stem_channels; h->cp0 = ((c.stem_channels + 31) / 32) * 32; h->head = c.head_channels;      // cp0 = 32 for B0 / B1: the stem's output and the first depthwise run at the real width
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     if (h->init_alarm() != AVEXHIP_OK || effnet_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
     return h;
@@ -329,16 +329,20 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             // long thin projections run in the skinny streaming kernel, which applies the squeeze-excitation scale to its A rows as it loads
             // them: the rescale pass over the expanded tensor (read + write) disappears
             static const bool no_se_fold = getenv("AVEX_AMD_SE_FOLD") && atoi(getenv("AVEX_AMD_SE_FOLD")) == 0;
-            const bool se_fold = !no_se_fold && !hooked && M2 >= 32768 && (b.cp_exp == 64 || b.cp_exp == 128 || b.cp_exp == 256) && pad128(b.cout) * b.cp_exp <= 32768;
+            const bool skinny_k = b.cp_exp == 32 || b.cp_exp == 64 || b.cp_exp == 128 || b.cp_exp == 256;
+            const bool skinny_proj = !hooked && skinny_k && pad128(b.cout) * b.cp_exp <= 32768 && (b.cp_out == 64 || b.cp_out % 128 == 0);
+            const bool se_fold = !no_se_fold && skinny_proj;
             prof.begin("se", 0.0);
             RC(avexhip_effnet_se(w.pool, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, se_fold ? nullptr : w.act[dw], dt, s));
             prof.end();
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = pad128(b.cout); g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
             g.n_store = b.cp_out < g.N ? b.cp_out : 0;
-            const bool skinny_k = b.cp_exp == 64 || b.cp_exp == 128 || b.cp_exp == 256;
-            if (b.cp_out == 64 && M2 >= 32768 && !hooked && skinny_k) { g.N = 64; g.n_store = 0; }      // the skinny streaming kernel computes 64 columns as such
-            if (se_fold) { g.variant = 7; g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
+            if (skinny_proj) {      // whatever the row count: the 128-tile kernels do not take K = 32 or 64 columns
+                g.variant = 7;
+                if (b.cp_out == 64) { g.N = 64; g.n_store = 0; }
+                if (se_fold) { g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
+            }
             if (b.residual) { g.resid_half = w.act[in_buf]; g.ldrh = b.cp_in; }
             g.out_half = w.act[out]; g.ldh = b.cp_out;
             if (hooked) { g.out_raw = w.raw; g.ldraw = b.cp_out; }

@@ -944,7 +944,7 @@ static int launch_skinny(const avx::GemmArgs& a, hipStream_t s) {
 
 // does the skinny kernel take this product?  (half output only, no fp32 / raw outputs, no folded LayerNorm, no row mask)
 static bool skinny_ok(const avx::GemmArgs& a) {
-    if (!(a.K == 64 || a.K == 128 || a.K == 256) || !(a.N == 64 || a.N == 128 || a.N == 256) || a.N * a.K > 32768) return false;
+    if (!(a.K == 32 || a.K == 64 || a.K == 128 || a.K == 256) || !(a.N == 64 || a.N == 128 || a.N == 256) || a.N * a.K > 32768) return false;
     if (!a.out_half || a.out_f32 || a.out_raw || a.resid || a.row_zero || a.ln_rows || a.lnr_y || a.stats_out || a.pool_part) return false;
     if (a.lda % 8 || a.ldw % 8 || a.ldh % 8 || (a.resid_half && a.ldrh % 8) || (a.n_store > 0 && a.n_store % 16)) return false;
     return true;
@@ -953,7 +953,7 @@ static bool skinny_ok(const avx::GemmArgs& a) {
 template <typename T>
 static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
 #define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) return a.a_scale ? launch_skinny<T, NTV, KSV, true>(a, s) : launch_skinny<T, NTV, KSV, false>(a, s)
-    AVX_SK(4, 2); AVX_SK(4, 4); AVX_SK(4, 8); AVX_SK(8, 2); AVX_SK(8, 4); AVX_SK(8, 8); AVX_SK(16, 2); AVX_SK(16, 4);
+    AVX_SK(4, 1); AVX_SK(8, 1); AVX_SK(4, 2); AVX_SK(4, 4); AVX_SK(4, 8); AVX_SK(8, 2); AVX_SK(8, 4); AVX_SK(8, 8); AVX_SK(16, 2); AVX_SK(16, 4);
 #undef AVX_SK
     avexhip_set_error("gemm: no skinny instantiation for N=%d K=%d", a.N, a.K);
     return AVEXHIP_ERR_INVALID;
@@ -964,10 +964,10 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     // variant 7 / auto for long thin products: the skinny streaming kernel (W resident in LDS, A rows straight into MFMA operands)
     AVX_REQUIRE(!a.a_scale || (a.variant == 7 && a.a_scale_rows > 0 && a.a_scale_ld >= a.K && a.a_scale_ld % 4 == 0), "gemm: a_scale is built for the skinny kernel (variant 7)");
     if (a.variant == 7) {
-        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K, N in {64, 128, 256} with N K <= 32768, half output only (N=%d K=%d)", a.N, a.K);
+        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K in {32, 64, 128, 256}, N in {64, 128, 256} with N K <= 32768, half output only (N=%d K=%d)", a.N, a.K);
         return launch_skinny_any<T>(a, s);
     }
-    if (a.variant == 0 && a.M >= 32768 && skinny_ok(a) &&
+    if (a.variant == 0 && a.M >= 32768 && a.K >= 64 && skinny_ok(a) &&
         (a.N % BN != 0 || (!(getenv("AVEX_AMD_GEMM_SKINNY") && atoi(getenv("AVEX_AMD_GEMM_SKINNY")) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"))))
         return launch_skinny_any<T>(a, s);
     // variant: 0 = auto, 1 = 128-tile register staging, 3 = 128-tile LDS-DMA, 5 (or 2, its tile-per-workgroup ancestor's number) =
@@ -1040,9 +1040,9 @@ namespace avx {
 int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     AVX_REQUIRE(a.A && a.W, "gemm: A and W must be non-null");
     AVX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-    AVX_REQUIRE(a.N % BN == 0 || (a.N == 64 && (a.variant == 7 || (a.variant == 0 && a.M >= 32768)) && skinny_ok(a)),
+    AVX_REQUIRE(a.N % BN == 0 || (a.N == 64 && (a.variant == 7 || (a.variant == 0 && a.M >= 32768 && a.K >= 64)) && skinny_ok(a)),
                 "gemm: N=%d must be a multiple of %d (64 columns: the skinny streaming kernel only, >= 32768 rows)", a.N, BN);
-    AVX_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+    AVX_REQUIRE(a.K % BK == 0 || (a.K == 32 && a.variant == 7), "gemm: K=%d must be a multiple of %d (32: the skinny kernel, variant 7)", a.K, BK);
     AVX_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
     AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw, "gemm: no output buffer");
     AVX_REQUIRE((!a.out_f32 || a.ldo % 4 == 0) && (!a.out_half || a.ldh % 4 == 0) &&
