@@ -41,7 +41,7 @@ class GemmArgs(C.Structure):
                 ("ln_rows", C.c_void_p), ("ln_s", C.c_void_p),
                 ("lnr_y", C.c_void_p), ("ldy", C.c_int64), ("lnr_rows", C.c_void_p),
                 ("lnr_gamma", C.c_void_p), ("lnr_beta", C.c_void_p), ("stats_out", C.c_void_p),
-                ("overflow_count", C.c_void_p), ("pool_part", C.c_void_p), ("pool_rows", C.c_int32)]
+                ("overflow_count", C.c_void_p), ("pool_part", C.c_void_p), ("pool_rows", C.c_int32), ("pool_mode", C.c_int32)]
 
 
 class BeatsConfig(C.Structure):
@@ -125,6 +125,7 @@ SYMBOLS = {
     "avexhip_cast_half_to_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "avexhip_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _P]),
     "avexhip_pool_reduce": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
+    "avexhip_pool_reduce_mode": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.c_int, _P]),
     "avexhip_ln_rowstats": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, _P, _P]),
     "avexhip_layernorm": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P,
                                     C.c_int64, C.c_int, _P]),

@@ -303,9 +303,9 @@ class Model(ModelBase):
         was_training = self.training
         if was_training:
             self.eval()
-        # mean-aggregation lets the device reduce every tap to (B, 768) instead of writing (B, T', 768)
+        # mean / max / cls_token aggregation lets the device reduce every tap to (B, 768) instead of writing (B, T', 768)
         own_hooks_only = all(len(m._forward_hooks) <= 1 for m in self._tap_modules())
-        self._pooled_taps = aggregation == "mean" and own_hooks_only
+        self._pooled_taps = aggregation if (aggregation != "none" and own_hooks_only) else False
         self._want_features = False
         try:
             self._clear_hook_outputs()

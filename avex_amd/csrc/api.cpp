@@ -58,11 +58,14 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     g.resid_half = a->resid_half; g.ldrh = a->ldrh;
     g.out_f32 = a->out_f32; g.ldo = a->ldo; g.out_half = a->out_half; g.ldh = a->ldh;
     g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
-    g.pool_part = a->pool_part; g.pool_T = a->pool_rows;
+    g.pool_part = a->pool_part; g.pool_T = a->pool_rows; g.pool_mode = a->pool_mode;
     return avx::gemm(g, dtype, (hipStream_t)stream);
 }
 extern "C" int avexhip_pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, void* stream) {
     return avx::pool_reduce(part, B, T, N, out, ldo, (hipStream_t)stream);
+}
+extern "C" int avexhip_pool_reduce_mode(const float* part, int B, int T, int N, float* out, int64_t ldo, int mode, void* stream) {
+    return avx::pool_reduce(part, B, T, N, out, ldo, (hipStream_t)stream, mode);
 }
 extern "C" int avexhip_ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, void* stream) {
     return avx::ln_rowstats(stats, M, nseg, eps, rows, (hipStream_t)stream);
@@ -407,6 +410,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     const int Tt = nt * nf;
     AVX_REQUIRE(Tt >= 1, "beats_forward: input too short (%d frames -> 0 tokens)", frames);
     AVX_REQUIRE(hook_mask == 0 || hook_out, "beats_forward: hook_mask set but hook_out is NULL");
+    AVX_REQUIRE(hook_pooled >= 0 && hook_pooled <= 3, "beats_forward: hook_pooled = %d (0 full taps, 1 mean, 2 max, 3 first token)", hook_pooled);
     AVX_REQUIRE((hook_mask >> (L + 1)) == 0, "beats_forward: hook_mask has bits beyond layer %d", L);
     // hook 0 is post_extract_proj's output; a model with embed_dim == encoder_embed_dim has no such layer (beats.py:357-358)
     AVX_REQUIRE(!(hook_mask & 1u) || h->w_post, "beats_forward: hook 0 (post_extract_proj) requested but this model has no post_extract_proj");
@@ -509,7 +513,7 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
         if (hook0 && h->w_post) {
             // the reference's hook holds the tensor that the encoder then zeroes in place at padded tokens
             // (beats.py:359-361 + backbone.py:169-170), so the tap equals x after masking
-            if (hook_pooled) RC(avx::mean_pool(x32, Bc, Tt, E, nullptr, hook_out[0] + (size_t)c0 * E, cs));
+            if (hook_pooled) RC(avx::agg_pool(x32, Bc, Tt, E, hook_pooled, hook_out[0] + (size_t)c0 * E, cs));
             else AVX_HIP_CHECK(hipMemcpyAsync(hook_out[0] + (size_t)c0 * Tt * E, x32, sizeof(float) * (size_t)M * E, hipMemcpyDeviceToDevice, cs));
         }
         // 3. convolutional positional embedding + residual, encoder LayerNorm

@@ -277,6 +277,7 @@ struct GemmArgs {
     // pool_part[block][slot][N], slot 0 = the clip of the block's first row, slot 1 = the next clip.  avx::pool_reduce adds a clip's
     // blocks in order and divides by pool_T.  256-tile kernel, generic epilogue.
     float* pool_part; int pool_T;
+    int pool_mode;            // 0: column sums (mean after pool_reduce); 1: column maxima; 2: each clip's FIRST row, written straight to pool_part = [clips][N]
     // 0, or the number of leading output columns that exist in memory (a multiple of 4, < N): the product is computed for N (a multiple of
     // the tile width, W and bias padded by the caller) but rows of every output / residual are only n_store wide.  128-tile kernels.
     int n_store;
@@ -293,7 +294,10 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // fp32 NHWC rows [B * HW, ld] -> NCHW [B, C, HW], optionally undoing a folded BatchNorm: (x - shift[c]) / scale[c] (effnet.hip)
 int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s);
 // GemmArgs::pool_part [ceil(M / 64)][2][N] -> out[b][n] = mean over clip b's T rows (b < B, M = B * T), blocks added in order
-int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s);
+//                                                 (mode 1: the maximum over the clip's rows instead)
+int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s, int mode = 0);
+// fp32 [B, T, C] -> [B, C]: mode 1 mean, 2 max over the T rows, 3 the first row (the aggregations of extract_embeddings, beats_model.py:403-417)
+int agg_pool(const float* in, int B, int T, int C, int mode, float* out, hipStream_t s);
 // partial statistics [M][nseg][2] (GemmArgs::stats_out) -> [M][2] (rstd, -mu * rstd), summed in segment order (deterministic)
 int ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, hipStream_t s);
 // ga = alpha * gamma, bb = bias + alpha * beta: the column vectors a residual-side fold takes (GemmArgs::lnr_prefolded)

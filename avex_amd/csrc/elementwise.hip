@@ -439,16 +439,28 @@ __global__ __launch_bounds__(256) void ln_rowstats_kernel(const float* __restric
 }
 
 // GemmArgs::pool_part -> per-clip means: one thread per (clip, column); a clip's 64-row blocks are added in increasing order
-__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int B, int T, int N, float* __restrict__ out, int64_t ldo) {
+__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int B, int T, int N, float* __restrict__ out, int64_t ldo, int mode) {
     const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (n >= N) return;
     const int64_t r0 = (int64_t)b * T, r1 = r0 + T - 1;
-    float acc = 0.f;
+    float acc = mode == 1 ? -__builtin_inff() : 0.f;
     for (int64_t rb = r0 >> 6; rb <= (r1 >> 6); ++rb) {
         const int64_t first_clip = (rb * 64) / T;       // the clip of the block's first row owns slot 0
-        acc += part[(rb * 2 + (first_clip == b ? 0 : 1)) * N + n];
+        const float v = part[(rb * 2 + (first_clip == b ? 0 : 1)) * N + n];
+        acc = mode == 1 ? fmaxf(acc, v) : acc + v;
     }
-    out[(int64_t)b * ldo + n] = acc * (1.0f / (float)T);
+    out[(int64_t)b * ldo + n] = mode == 1 ? acc : acc * (1.0f / (float)T);
+}
+
+// fp32 [B, T, C] -> [B, C]: the maximum over a clip's rows (mode 2) or its first row (mode 3)
+__global__ __launch_bounds__(256) void agg_pool_kernel(const float* __restrict__ in, int T, int C, int mode, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    const float* p = in + (int64_t)b * T * C + c;
+    float v = p[0];
+    if (mode == 2)
+        for (int t = 1; t < T; ++t) v = fmaxf(v, p[(int64_t)t * C]);
+    out[(int64_t)b * C + c] = v;
 }
 
 // column vectors of a residual-side LayerNorm fold: ga = alpha * gamma, bb = bias + alpha * beta (GemmArgs::lnr_prefolded)
@@ -599,9 +611,17 @@ int token_embed_ln(const void* patches, const float* pos, const float* cls, cons
     return AVEXHIP_OK;
 }
 
-int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s) {
-    AVX_REQUIRE(part && out && B > 0 && T >= 64 && N > 0, "pool_reduce: bad arguments (B=%d T=%d N=%d)", B, T, N);
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, part, B, T, N, out, ldo);
+int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s, int mode) {
+    AVX_REQUIRE(part && out && B > 0 && T >= 64 && N > 0 && (mode == 0 || mode == 1), "pool_reduce: bad arguments (B=%d T=%d N=%d mode=%d)", B, T, N, mode);
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, part, B, T, N, out, ldo, mode);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+int agg_pool(const float* in, int B, int T, int C, int mode, float* out, hipStream_t s) {
+    if (mode == 1) return mean_pool(in, B, T, C, nullptr, out, s);
+    AVX_REQUIRE(in && out && B > 0 && T > 0 && C > 0 && (mode == 2 || mode == 3), "agg_pool: bad arguments (mode %d)", mode);
+    hipLaunchKernelGGL(agg_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, in, T, C, mode, out);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }

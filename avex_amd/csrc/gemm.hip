@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
-    static_assert(EPI >= 0 && EPI <= 2 && LN >= 0 && LN <= 3 && (EPI != 1 || LN <= 1) && (EPI != 0 || LN == 0), "epilogue selector");
+    static_assert(EPI >= 0 && EPI <= 2 && LN >= 0 && LN <= 3 && (EPI != 1 || LN <= 1), "epilogue selector");      // (EPI 0: LN is the pool mode)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;      // wm also selects the stagger group (waves 4-7 lag one barrier)
@@ -669,9 +669,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 if (p.bias) { b0 = *(const f32x4*)(p.bias + nb); b1 = *(const f32x4*)(p.bias + nb + 4); }
                 f32x4 ls0 = b0, ls1 = b0, lg0 = b0, lg1 = b0, lb0 = b0, lb1 = b0;     // folded-LayerNorm column vectors (see GemmArgs)
                 // pool_part: column sums of the raw tap over this wave's 64 rows, split at the one clip boundary a 64-row block can hold
-                f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = pa0, pb0 = pa0, pb1 = pa0;
+                // (EPI 0 reads its third template argument as the pool mode -- 0 none, 1 column sums, 2 column maxima, 3 each clip's first row --
+                //  so that the ordinary generic epilogue carries none of this: as run-time branches it cost 68 spilled registers)
+                constexpr int POOL = EPI == 0 ? LN : 0;
+                const float pinit = POOL == 2 ? -__builtin_inff() : 0.f;
+                f32x4 pa0 = {pinit, pinit, pinit, pinit}, pa1 = pa0, pb0 = pa0, pb1 = pa0;
                 const int pool_rb = (em0 + wn * 64) >> 6;
-                const int pool_bnd = p.pool_part ? (pool_rb * 64 / p.pool_T + 1) * p.pool_T : 0;      // first row of the block's second clip
+                const int pool_bnd = POOL ? (pool_rb * 64 / p.pool_T + 1) * p.pool_T : 0;      // first row of the block's second clip
                 if (p.ln_rows) { ls0 = *(const f32x4*)(p.ln_s + nb); ls1 = *(const f32x4*)(p.ln_s + nb + 4); }
                 if (p.lnr_y) {      // (the launcher has folded alpha into gamma and alpha * beta into the bias: GemmArgs::lnr_prefolded)
                     lg0 = *(const f32x4*)(p.lnr_gamma + nb); lg1 = *(const f32x4*)(p.lnr_gamma + nb + 4);
@@ -708,7 +712,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                                 st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb), v0, p.nt);
                                 st_out((f32x4*)(p.out_raw + (int64_t)m * p.ldraw + nb + 4), v1, p.nt);
                             }
-                            if (p.pool_part) {
+                            if constexpr (POOL == 3) {      // pool_part IS the [clips][N] output: the row that starts a clip is copied
+                                if (m == pool_bnd || m == pool_bnd - p.pool_T) {
+                                    float* dst = p.pool_part + (int64_t)(m / p.pool_T) * p.N + nb;
+                                    *(f32x4*)dst = v0; *(f32x4*)(dst + 4) = v1;
+                                }
+                            } else if constexpr (POOL == 2) {
+                                if (m < pool_bnd) { pa0 = __builtin_elementwise_max(pa0, v0); pa1 = __builtin_elementwise_max(pa1, v1); }
+                                else { pb0 = __builtin_elementwise_max(pb0, v0); pb1 = __builtin_elementwise_max(pb1, v1); }
+                            } else if constexpr (POOL == 1) {
                                 if (m < pool_bnd) { pa0 += v0; pa1 += v1; } else { pb0 += v0; pb1 += v1; }
                             }
                             if (p.resid) {
@@ -753,15 +765,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                if (p.pool_part) {
-                    // the 8 lanes with the same (lane & 7) hold the same 8 columns of different rows: add them in a fixed order
+                if constexpr (POOL == 1 || POOL == 2) {
+                    // the 8 lanes with the same (lane & 7) hold the same 8 columns of different rows: combine them in a fixed order
                     // (xor 8, 16, 32), then lanes 0..7 write the block's two slots
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
 #pragma unroll
                         for (int sh = 8; sh <= 32; sh <<= 1) {
-                            pa0[e] += __shfl_xor(pa0[e], sh, 64); pa1[e] += __shfl_xor(pa1[e], sh, 64);
-                            pb0[e] += __shfl_xor(pb0[e], sh, 64); pb1[e] += __shfl_xor(pb1[e], sh, 64);
+                            if constexpr (POOL == 2) {
+                                pa0[e] = __builtin_fmaxf(pa0[e], __shfl_xor(pa0[e], sh, 64)); pa1[e] = __builtin_fmaxf(pa1[e], __shfl_xor(pa1[e], sh, 64));
+                                pb0[e] = __builtin_fmaxf(pb0[e], __shfl_xor(pb0[e], sh, 64)); pb1[e] = __builtin_fmaxf(pb1[e], __shfl_xor(pb1[e], sh, 64));
+                            } else {
+                                pa0[e] += __shfl_xor(pa0[e], sh, 64); pa1[e] += __shfl_xor(pa1[e], sh, 64);
+                                pb0[e] += __shfl_xor(pb0[e], sh, 64); pb1[e] += __shfl_xor(pb1[e], sh, 64);
+                            }
                         }
                     }
                     if (er == 0 && pool_rb * 64 < p.M) {
@@ -988,7 +1005,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         if (variant == 0 || variant == 2 || variant == 5) variant = 3;
     }
     if (a.pool_part) {
-        AVX_REQUIRE(a.pool_T >= 64, "gemm: pool_part needs clips of at least 64 rows (got %d)", a.pool_T);
+        AVX_REQUIRE(a.pool_T >= 64 && a.pool_mode >= 0 && a.pool_mode <= 2, "gemm: pool_part needs clips of at least 64 rows (got %d) and pool_mode 0..2 (got %d)", a.pool_T, a.pool_mode);
         AVX_REQUIRE((a.variant == 0 || a.variant == 2 || a.variant == 5) && a.N % T2 == 0 && a.K >= 2 * BK, "gemm: pool_part is built for the 256-tile kernel only");
         variant = 5;
     }
@@ -1016,6 +1033,11 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         if (fast_resid) {
             if (a.lnr_y) return a.stats_out ? launch256<T, 2, 3>(a5, grid, s) : launch256<T, 2, 1>(a5, grid, s);
             return a.stats_out ? launch256<T, 2, 2>(a5, grid, s) : launch256<T, 2, 0>(a5, grid, s);
+        }
+        if (a.pool_part) {
+            if (a.pool_mode == 0) return launch256<T, 0, 1>(a5, grid, s);
+            if (a.pool_mode == 1) return launch256<T, 0, 2>(a5, grid, s);
+            return launch256<T, 0, 3>(a5, grid, s);
         }
         return launch256<T, 0, 0>(a5, grid, s);
     }

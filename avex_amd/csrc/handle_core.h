@@ -445,15 +445,18 @@ inline Tap tap_begin(const CoreCfg& c, const CoreWs& w, const CoreIo& io, int la
     const size_t per_clip = io.hook_pooled ? (size_t)c.E : (size_t)io.Tt * c.E;
     t.out = io.hook_out[io.hook_bit0 + layer] + io.c0 * per_clip;
     static const bool no_fuse = getenv("AVEX_AMD_POOL_FUSE") && atoi(getenv("AVEX_AMD_POOL_FUSE")) == 0;
+    // io.hook_pooled: 1 mean, 2 max, 3 first token over a clip's rows (extract_embeddings' aggregations, beats_model.py:403-417)
     t.fused = io.hook_pooled && io.Tt >= 64 && c.E % 256 == 0 && g.K >= 128 && !no_fuse;
-    if (t.fused) { g.pool_part = w.pool; g.pool_T = io.Tt; }
-    else { g.out_raw = io.hook_pooled ? w.raw : t.out; g.ldraw = c.E; }
+    if (t.fused) {
+        g.pool_T = io.Tt; g.pool_mode = io.hook_pooled - 1;
+        g.pool_part = io.hook_pooled == 3 ? t.out : w.pool;      // the first rows go straight to the caller's [B, E]
+    } else { g.out_raw = io.hook_pooled ? w.raw : t.out; g.ldraw = c.E; }
     return t;
 }
 inline int tap_finish(const Tap& t, const CoreCfg& c, const CoreWs& w, const CoreIo& io, hipStream_t cs) {
     if (!t.hooked || !io.hook_pooled) return AVEXHIP_OK;
-    if (t.fused) return avx::pool_reduce(w.pool, io.Bc, io.Tt, c.E, t.out, c.E, cs);
-    return avx::mean_pool(w.raw, io.Bc, io.Tt, c.E, nullptr, t.out, cs);
+    if (t.fused) return io.hook_pooled == 3 ? AVEXHIP_OK : avx::pool_reduce(w.pool, io.Bc, io.Tt, c.E, t.out, c.E, cs, io.hook_pooled - 1);
+    return avx::agg_pool(w.raw, io.Bc, io.Tt, c.E, io.hook_pooled, t.out, cs);
 }
 
 // fc1 (+ activation) of a prepared GemmArgs `g` (A, W, bias, fold fields set; N = F, output w.hh): plain, or the gated linear unit

@@ -383,13 +383,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
          lnr_y: Optional[torch.Tensor] = None, lnr_rows: Optional[torch.Tensor] = None,
          lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False,
          lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0,
-         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0) -> Dict[str, torch.Tensor]:
+         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0, pool_mode: str = "mean") -> Dict[str, torch.Tensor]:
     """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_rows``/``ln_s`` fold a
     LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual (the ``*_rows`` tensors come from
     :func:`ln_rowstats`), ``stats_out`` returns the per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"``;
     ``overflow`` is an optional ``uint32``/``int32`` device scalar the f16 range alarm adds to (include/avexhip.h); ``pool_rows`` = T
     treats the rows as clips of T rows and returns under ``"pooled"`` the per-clip mean of the raw output (bias added, before residual /
-    activation) without materialising it (``pool_part`` + ``avexhip_pool_reduce``)."""
+    activation) without materialising it (``pool_part`` + ``avexhip_pool_reduce``); ``pool_mode`` "max" / "cls_token" return the per-clip
+    maximum / first row instead."""
     _need_cuda(a, w)
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise ValueError("a and w must both be float16 or bfloat16")
@@ -441,15 +442,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     if pool_rows:
         if M % pool_rows:
             raise ValueError("pool_rows must divide the number of rows")
-        part = torch.full(((M + 63) // 64, 2, N), float("nan"), dtype=torch.float32, device=a.device)      # NaN: an unwritten slot that is read shows
-        args.pool_part, args.pool_rows = _ptr(part), int(pool_rows)
+        mode = {"mean": 0, "max": 1, "cls_token": 2}[pool_mode]
+        if mode == 2:
+            part = torch.full((M // pool_rows, N), float("nan"), dtype=torch.float32, device=a.device)
+        else:
+            part = torch.full(((M + 63) // 64, 2, N), float("nan"), dtype=torch.float32, device=a.device)      # NaN: an unwritten slot that is read shows
+        args.pool_part, args.pool_rows, args.pool_mode = _ptr(part), int(pool_rows), mode
     if stats_out:
         res["stats"] = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=a.device)
         args.stats_out = _ptr(res["stats"])
     check(lib().avexhip_gemm(C.byref(args), code, _stream()), "gemm")
-    if part is not None:
+    if part is not None and args.pool_mode == 2:
+        res["pooled"] = part
+    elif part is not None:
         res["pooled"] = torch.empty((M // pool_rows, N), dtype=torch.float32, device=a.device)
-        check(lib().avexhip_pool_reduce(_ptr(part), M // pool_rows, int(pool_rows), N, _ptr(res["pooled"]), N, _stream()), "pool_reduce")
+        check(lib().avexhip_pool_reduce_mode(_ptr(part), M // pool_rows, int(pool_rows), N, _ptr(res["pooled"]), N, int(args.pool_mode), _stream()), "pool_reduce")
     return res
 
 
@@ -629,6 +636,20 @@ def handle_profile(fn, h) -> List[Tuple[str, float, float]]:
     return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
 
 
+def pool_code(hook_pooled) -> int:
+    """``hook_pooled`` of the encoder forwards as the C ABI's code: False / 0 full taps, True / 1 / "mean", 2 / "max", 3 / "cls_token"
+    (the aggregations of ``extract_embeddings``, beats_model.py:403-417)."""
+    if isinstance(hook_pooled, str):
+        try:
+            return {"none": 0, "mean": 1, "max": 2, "cls_token": 3}[hook_pooled]
+        except KeyError as e:
+            raise ValueError(f"Unsupported aggregation method: {hook_pooled}") from e
+    code = int(hook_pooled)
+    if not 0 <= code <= 3:
+        raise ValueError(f"hook_pooled must be 0..3, got {hook_pooled!r}")
+    return code
+
+
 class BeatsGraph:
     """A recorded forward of a ``BeatsEncoder`` at one input shape.  ``wav`` (and ``frame_pad`` when asked for) are the graph's static
     inputs: write the next batch INTO them (``g.wav.copy_(x)``), call ``replay()``, read ``features`` / ``pooled`` / ``hooks[i]`` --
@@ -660,7 +681,7 @@ class BeatsGraph:
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._g = lib().avexhip_beats_graph_capture(enc._h, _ptr(self.wav), B, T, T, _ptr(self.frame_pad), mask, self._ptrs, int(hook_pooled),
+            self._g = lib().avexhip_beats_graph_capture(enc._h, _ptr(self.wav), B, T, T, _ptr(self.frame_pad), mask, self._ptrs, pool_code(hook_pooled),
                                                         _ptr(self.features), _ptr(self.pooled), _ptr(self._ws), self._ws.numel(), _stream())
         cur.wait_stream(side)
         if not self._g:
@@ -724,9 +745,11 @@ class BeatsEncoder:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=device)
         return self._ws
 
-    def forward(self, wav: torch.Tensor, *, hook_layers: Sequence[int] = (), hook_pooled: bool = False,
+    def forward(self, wav: torch.Tensor, *, hook_layers: Sequence[int] = (), hook_pooled=False,
                 want_features: bool = True, want_pooled: bool = False, frame_pad: Optional[torch.Tensor] = None
                 ) -> Dict[str, object]:
+        """``hook_pooled``: False -> taps ``[B, T', E]``; True / "mean", "max", "cls_token" -> ``[B, E]``, reduced over the tokens on the
+        device (inside the GEMM epilogue that produces the tap when clips have >= 64 tokens)."""
         _need_cuda(wav)
         if wav.dim() != 2:
             raise ValueError("wav must be [B, T]")
@@ -758,7 +781,7 @@ class BeatsEncoder:
             if pad.shape != (B, Tt):
                 raise ValueError(f"frame_pad must be [B={B}, T'={Tt}], got {tuple(pad.shape)}")
         check(lib().avexhip_beats_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(pad), mask, ptrs,
-                                          int(hook_pooled), _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
+                                          pool_code(hook_pooled), _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
               "beats_forward")
         if self.on_overflow != "ignore":
             new = self._new_overflow(sync=self.on_overflow in ("raise", "retry"))

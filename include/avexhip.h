@@ -250,10 +250,13 @@ typedef struct {
      * boundary it can contain: pool_part[ceil(M / 64)][2][N] fp32 (slot 0 = the clip of the block's first row).
      * avexhip_pool_reduce adds each clip's blocks in order and divides by pool_rows.  NULL = off. */
     float* pool_part; int32_t pool_rows;
+    int32_t pool_mode;                 /* 0: sums (mean after avexhip_pool_reduce); 1: maxima (avexhip_pool_reduce_mode(.., 1));
+                                          2: every clip's first row, written straight to pool_part = [M / pool_rows][N] */
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
 /* pool_part as written through avexhip_gemm_args.pool_part -> out[b, n] = mean over clip b's T rows of the raw GEMM output (bit-reproducible). */
 int avexhip_pool_reduce(const float* part_dev, int B, int T, int N, float* out_dev, int64_t ldo, void* stream);
+int avexhip_pool_reduce_mode(const float* part_dev, int B, int T, int N, float* out_dev, int64_t ldo, int mode, void* stream);   /* mode 1: maximum */
 /* stats [M][nseg][2] as written through avexhip_gemm_args.stats_out (nseg = row width / 64, even) -> rows [M][2] =
  * (rstd, -mean * rstd) with rstd = 1 / sqrt(var + eps); segments are added in order (bit-reproducible).  `rows` must be
  * readable up to M rounded up to an even number of rows. */
@@ -383,8 +386,10 @@ size_t avexhip_beats_workspace_bytes(const avexhip_beats* h, int B, int64_t T);
 
 /* hook_mask bit i (i = 0..L) selects layer i of the reference's layer map
  * (0 = backbone.post_extract_proj, i = backbone.encoder.layers.{i-1}.fc2, beats_model.py:206-227).
- * hook_out[i] receives the raw module output, batch-first [B, T', E] fp32 (hook_pooled == 0) or
- * its mean over T' [B, E] (hook_pooled == 1).  features_out: [B, T', E] fp32 or NULL.
+ * hook_out[i] receives the raw module output, batch-first [B, T', E] fp32 (hook_pooled == 0) or, reduced over
+ * the T' tokens to [B, E], its mean (1), maximum (2) or first token (3): extract_embeddings' aggregations
+ * (beats_model.py:403-417); clips of >= 64 tokens are reduced inside the GEMM epilogue that produces the tap
+ * (no [B, T', E] tensor exists).  features_out: [B, T', E] fp32 or NULL.
  * pooled_out: [B, E] fp32 (features.mean(dim=1)) or NULL.  frame_pad: optional [B, T'] uint8
  * token padding mask (1 = padded; beats.py:283-302 geometry is applied by the caller). */
 int avexhip_beats_forward(avexhip_beats* h, const float* wav_dev, int B, int64_t T,

@@ -27,6 +27,8 @@ def timeit(fn, n=10):
 cases = [("pooled features only", dict(want_features=False, want_pooled=True)),
          ("+ last-layer tap, mean-pooled", dict(hook_layers=[12], hook_pooled=True, want_features=False, want_pooled=True)),
          ("+ all 13 taps, mean-pooled", dict(hook_layers=list(range(13)), hook_pooled=True, want_features=False, want_pooled=True)),
+         ("+ all 13 taps, max over tokens", dict(hook_layers=list(range(13)), hook_pooled="max", want_features=False, want_pooled=True)),
+         ("+ all 13 taps, first token", dict(hook_layers=list(range(13)), hook_pooled="cls_token", want_features=False, want_pooled=True)),
          ("+ last-layer tap, unpooled", dict(hook_layers=[12], want_features=False, want_pooled=True)),
          ("+ all 13 taps, unpooled", dict(hook_layers=list(range(13)), want_features=False, want_pooled=True)),
          ("features [B, 496, 768] fp32", dict(want_features=True, want_pooled=False))]

@@ -75,6 +75,24 @@ def test_pooled_and_hooks_match_reference(encoder, golden_dir, tag, B, T):
     assert rel_l2(r2["pooled"].cpu().numpy(), pooled) < 1e-6
 
 
+def test_pooled_tap_aggregations(encoder):
+    """hook_pooled = "mean" / "max" / "cls_token": taps reduced over the tokens on the device (inside the producing GEMM's epilogue for
+    clips of >= 64 tokens, through a scratch tap for shorter ones) equal the same reduction of the full taps -- max and first token bit
+    for bit.  Hook 0 (post_extract_proj) takes the scratch route at every length."""
+    for samples in (160000, 16000):          # 496 tokens (fused), 48 tokens (scratch)
+        wav = torch.from_numpy(synth.noise_clips(3, samples, seed=23)).cuda()
+        full = encoder.forward(wav, hook_layers=[0, 1, 7, 12], want_features=False)["hooks"]
+        for agg in ("mean", "max", "cls_token"):
+            r = encoder.forward(wav, hook_layers=[0, 1, 7, 12], hook_pooled=agg, want_features=False)["hooks"]
+            for i in (0, 1, 7, 12):
+                want = {"mean": full[i].mean(1), "max": full[i].max(1)[0], "cls_token": full[i][:, 0]}[agg]
+                assert r[i].shape == want.shape
+                if agg == "mean":
+                    assert rel_l2(r[i].cpu().numpy(), want.cpu().numpy()) < 1e-5
+                else:
+                    assert torch.equal(r[i], want), (samples, agg, i)
+
+
 def test_chunking_is_invisible(encoder):
     """max_chunk_clips=3 above: a batch of 7 runs as 3+3+1 and must equal per-clip runs."""
     wav = torch.from_numpy(synth.noise_clips(7, 32000, seed=11)).cuda()

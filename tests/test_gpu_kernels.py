@@ -164,6 +164,12 @@ def test_gemm_pooled_tap(built_lib, dtype, B, T, grid, monkeypatch):
     assert rel_l2(pooled, want) < 1e-5
     r2 = K.gemm(_dev(a, td), _dev(w, td), bias=_dev(bias), resid_half=_dev(res, td), alpha=2.0, out_f32=False, out_half=True, pool_rows=T)
     assert torch.equal(r2["pooled"], r["pooled"])                       # blocks are added in a fixed order: reproducible bits
+    # the other two aggregations of extract_embeddings (beats_model.py:403-417): the maximum over a clip's rows and its first row -- exact
+    tap = raw["raw"].reshape(B, T, N)
+    rmax = K.gemm(_dev(a, td), _dev(w, td), bias=_dev(bias), resid_half=_dev(res, td), alpha=2.0, out_f32=False, out_half=True, pool_rows=T, pool_mode="max")
+    assert torch.equal(rmax["pooled"], tap.max(dim=1)[0]) and torch.equal(rmax["half"], raw["half"])
+    rcls = K.gemm(_dev(a, td), _dev(w, td), bias=_dev(bias), resid_half=_dev(res, td), alpha=2.0, out_f32=False, out_half=True, pool_rows=T, pool_mode="cls_token")
+    assert torch.equal(rcls["pooled"], tap[:, 0]) and torch.equal(rcls["half"], raw["half"])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
