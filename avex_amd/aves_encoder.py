@@ -118,7 +118,7 @@ class AvesEncoder:
 
     @torch.no_grad()
     def forward(self, wav: torch.Tensor, hook_layers: Iterable[int] = (), want_features: bool = True, want_pooled: bool = False,
-                frame_pad: Optional[torch.Tensor] = None, hook_pooled: bool = False) -> Dict[str, object]:
+                frame_pad: Optional[torch.Tensor] = None, hook_pooled=False) -> Dict[str, object]:
         """``hook_layers``: transformer layer indices whose ``feed_forward.output_dense`` output is returned (fp32 ``[B, T', 768]``)."""
         if wav.dim() != 2 or wav.dtype != torch.float32 or not wav.is_cuda:
             raise ValueError("wav must be a [B, T] float32 CUDA tensor")
@@ -148,7 +148,7 @@ class AvesEncoder:
             pad = frame_pad.to(device=dev, dtype=torch.uint8).contiguous()
             if pad.shape != (B, Tt):
                 raise ValueError(f"frame_pad must be [B={B}, T'={Tt}], got {tuple(pad.shape)}")
-        _capi.check(_capi.lib().avexhip_aves_forward(self._h, K._ptr(wav), B, T, wav.stride(0), K._ptr(pad), mask, ptrs, int(hook_pooled), K._ptr(feats),
+        _capi.check(_capi.lib().avexhip_aves_forward(self._h, K._ptr(wav), B, T, wav.stride(0), K._ptr(pad), mask, ptrs, K.pool_code(hook_pooled), K._ptr(feats),
                                                      K._ptr(pooled), K._ptr(self._ws), self._ws.numel(), K._stream()), "aves_forward")
         out: Dict[str, object] = {"hooks": hooks}
         if want_features:

@@ -246,7 +246,7 @@ extern "C" int avexhip_eat_forward(avexhip_eat* h, const float* wav, int B, int6
         prof.end();
         // 3. the blocks; hook i = blocks.{i}.attn.proj (eat_hf.py:220-236)
         CoreIo io;
-        io.Bc = Bc; io.Tt = Tt; io.c0 = (size_t)c0; io.hook_mask = hook_mask; io.hook_bit0 = 0; io.hook_out = hook_out; io.hook_pooled = hook_pooled;
+        io.Bc = Bc; io.Tt = Tt; io.c0 = (size_t)c0; io.hook_mask = hook_mask; io.hook_bit0 = 0; io.hook_out = hook_out; io.hook_pooled = hook_pooled < 0 ? 0 : (hook_pooled > 3 ? 3 : hook_pooled);
         io.features_out = features_out;
         io.pooled_out = pooling == 2 ? pooled_out : nullptr;
         float* cls_scratch = nullptr;
@@ -520,7 +520,7 @@ extern "C" int avexhip_aves_forward(avexhip_aves* h, const float* wav, int B, in
         // 3. the layers; hook i = encoder.transformer.layers.{i}.feed_forward.output_dense (aves_model.py:100-126)
         CoreIo io;
         io.Bc = Bc; io.Tt = Tt; io.c0 = (size_t)c0; io.pad = frame_pad ? frame_pad + (size_t)c0 * Tt : nullptr;
-        io.hook_mask = hook_mask; io.hook_bit0 = 0; io.hook_out = hook_out; io.hook_pooled = hook_pooled;
+        io.hook_mask = hook_mask; io.hook_bit0 = 0; io.hook_out = hook_out; io.hook_pooled = hook_pooled < 0 ? 0 : (hook_pooled > 3 ? 3 : hook_pooled);
         io.features_out = features_out; io.pooled_out = pooled_out;
         RC(avxh::run_layers(h, h->core, h->layers, w.core, io, prof, s));
     }

@@ -88,7 +88,7 @@ class EatEncoder:
 
     @torch.no_grad()
     def forward(self, wav: Optional[torch.Tensor] = None, *, spec: Optional[torch.Tensor] = None, hook_layers: Iterable[int] = (),
-                want_features: bool = True, pooling: Optional[str] = None, hook_pooled: bool = False) -> Dict[str, object]:
+                want_features: bool = True, pooling: Optional[str] = None, hook_pooled=False) -> Dict[str, object]:
         """``hook_layers``: block indices whose ``attn.proj`` output is returned (fp32 ``[B, 513, 768]``, or ``[B, 768]`` token means with
         ``hook_pooled``); ``pooling``: ``"cls"`` / ``"mean"`` adds ``out["pooled"]`` ``[B, 768]`` (eat_hf.py:283-288)."""
         if (wav is None) == (spec is None):
@@ -123,7 +123,7 @@ class EatEncoder:
         feats = torch.empty((B, Tt, E), dtype=torch.float32, device=dev) if want_features else None
         pooled = torch.empty((B, E), dtype=torch.float32, device=dev) if pooling else None
         _capi.check(_capi.lib().avexhip_eat_forward(self._h, K._ptr(wav), B, T, wav.stride(0) if wav is not None else 0, K._ptr(spec), mask, ptrs,
-                                                    int(hook_pooled), K._ptr(feats), K._ptr(pooled), {None: 0, "cls": 1, "mean": 2}[pooling],
+                                                    K.pool_code(hook_pooled), K._ptr(feats), K._ptr(pooled), {None: 0, "cls": 1, "mean": 2}[pooling],
                                                     K._ptr(self._ws), self._ws.numel(), K._stream()), "eat_forward")
         out: Dict[str, object] = {"hooks": hooks}
         if want_features:
