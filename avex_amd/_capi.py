@@ -41,7 +41,8 @@ class GemmArgs(C.Structure):
                 ("ln_rows", C.c_void_p), ("ln_s", C.c_void_p),
                 ("lnr_y", C.c_void_p), ("ldy", C.c_int64), ("lnr_rows", C.c_void_p),
                 ("lnr_gamma", C.c_void_p), ("lnr_beta", C.c_void_p), ("stats_out", C.c_void_p),
-                ("overflow_count", C.c_void_p), ("pool_part", C.c_void_p), ("pool_rows", C.c_int32), ("pool_mode", C.c_int32)]
+                ("overflow_count", C.c_void_p), ("pool_part", C.c_void_p), ("pool_rows", C.c_int32), ("pool_mode", C.c_int32),
+                ("splitk_ws", C.c_void_p), ("splitk_bytes", C.c_size_t)]
 
 
 class BeatsConfig(C.Structure):

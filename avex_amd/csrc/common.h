@@ -284,6 +284,9 @@ struct GemmArgs {
     // skinny kernel (variant 7): A[m][k] *= a_scale[(m / a_scale_rows) * a_scale_ld + k] (fp32 product rounded to the operand type) as the rows
     // are loaded: a per-(clip, channel) rescale of the input without a pass of its own (EfficientNet's squeeze-excitation)
     const float* a_scale; int a_scale_rows; int a_scale_ld;
+    // 128-tile LDS-DMA kernel: scratch for split-K (fp32 partial products [S][M][N]), or NULL.  With it a product of <= 64 tiles and
+    // K >= 1024 is split S <= 8 ways along K and finished by splitk_epilogue_kernel (partials added in order).
+    float* splitk_ws; size_t splitk_bytes;
     // sticky range alarm: the number of (lane, launch) pairs that rounded at least one |value| > 65504 to an f16 output is added
     // here (one atomic per wave at most, at the end of the kernel); NULL = not counted.  bf16 outputs cannot overflow.
     unsigned int* ovf;

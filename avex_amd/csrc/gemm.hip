@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
-    const int nk = p.K / BK;
+    // split-K (gridDim.y > 1, LDS-DMA form only): this workgroup takes K / gridDim.y of the contraction and leaves its fp32 partial tile in
+    // p.splitk_ws[blockIdx.y][M][N]; splitk_epilogue_kernel adds the partials in order and applies the epilogue.  For the few-row, long-K
+    // product of a single clip (fc2: 24 workgroups x 48 K-steps on 256 CUs).
+    const int kofs = GLDS ? (int)blockIdx.y * (p.K / (int)gridDim.y) : 0;
+    const int nk = (GLDS ? p.K / (int)gridDim.y : p.K) / BK;
 
     // ---- staging -------------------------------------------------------------------------
     // LDS-DMA: wave w fills rows [32w, 32w+32) of each operand tile with 4 instructions of 8 rows.
@@ -95,11 +99,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 
     // ---- main loop: one barrier per K-step, next tile in flight during compute --------------
     if constexpr (GLDS) {
-        stage_dma(0, 0);
+        stage_dma(0, kofs);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMA pieces of tile kt have landed
             __syncthreads();  // everyone's pieces landed; everyone finished reading buffer (kt+1)&1
-            if (kt + 1 < nk) stage_dma((kt + 1) & 1, (kt + 1) * BK);
+            if (kt + 1 < nk) stage_dma((kt + 1) & 1, kofs + (kt + 1) * BK);
             compute(kt & 1);
         }
     } else {
@@ -138,6 +142,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
+    if (GLDS && gridDim.y > 1) {      // split-K: the raw partial tile
+        float* part = p.splitk_ws + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wc * 64 + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(part + (int64_t)m * p.N + n0 + wr * 64 + i * 16 + (lane >> 4) * 4) = acc[i][j];
+        }
+        return;
+    }
     const float alpha = p.alpha;
     float ovf_mx = 0.f;
 #pragma unroll
@@ -175,6 +190,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
     ovf_commit<T>(p.ovf, ovf_mx);
 }
 
+
+// split-K partials [S][M][N] -> the epilogue of gemm_nt_kernel on their sum (added in split order: reproducible).  One thread = 4 columns.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, int S) {
+    typedef typename Half<T>::v4 v4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nq = p.N >> 2;
+    float ovf_mx = 0.f;
+    if (idx < (int64_t)p.M * nq) {
+        const int m = (int)(idx / nq), n = (int)(idx - (int64_t)m * nq) * 4;
+        f32x4 v = *(const f32x4*)(p.splitk_ws + (int64_t)m * p.N + n);
+        for (int sp = 1; sp < S; ++sp) v += *(const f32x4*)(p.splitk_ws + ((int64_t)sp * p.M + m) * p.N + n);
+        if (!(p.n_store > 0 && n >= p.n_store)) {
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (p.row_zero != nullptr && p.row_zero[m] != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.out_raw) *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + n) = v;
+            if (p.resid) {
+                const f32x4 r = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
+                v = r * p.alpha + v;
+            } else if (p.resid_half) {
+                const v4 rh = *(const v4*)((const T*)p.resid_half + (int64_t)m * p.ldrh + n);
+                const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                v = r * p.alpha + v;
+            }
+            if (p.gelu) v = act4_any(v, p.gelu);
+            if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
+            if (p.out_half) {
+                ovf_see4<T>(ovf_mx, v);
+                v4 h;
+                h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+                *(v4*)((T*)p.out_half + (int64_t)m * p.ldh + n) = h;
+            }
+        }
+    }
+    ovf_commit<T>(p.ovf, ovf_mx);
+}
 
 // ---------------------------------------------------------------------------------------------
 // The 256-tile pipeline (gemm256p_kernel below): 256x256x64 tile, 8 waves (2 along n x 4 along m, 128x64 outputs per wave), 128 KiB LDS
@@ -1049,7 +1100,20 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     if (variant == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3(tiles), dim3(256), lds, s, a);
     } else {
-        hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(tiles), dim3(256), lds, s, a);
+        // split-K when the caller lent a workspace and the product is few tiles of a long contraction (one clip's fc2: 24 tiles, K = 3072)
+        int S = 1;
+        if (a.splitk_ws && a.K >= 1024) {
+            int n_cu = 256;
+            { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
+            S = 8;      // as many splits as keep the launch within two workgroups per CU
+            while (S > 1 && (tiles * S > 2 * n_cu || a.K % (S * BK) != 0 || (size_t)S * a.M * a.N * sizeof(float) > a.splitk_bytes)) S >>= 1;
+        }
+        hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(tiles, S), dim3(256), lds, s, a);
+        if (S > 1) {
+            AVX_LAUNCH_CHECK();
+            const int64_t nthr = (int64_t)a.M * (a.N / 4);
+            hipLaunchKernelGGL((splitk_epilogue_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a, S);
+        }
     }
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;

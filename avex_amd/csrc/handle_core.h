@@ -314,7 +314,9 @@ inline void fold_policy(bool fast, int E, int F, bool* fold, int* min_rows) {
     const char* e = getenv("AVEX_AMD_LN_FOLD");
     const bool is_auto = !e || e[0] == 'a' || e[0] == 'A';
     *fold = fast && E % 256 == 0 && F % 256 == 0 && !(e && !is_auto && atoi(e) == 0);
-    *min_rows = is_auto ? 1024 : 0;
+    int rows = 1024;
+    if (e && is_auto) { const char* c = strchr(e, ':'); if (c && atoi(c + 1) > 0) rows = atoi(c + 1); }      // "auto:4096": another threshold (experiments)
+    *min_rows = is_auto ? rows : 0;
 }
 
 // upload layer i (and, with the fold, its LayerNorm-folded copies; layer i - 1 must have been built)
@@ -392,6 +394,7 @@ struct CoreWs {
     float* x; char* xh; float* pre; char* preh; char* qkv; char* ah; char* hh; float* raw;
     char* hh2;                // GLU: fc1's [M, 2F] output before the gate
     float* pool;              // mean-pooled hook taps: per-block column sums [ceil(M / 64)][2][E] (GemmArgs::pool_part)
+    float* splitk; size_t splitk_bytes;      // split-K partials of the few-row products (GemmArgs::splitk_ws): 8 x min(M, 1024) x E floats
     float* st1; float* st2;   // folded LayerNorm: per-row partial statistics [M][E/64][2] of y1 (preh) and y2 (xh)
     float* r1; float* r2;     // ... reduced to (rstd, -mu rstd) per row by avx::ln_rowstats
 };
@@ -409,6 +412,8 @@ inline CoreWs carve_core(const CoreCfg& c, size_t M, Take&& take) {
     w.hh = (char*)take(M * c.F * 2);
     w.hh2 = (char*)take(c.glu ? M * c.F * 4 : 256);
     w.pool = (float*)take(((M + 63) / 64) * 2 * (size_t)c.E * 4);
+    w.splitk_bytes = (8 * M < 16384 ? 8 * M : 16384) * (size_t)c.E * 4;      // 8 splits up to 2 048 rows, 2 up to 8 192
+    w.splitk = (float*)take(w.splitk_bytes);
     w.raw = (float*)take(M * c.E * 4);
     w.st1 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
     w.st2 = (float*)take(c.fold ? M * (c.E / 64) * 8 : 256);
@@ -520,6 +525,7 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         RC(ffn_hidden(h, c, w, g, M, prof, cs));
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
+        if (M <= 8192) { g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes; }
         if (fast) { g.resid_half = s1_h; g.ldrh = E; g.out_half = s0_h; g.ldh = E; }
         else { g.resid = s1_32; g.ldr = E; g.out_f32 = s0_32; g.ldo = E; }
         Tap tap_f;
@@ -618,6 +624,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         const bool last = i == L - 1;
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
+        if (M <= 8192) { g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes; }
         if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
         else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
         if (fold) {   // residual = LN1(y1) on the fly; y2 (raw) goes to xh, which nothing reads any more in this layer

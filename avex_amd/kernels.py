@@ -383,7 +383,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
          lnr_y: Optional[torch.Tensor] = None, lnr_rows: Optional[torch.Tensor] = None,
          lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False,
          lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0,
-         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0, pool_mode: str = "mean") -> Dict[str, torch.Tensor]:
+         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0, pool_mode: str = "mean", splitk: bool = False) -> Dict[str, torch.Tensor]:
     """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_rows``/``ln_s`` fold a
     LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual (the ``*_rows`` tensors come from
     :func:`ln_rowstats`), ``stats_out`` returns the per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"``;
@@ -438,6 +438,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
         if overflow.numel() != 1 or overflow.element_size() != 4 or not overflow.is_cuda:
             raise ValueError("overflow must be a 4-byte device scalar")
         args.overflow_count = _ptr(overflow)
+    sk_ws = None
+    if splitk:      # lend the 128-tile kernel scratch for split-K (used when the product is few tiles of a long contraction)
+        sk_ws = torch.empty((8 * M * N,), dtype=torch.float32, device=a.device)
+        args.splitk_ws, args.splitk_bytes = _ptr(sk_ws), sk_ws.numel() * 4
     part = None
     if pool_rows:
         if M % pool_rows:

@@ -252,6 +252,10 @@ typedef struct {
     float* pool_part; int32_t pool_rows;
     int32_t pool_mode;                 /* 0: sums (mean after avexhip_pool_reduce); 1: maxima (avexhip_pool_reduce_mode(.., 1));
                                           2: every clip's first row, written straight to pool_part = [M / pool_rows][N] */
+    /* 128-tile kernel (variant 3): scratch of splitk_bytes for split-K, or NULL.  With it a product of <= 64 output tiles and
+     * K >= 1024 (one clip's fc2) is split up to 8 ways along K -- fp32 partials [S][M][N] -- and finished by a second kernel that
+     * adds the partials in order and applies the epilogue. */
+    float* splitk_ws; size_t splitk_bytes;
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
 /* pool_part as written through avexhip_gemm_args.pool_part -> out[b, n] = mean over clip b's T rows of the raw GEMM output (bit-reproducible). */

@@ -197,6 +197,30 @@ def test_gemm_skinny_streaming(built_lib, dtype, N, Kd):
     assert float((got - want).norm() / want.norm()) < (2e-3 if dtype == "f16" else 1.2e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", [(496, 768, 3072), (96, 768, 3072), (1000, 128, 1024), (300, 256, 2048)])
+def test_gemm_split_k(built_lib, dtype, M, N, Kd):
+    """Split-K of the 128-tile kernel for few-row, long-K products (one clip's fc2): fp32 partials added in order + the full epilogue
+    (bias, half residual, raw tap, both outputs) in a second kernel, against the unsplit launch (same products, another summation order)
+    and fp64."""
+    from avex_amd import kernels as K
+    td = _tdt(dtype)
+    a = _dev(round_half(synth.normal(f"spA{M}", (M, Kd), 1.0), dtype), td)
+    w = _dev(round_half(synth.normal(f"spW{N}", (N, Kd), 0.03), dtype), td)
+    bias = _dev(synth.normal("spb", (N,), 0.3))
+    res = _dev(round_half(synth.normal(f"spR{M}", (M, N), 1.0), dtype), td)
+    kw = dict(bias=bias, resid_half=res, alpha=2.0, out_f32=True, out_half=True, out_raw=True, variant=3)
+    r1 = K.gemm(a, w, **kw)
+    r8 = K.gemm(a, w, splitk=True, **kw)
+    for k in ("f32", "raw"):
+        assert rel_l2(r8[k].cpu().numpy(), r1[k].cpu().numpy()) < 2e-6
+    assert rel_l2(r8["half"].float().cpu().numpy(), r1["half"].float().cpu().numpy()) < (1e-3 if dtype == "f16" else 8e-3)
+    want = (a.double() @ w.double().T + bias.double()).cpu().numpy()
+    assert rel_l2(r8["raw"].cpu().numpy(), want) < 1e-5
+    r8b = K.gemm(a, w, splitk=True, **kw)
+    assert torch.equal(r8b["f32"], r8["f32"])          # partials are added in split order: reproducible
+
+
 def test_gemm_pooled_tap_refuses_short_clips(built_lib):
     from avex_amd import kernels as K
     from avex_amd._capi import AvexHipError
