@@ -33,6 +33,14 @@ inline int pad128(int c) { return ((c + 127) / 128) * 128; }
 // spatial sizes: padded to 128 they were 3 - 8x their size), else a multiple of 128.  GEMM outputs narrower than the 128-column tile
 // are computed at pad128 and stored through GemmArgs::n_store.
 inline int padc(int c) { return c <= 64 ? 64 : pad128(c); }
+// ... and of an EXPANDED tensor: 96 and 144 (-> 160) channels stay that narrow when the skinny streaming kernel is there to take K, N = 96 / 160
+// (padded to 128 / 256 the 144-channel tensors were 44 % padding)
+inline bool skinny_enabled() { const char* e = getenv("AVEX_AMD_GEMM_SKINNY"); return !(e && atoi(e) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"); }
+inline int padx(int c) {
+    const int p32 = ((c + 31) / 32) * 32;
+    return (skinny_enabled() && (p32 == 96 || p32 == 160)) ? p32 : padc(c);
+}
+inline bool skinny_dim(int d) { return d == 32 || d == 64 || d == 96 || d == 128 || d == 160 || d == 256; }
 
 struct Block {
     int k = 3, stride = 1, cin = 0, cexp = 0, cout = 0, cs = 0;     // cs: squeeze width
@@ -138,7 +146,7 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
             const int d = b.has_expand ? 1 : 0;
             if (b.has_expand) {
                 RC(pointwise(h, tb, p + "0.0", p + "0.1", b.cexp, b.cin, cp, &b.w_exp, &b.b_exp, nullptr, nullptr));
-                cp = padc(b.cexp);
+                cp = padx(b.cexp);
             }
             b.cp_exp = cp;
             {   // depthwise k x k + BN: [k*k, cp]
@@ -244,7 +252,7 @@ extern "C" avexhip_effnet* avexhip_effnet_create(const avexhip_effnet_config* cf
     h->cfg = c;
     if (!(h->cfg.bn_eps > 0.f)) h->cfg.bn_eps = 1e-5f;
     h->dtype = c.operand_dtype;
-    h->c0 = c.stem_channels; h->cp0 = ((c.stem_channels + 31) / 32) * 32; h->head = c.head_channels;      // cp0 = 32 for B0 / B1: the stem's output and the first depthwise run at the real width
+    h->c0 = c.stem_channels; h->cp0 = skinny_enabled() ? ((c.stem_channels + 31) / 32) * 32 : ((c.stem_channels + 63) / 64) * 64; h->head = c.head_channels;      // cp0 = 32 for B0 / B1: the stem's output and the first depthwise run at the real width
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     if (h->init_alarm() != AVEXHIP_OK || effnet_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
     return h;
@@ -313,6 +321,9 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
                 memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
                 g.A = w.act[in_buf]; g.lda = b.cp_in; g.W = b.w_exp; g.ldw = b.cp_in; g.M = M_in; g.N = pad128(b.cexp); g.K = b.cp_in; g.bias = b.b_exp; g.gelu = 2;
                 g.out_half = w.act[o]; g.ldh = b.cp_exp; g.n_store = b.cp_exp < g.N ? b.cp_exp : 0;
+                if (skinny_enabled() && skinny_dim(b.cp_in) && skinny_dim(b.cp_exp) && b.cp_exp != 32 && b.cp_exp * b.cp_in <= 32768) {
+                    g.N = b.cp_exp; g.n_store = 0; g.variant = 7;      // whatever the row count: the 128-tile kernels take neither K = 32 nor 96 / 160 columns
+                }
                 prof.begin("gemm.expand", 2.0 * M_in * (double)b.cexp * b.cin);
                 RC(avx::gemm(g, dt, s));
                 prof.end();
@@ -329,9 +340,8 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             // long thin projections run in the skinny streaming kernel, which applies the squeeze-excitation scale to its A rows as it loads
             // them: the rescale pass over the expanded tensor (read + write) disappears
             static const bool no_se_fold = getenv("AVEX_AMD_SE_FOLD") && atoi(getenv("AVEX_AMD_SE_FOLD")) == 0;
-            const bool skinny_k = b.cp_exp == 32 || b.cp_exp == 64 || b.cp_exp == 128 || b.cp_exp == 256;
-            const bool skinny_proj = !hooked && skinny_k && pad128(b.cout) * b.cp_exp <= 32768 && (b.cp_out == 64 || b.cp_out % 128 == 0);
-            const bool se_fold = !no_se_fold && skinny_proj;
+            const bool skinny_proj = skinny_enabled() && skinny_dim(b.cp_exp) && pad128(b.cout) * b.cp_exp <= 32768 && (b.cp_out == 64 || b.cp_out == 128 || b.cp_out == 256);
+            const bool se_fold = skinny_proj && (!no_se_fold || hooked);      // (the skinny kernel's raw tap comes with the scale)
             prof.begin("se", 0.0);
             RC(avexhip_effnet_se(w.pool, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, se_fold ? nullptr : w.act[dw], dt, s));
             prof.end();

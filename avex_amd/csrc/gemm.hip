@@ -874,22 +874,28 @@ static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
 // as the A operand a lane ends up with four consecutive output columns of one row (8-byte stores).  One wave = 32 rows x N per trip.
 // NT = N / 16, KS = K / 32 are compile-time (register arrays).  Epilogue: bias, activation, half residual, n_store; half output only.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NT, int KS, bool SCALE>
+template <typename T, int NT, int KS, bool SCALE, bool RAW>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     constexpr int N = NT * 16, K = KS * 32, KC = K / 8;      // KC 16-byte chunks per W row
-    constexpr int SW = KC >= 8 ? 7 : KC - 1;                 // chunk index XOR (row & SW): 16 consecutive rows at one chunk spread over the banks
+    // chunk index XOR (row & SW): 16 consecutive rows at one chunk spread over the banks; SW + 1 = the largest power of two (<= 8) dividing KC,
+    // so that the swizzled index stays inside the row (K = 96: KC = 12, SW = 3)
+    constexpr int SW = KC % 8 == 0 ? 7 : (KC % 4 == 0 ? 3 : 1);
+    constexpr int G = NT % 4 == 0 ? 4 : 2;                   // MFMA tiles whose accumulators a lane stores as one run of 4 G consecutive columns
+    static_assert(NT % G == 0 && KC % 2 == 0, "skinny kernel: N must be a multiple of 32, K of 32");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const T* W = (const T*)p.W;
     const T* A = (const T*)p.A;
-    // W rows are PERMUTED on their way into the LDS so that a lane's accumulators of four MFMA tiles are 16 CONSECUTIVE output columns:
+    // W rows are PERMUTED on their way into the LDS so that a lane's accumulators of G = 4 MFMA tiles are 16 CONSECUTIVE output columns:
     // LDS row (tile 4 t + q, row 4 g + r) holds W row n = 64 t + 16 g + 4 q + r.  A lane (g = lane / 16) then owns columns
     // 64 t + 16 g .. + 15 of its output row -- two 16-byte stores -- and the four lanes of a row cover one whole 128-byte line.
+    // (N = 96, 160: G = 2, runs of 8 columns, one 16-byte store.)
     for (int c = tid; c < N * KC; c += 256) {
         const int n = c / KC, ch = c - n * KC;
-        const int row = (((n >> 6) * 4 + ((n >> 2) & 3)) << 4) + (((n >> 4) & 3) << 2) + (n & 3);
+        const int t = n / (16 * G), within = n - t * (16 * G);
+        const int row = ((t * G + ((within % (4 * G)) >> 2)) << 4) + ((within / (4 * G)) << 2) + (n & 3);
         *(uint4*)(smem + ((row * KC + (ch ^ (row & SW))) << 4)) = *(const uint4*)(W + (int64_t)n * p.ldw + ch * 8);
     }
     __syncthreads();
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
             }
         }
         // 128 output columns at a time (N = 256: two passes over the same A fragments): 64 accumulator registers instead of 128
-        constexpr int NTP = NT > 8 ? 8 : NT;
+        constexpr int NTP = (NT > 8 && NT % 8 == 0) ? 8 : NT;
 #pragma unroll
         for (int np = 0; np < NT; np += NTP) {
             f32x4 acc[NTP][2];
@@ -966,16 +972,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                 const int64_t m = r0 + rt * 16 + lr;
                 if (m >= p.M) continue;
 #pragma unroll
-                for (int t = 0; t < NTP / 4; ++t) {
-                    const int n = (np / 4 + t) * 64 + lq * 16;      // this lane's 16 consecutive columns
+                for (int t = 0; t < NTP / G; ++t) {
+                    const int n = (np / G + t) * (16 * G) + lq * (4 * G);      // this lane's 4 G consecutive columns
                     if (n >= nst) continue;
                     v8 rh[2];
-                    if (p.resid_half) { rh[0] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n); rh[1] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n + 8); }
+                    if (p.resid_half) {
+                        rh[0] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n);
+                        if (G == 4) rh[1] = *(const v8*)((const T*)p.resid_half + m * p.ldrh + n + 8);
+                    }
                     v8 h[2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v = acc[4 * t + q][rt];
+                    for (int q = 0; q < G; ++q) {
+                        f32x4 v = acc[G * t + q][rt];
                         if (p.bias) v += *(const f32x4*)(p.bias + n + 4 * q);
+                        if constexpr (RAW) *(f32x4*)(p.out_raw + m * p.ldraw + n + 4 * q) = v;      // fp32 hook tap (before the residual); a template flag: as a run-time branch it cost the N = 128 instantiation its second wave per SIMD
                         if (p.resid_half) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = (float)rh[q >> 1][4 * (q & 1) + e] * alpha + v[e];
@@ -986,7 +996,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                         for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = Half<T>::from(v[e]);
                     }
                     *(v8*)((T*)p.out_half + m * p.ldh + n) = h[0];
-                    *(v8*)((T*)p.out_half + m * p.ldh + n + 8) = h[1];
+                    if (G == 4) *(v8*)((T*)p.out_half + m * p.ldh + n + 8) = h[1];
                 }
             }
         }
@@ -994,34 +1004,42 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
     ovf_commit<T>(p.ovf, ovf_mx);
 }
 
-template <typename T, int NT, int KS, bool SCALE>
+template <typename T, int NT, int KS, bool SCALE, bool RAW>
 static int launch_skinny(const avx::GemmArgs& a, hipStream_t s) {
     int n_cu = 256;
     { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
     const size_t lds = (size_t)NT * 16 * KS * 32 * 2;
-    AVX_ENSURE_LDS((gemm_skinny_kernel<T, NT, KS, SCALE>), 64 * 1024);
+    AVX_ENSURE_LDS((gemm_skinny_kernel<T, NT, KS, SCALE, RAW>), 64 * 1024);
     const int64_t nblk = ((int64_t)a.M + 127) / 128;
     int per_cu = (int)(128 * 1024 / (lds > 16384 ? lds : 16384));      // workgroups per CU the LDS (and ~100 registers per lane) allows
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int64_t grid = (int64_t)n_cu * per_cu;
     grid = grid < nblk ? grid : nblk;
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, NT, KS, SCALE>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, NT, KS, SCALE, RAW>), dim3((unsigned)grid), dim3(256), lds, s, a);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
 
 // does the skinny kernel take this product?  (half output only, no fp32 / raw outputs, no folded LayerNorm, no row mask)
 static bool skinny_ok(const avx::GemmArgs& a) {
-    if (!(a.K == 32 || a.K == 64 || a.K == 128 || a.K == 256) || !(a.N == 64 || a.N == 128 || a.N == 256) || a.N * a.K > 32768) return false;
-    if (!a.out_half || a.out_f32 || a.out_raw || a.resid || a.row_zero || a.ln_rows || a.lnr_y || a.stats_out || a.pool_part) return false;
-    if (a.lda % 8 || a.ldw % 8 || a.ldh % 8 || (a.resid_half && a.ldrh % 8) || (a.n_store > 0 && a.n_store % 16)) return false;
+    if (!(a.K == 32 || a.K == 64 || a.K == 96 || a.K == 128 || a.K == 160 || a.K == 256) ||
+        !(a.N == 64 || a.N == 96 || a.N == 128 || a.N == 160 || a.N == 256) || a.N * a.K > 32768) return false;
+    if (!a.out_half || a.out_f32 || a.resid || a.row_zero || a.ln_rows || a.lnr_y || a.stats_out || a.pool_part) return false;
+    if (a.lda % 8 || a.ldw % 8 || a.ldh % 8 || (a.resid_half && a.ldrh % 8) || (a.out_raw && a.ldraw % 4) || (a.n_store > 0 && a.n_store % 16)) return false;
     return true;
 }
 
 template <typename T>
 static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
-#define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) return a.a_scale ? launch_skinny<T, NTV, KSV, true>(a, s) : launch_skinny<T, NTV, KSV, false>(a, s)
+    // the raw fp32 tap exists for the projection widths (N = 64, 128, 256) in one form: with the A-row scale (a NULL a_scale is refused)
+#define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) { \
+        if (a.out_raw) { \
+            if constexpr (NTV == 4 || NTV == 8 || NTV == 16) { if (a.a_scale) return launch_skinny<T, NTV, KSV, true, true>(a, s); } \
+            avexhip_set_error("gemm: the skinny kernel writes a raw tap only for N = 64 / 128 / 256 with a_scale (N=%d)", a.N); return AVEXHIP_ERR_INVALID; \
+        } \
+        return a.a_scale ? launch_skinny<T, NTV, KSV, true, false>(a, s) : launch_skinny<T, NTV, KSV, false, false>(a, s); }
     AVX_SK(4, 1); AVX_SK(8, 1); AVX_SK(4, 2); AVX_SK(4, 4); AVX_SK(4, 8); AVX_SK(8, 2); AVX_SK(8, 4); AVX_SK(8, 8); AVX_SK(16, 2); AVX_SK(16, 4);
+    AVX_SK(6, 2); AVX_SK(4, 3); AVX_SK(8, 3); AVX_SK(10, 2); AVX_SK(4, 5); AVX_SK(8, 5);      // EfficientNet's 96- and 144 (-> 160)-channel expansions
 #undef AVX_SK
     avexhip_set_error("gemm: no skinny instantiation for N=%d K=%d", a.N, a.K);
     return AVEXHIP_ERR_INVALID;
@@ -1032,10 +1050,10 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     // variant 7 / auto for long thin products: the skinny streaming kernel (W resident in LDS, A rows straight into MFMA operands)
     AVX_REQUIRE(!a.a_scale || (a.variant == 7 && a.a_scale_rows > 0 && a.a_scale_ld >= a.K && a.a_scale_ld % 4 == 0), "gemm: a_scale is built for the skinny kernel (variant 7)");
     if (a.variant == 7) {
-        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K in {32, 64, 128, 256}, N in {64, 128, 256} with N K <= 32768, half output only (N=%d K=%d)", a.N, a.K);
+        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K in {32, 64, 96, 128, 160, 256}, N in {64, 96, 128, 160, 256} with N K <= 32768, a half output (N=%d K=%d)", a.N, a.K);
         return launch_skinny_any<T>(a, s);
     }
-    if (a.variant == 0 && a.M >= 32768 && a.K >= 64 && skinny_ok(a) &&
+    if (a.variant == 0 && a.M >= 32768 && a.K % 64 == 0 && (a.N == 64 || a.N % 128 == 0) && !a.out_raw && skinny_ok(a) &&
         (a.N % BN != 0 || (!(getenv("AVEX_AMD_GEMM_SKINNY") && atoi(getenv("AVEX_AMD_GEMM_SKINNY")) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"))))
         return launch_skinny_any<T>(a, s);
     // variant: 0 = auto, 1 = 128-tile register staging, 3 = 128-tile LDS-DMA, 5 (or 2, its tile-per-workgroup ancestor's number) =
@@ -1126,9 +1144,9 @@ namespace avx {
 int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     AVX_REQUIRE(a.A && a.W, "gemm: A and W must be non-null");
     AVX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-    AVX_REQUIRE(a.N % BN == 0 || (a.N == 64 && (a.variant == 7 || (a.variant == 0 && a.M >= 32768 && a.K >= 64)) && skinny_ok(a)),
+    AVX_REQUIRE(a.N % BN == 0 || ((a.variant == 7 || (a.variant == 0 && a.N == 64 && a.M >= 32768 && a.K % 64 == 0)) && skinny_ok(a)),
                 "gemm: N=%d must be a multiple of %d (64 columns: the skinny streaming kernel only, >= 32768 rows)", a.N, BN);
-    AVX_REQUIRE(a.K % BK == 0 || (a.K == 32 && a.variant == 7), "gemm: K=%d must be a multiple of %d (32: the skinny kernel, variant 7)", a.K, BK);
+    AVX_REQUIRE(a.K % BK == 0 || (a.K % 32 == 0 && a.variant == 7), "gemm: K=%d must be a multiple of %d (of 32 with the skinny kernel, variant 7)", a.K, BK);
     AVX_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
     AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw, "gemm: no output buffer");
     AVX_REQUIRE((!a.out_f32 || a.ldo % 4 == 0) && (!a.out_half || a.ldh % 4 == 0) &&
