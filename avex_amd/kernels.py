@@ -341,6 +341,17 @@ def dense_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out.reshape(*lead, N)
 
 
+def lstm_layer(xg: torch.Tensor, w_hh_t: torch.Tensor, out: torch.Tensor, col: int = 0, reverse: bool = False) -> None:
+    """One direction of one ``nn.LSTM`` layer: ``xg [B, T, 4H]`` (input half of the gates, biases included), ``w_hh_t [H, 4H]`` (W_hh
+    transposed) -> ``out[:, :, col:col + H]`` (``out [B, T, W]`` contiguous, ``W >= col + H``)."""
+    _need_cuda(xg, w_hh_t, out)
+    B, T, G = xg.shape
+    H = G // 4
+    if w_hh_t.shape != (H, 4 * H) or out.shape[:2] != (B, T) or out.shape[2] < col + H or not (xg.is_contiguous() and w_hh_t.is_contiguous() and out.is_contiguous()):
+        raise ValueError("lstm_layer: shapes")
+    check(lib().avexhip_lstm_layer(_ptr(xg), _ptr(w_hh_t), B, T, H, int(bool(reverse)), int(out.data_ptr()) + 4 * col, out.shape[2], _stream()), "lstm_layer")
+
+
 def mha_f32(qkv: torch.Tensor, num_heads: int, key_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention core of ``nn.MultiheadAttention`` (eval, self attention): ``qkv [B, T, 3E]`` -> ``[B, T, E]``."""
     _need_cuda(qkv)

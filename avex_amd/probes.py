@@ -1,6 +1,6 @@
 """Probe heads evaluated on the device: forward-only mirrors of the reference's online probes.
 
-Reference: ``avex/models/probes/{base_probes,linear_probe,mlp_probe,attention_probe}.py``.  The reference probes are
+Reference: ``avex/models/probes/{base_probes,linear_probe,mlp_probe,attention_probe,transformer_probe,lstm_probe}.py``.  The reference probes are
 ``nn.Module`` s trained by autograd on top of ``base_model.extract_embeddings``; with this package's models that call already returns
 device tensors, so the reference's own probe classes train on them unchanged and nothing crosses PCIe.  What is mirrored here is the
 EVALUATION forward -- layer mixing (``_sum``), the 2-D / 3-D reshaping rules and the three heads -- running on this library's fp32
@@ -326,4 +326,133 @@ class AttentionProbe(_DeviceProbe):
         return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))
 
 
-PROBES: Dict[str, type] = {"linear": LinearProbe, "mlp": MLPProbe, "attention": AttentionProbe}
+class TransformerProbe(_DeviceProbe):
+    """transformer_probe.py:17-116: optional LEARNED positions (a Parameter, unlike the attention probe's sinusoids), ``num_layers``
+    post-LN ``nn.TransformerEncoderLayer`` s (self attention -> LayerNorm(x + attn) -> Linear / ReLU / Linear of width ``attention_dim``
+    -> LayerNorm(x + ff)), mean over the sequence, classifier.  With a key padding mask PyTorch's encoder (eval mode: nested-tensor
+    path) returns ZEROS at the padded positions and the reference's mean over all T positions includes them: mirrored."""
+
+    rank = 3
+
+    def __init__(self, base_model, layers, num_classes, device="cuda", feature_mode=False, input_dim=None, aggregation="mean",
+                 num_heads: int = 12, attention_dim: int = 768, num_layers: int = 4, dropout_rate: float = 0.1,
+                 max_sequence_length: Optional[int] = None, use_positional_encoding: bool = False, target_length=None,
+                 freeze_backbone=True) -> None:
+        self.num_heads = num_heads
+        self.attention_dim = attention_dim
+        self.num_layers = num_layers
+        self.dropout_rate = dropout_rate
+        self.max_sequence_length = max_sequence_length
+        self.use_positional_encoding = use_positional_encoding
+        super().__init__(base_model, layers, num_classes, device, feature_mode, input_dim, aggregation, target_length, freeze_backbone)
+
+    def build_head(self, d: int) -> None:
+        if d % self.num_heads != 0:                                 # transformer_probe.py:58-63: the largest divisor below
+            adjusted = min(self.num_heads, d)
+            while d % adjusted != 0 and adjusted > 1:
+                adjusted -= 1
+            self.num_heads = adjusted
+        f = self.attention_dim
+        for i in range(self.num_layers):
+            p = f"transformer.layers.{i}."
+            self._buf(p + "self_attn.in_proj_weight", 3 * d, d)
+            self._buf(p + "self_attn.in_proj_bias", 3 * d)
+            self._buf(p + "self_attn.out_proj.weight", d, d)
+            self._buf(p + "self_attn.out_proj.bias", d)
+            self._buf(p + "linear1.weight", f, d)
+            self._buf(p + "linear1.bias", f)
+            self._buf(p + "linear2.weight", d, f)
+            self._buf(p + "linear2.bias", d)
+            for n in ("norm1", "norm2"):
+                self._buf(p + n + ".weight", d)
+                self._buf(p + n + ".bias", d)
+                self.get_buffer(p + n + ".weight").fill_(1.0)
+        if self.use_positional_encoding:
+            self.register_buffer("pos_encoding", torch.zeros(1, self.max_sequence_length or 1000, d))
+        else:
+            self.pos_encoding = None
+        self._buf("classifier.weight", self.num_classes, d)
+        self._buf("classifier.bias", self.num_classes)
+
+    @torch.no_grad()
+    def forward(self, x, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = self._combine(self._get_embeddings(x, padding_mask))
+        B, T, D = h.shape
+        if self.pos_encoding is not None:
+            h = h + self.pos_encoding[:, :T]
+        if padding_mask is not None and padding_mask.shape[1] != T:   # transformer_probe.py:109-110
+            padding_mask = None
+        for i in range(self.num_layers):
+            p = f"transformer.layers.{i}."
+            qkv = K.dense_f32(h, self._p(p + "self_attn.in_proj_weight"), self._p(p + "self_attn.in_proj_bias"))
+            att = K.mha_f32(qkv, self.num_heads, padding_mask)
+            y = K.dense_f32(att, self._p(p + "self_attn.out_proj.weight"), self._p(p + "self_attn.out_proj.bias"), resid=h)
+            h = K.layernorm(y.reshape(B * T, D), self._p(p + "norm1.weight"), self._p(p + "norm1.bias"), eps=1e-5, want_f32=True, want_half=False)[0]
+            f = K.dense_f32(h, self._p(p + "linear1.weight"), self._p(p + "linear1.bias"), act="relu")
+            y = K.dense_f32(f, self._p(p + "linear2.weight"), self._p(p + "linear2.bias"), resid=h)
+            h = K.layernorm(y, self._p(p + "norm2.weight"), self._p(p + "norm2.bias"), eps=1e-5, want_f32=True, want_half=False)[0].reshape(B, T, D)
+        if padding_mask is not None:
+            h = h * (~padding_mask.to(device=h.device, dtype=torch.bool)).unsqueeze(-1).to(h.dtype)
+        pooled = K.mean_pool(h.contiguous())
+        return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))
+
+
+class LSTMProbe(_DeviceProbe):
+    """lstm_probe.py:17-104: optional learned positions, ``nn.LSTM(batch_first=True)`` with ``num_layers`` layers (optionally
+    bidirectional) of ``max(lstm_hidden_size, max_sequence_length // 4)`` units, mean over the sequence, classifier.  Per layer and
+    direction: one dense product for the input half of the gates, then the whole recurrence in ONE launch (``avexhip_lstm_layer``)."""
+
+    rank = 3
+
+    def __init__(self, base_model, layers, num_classes, device="cuda", feature_mode=False, input_dim=None, aggregation="mean",
+                 lstm_hidden_size: int = 256, num_layers: int = 2, bidirectional: bool = False, dropout_rate: float = 0.1,
+                 max_sequence_length: Optional[int] = None, use_positional_encoding: bool = False, target_length=None,
+                 freeze_backbone=True) -> None:
+        self.lstm_hidden_size = lstm_hidden_size
+        self.num_layers = num_layers
+        self.bidirectional = bidirectional
+        self.dropout_rate = dropout_rate
+        self.max_sequence_length = max_sequence_length
+        self.use_positional_encoding = use_positional_encoding
+        super().__init__(base_model, layers, num_classes, device, feature_mode, input_dim, aggregation, target_length, freeze_backbone)
+
+    def build_head(self, d: int) -> None:
+        hs = int(max(int((self.max_sequence_length or 4) / 4), self.lstm_hidden_size))      # lstm_probe.py:60
+        if hs % 64 or hs > 1024:
+            raise ValueError(f"LSTMProbe on the device needs a hidden size that is a multiple of 64 and at most 1024, got {hs}")
+        self.hidden = hs
+        dirs = 2 if self.bidirectional else 1
+        for layer in range(self.num_layers):
+            width = d if layer == 0 else hs * dirs
+            for suffix in ("", "_reverse")[:dirs]:
+                k = f"l{layer}{suffix}"
+                self._buf(f"lstm.weight_ih_{k}", 4 * hs, width)
+                self._buf(f"lstm.weight_hh_{k}", 4 * hs, hs)
+                self._buf(f"lstm.bias_ih_{k}", 4 * hs)
+                self._buf(f"lstm.bias_hh_{k}", 4 * hs)
+        self._buf("classifier.weight", self.num_classes, hs * dirs)
+        self._buf("classifier.bias", self.num_classes)
+        if self.use_positional_encoding:
+            self.register_buffer("pos_encoding", torch.zeros(1, self.max_sequence_length or 1000, d))
+        else:
+            self.pos_encoding = None
+
+    @torch.no_grad()
+    def forward(self, x, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = self._combine(self._get_embeddings(x, padding_mask))        # (the padding mask does not reach the LSTM in the reference either)
+        B, T, _ = h.shape
+        if self.pos_encoding is not None:
+            h = h + self.pos_encoding[:, :T]
+        hs, dirs = self.hidden, (2 if self.bidirectional else 1)
+        for layer in range(self.num_layers):
+            out = torch.empty((B, T, hs * dirs), dtype=torch.float32, device=h.device)
+            for di, suffix in enumerate(("", "_reverse")[:dirs]):
+                k = f"l{layer}{suffix}"
+                xg = K.dense_f32(h.contiguous(), self._p(f"lstm.weight_ih_{k}"), self._p(f"lstm.bias_ih_{k}") + self._p(f"lstm.bias_hh_{k}"))
+                K.lstm_layer(xg, self._p(f"lstm.weight_hh_{k}").t().contiguous(), out, col=di * hs, reverse=bool(di))
+            h = out
+        pooled = K.mean_pool(h)
+        return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))
+
+
+PROBES: Dict[str, type] = {"linear": LinearProbe, "mlp": MLPProbe, "attention": AttentionProbe, "transformer": TransformerProbe, "lstm": LSTMProbe}

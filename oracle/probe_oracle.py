@@ -102,3 +102,67 @@ def attention_probe(embs, sd, num_heads, key_pad=None):
                 sd[f"attention_layers.{i}.out_proj.weight"], sd[f"attention_layers.{i}.out_proj.bias"], num_heads, key_pad)
         x = layernorm(x + a, sd[f"layer_norms.{i}.weight"], sd[f"layer_norms.{i}.bias"])
     return linear(x.mean(1), sd["classifier.weight"], sd["classifier.bias"])
+
+
+def transformer_probe(embs, sd, num_heads, key_pad=None):
+    """``TransformerProbe.forward`` (transformer_probe.py:97-116): learned mix of the taps, optional positions, ``num_layers`` post-LN
+    ``nn.TransformerEncoderLayer`` s (self attention -> LayerNorm(x + attn) -> ReLU feed-forward -> LayerNorm(x + ff)), mean over the
+    sequence, classifier.  With a key padding mask PyTorch's encoder takes its nested-tensor path in eval mode and hands back ZEROS at
+    the padded positions, which the mean over all T positions then includes -- restated as such (pinned by probes_seq.npz)."""
+    x = layer_mix(embs, sd.get("layer_weights")) if isinstance(embs, (list, tuple)) else np.asarray(embs, np.float32)
+    x = x.astype(np.float64)
+    if "pos_encoding" in sd:
+        x = x + sd["pos_encoding"][:, : x.shape[1]]
+    if key_pad is not None and np.asarray(key_pad).shape[1] != x.shape[1]:
+        key_pad = None                                                       # transformer_probe.py:109-110
+    n_layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.layers.")})
+    for i in range(n_layers):
+        p = f"transformer.layers.{i}."
+        a = mha(x, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"], sd[p + "self_attn.out_proj.weight"],
+                sd[p + "self_attn.out_proj.bias"], num_heads, key_pad)
+        x = layernorm(x + a, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+        f = linear(np.maximum(linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"]), 0.0), sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+        x = layernorm(x + f, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    if key_pad is not None:
+        x = np.where(np.asarray(key_pad, bool)[..., None], 0.0, x)
+    return linear(x.mean(1), sd["classifier.weight"], sd["classifier.bias"])
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
+    """One direction of one ``nn.LSTM`` layer, batch first, zero initial state; gate order i, f, g, o (torch.nn.LSTM)."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    xg = x @ w_ih.T.astype(np.float64) + (b_ih.astype(np.float64) + b_hh.astype(np.float64))
+    h = np.zeros((B, H)); c = np.zeros((B, H))
+    out = np.zeros((B, T, H))
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        g = xg[:, t] + h @ w_hh.T.astype(np.float64)
+        i, f, gg, o = _sigmoid(g[:, :H]), _sigmoid(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), _sigmoid(g[:, 3 * H:])
+        c = f * c + i * gg
+        h = o * np.tanh(c)
+        out[:, t] = h
+    return out
+
+
+def lstm_probe(embs, sd):
+    """``LSTMProbe.forward`` (lstm_probe.py:87-104): learned mix, optional positions, ``nn.LSTM`` (layers / directions read off the state
+    dict), mean over the sequence, classifier.  (The padding mask does not reach the LSTM in the reference.)"""
+    x = layer_mix(embs, sd.get("layer_weights")) if isinstance(embs, (list, tuple)) else np.asarray(embs, np.float32)
+    x = x.astype(np.float64)
+    if "pos_encoding" in sd:
+        x = x + sd["pos_encoding"][:, : x.shape[1]]
+    layer = 0
+    while f"lstm.weight_ih_l{layer}" in sd:
+        outs = []
+        for suffix, rev in (("", False), ("_reverse", True)):
+            k = f"l{layer}{suffix}"
+            if f"lstm.weight_ih_{k}" not in sd:
+                continue
+            outs.append(lstm_layer(x, sd[f"lstm.weight_ih_{k}"], sd[f"lstm.weight_hh_{k}"], sd[f"lstm.bias_ih_{k}"], sd[f"lstm.bias_hh_{k}"], rev))
+        x = np.concatenate(outs, axis=-1)
+        layer += 1
+    return linear(x.mean(1), sd["classifier.weight"], sd["classifier.bias"])

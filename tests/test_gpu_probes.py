@@ -173,3 +173,50 @@ def test_projectors_and_interpolation_match_reference(built_lib, golden_dir):
         got = K.seq_interp_linear(x.cuda(), tout).cpu()
         # same formula, same float arithmetic; torch.s vectorised CPU kernel may contract w0 * x0 + w1 * x1 into an FMA
         assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5 and rel_l2(got.numpy(), ref.numpy()) < 2e-6, (tin, tout)
+
+
+def test_sequence_probes_match_reference_goldens(built_lib, golden_dir):
+    """The two remaining sequence probes against the reference's own TransformerProbe / LSTMProbe (tests/golden/make_seq_probe_goldens.py):
+    transformer with learned positions, with and without a key padding mask (the reference's encoder returns zeros at padded positions and
+    averages over all of them), the head-count adjustment (12 heads on 128 channels -> 8), one- and two-directional two-layer LSTMs."""
+    from avex_amd import probes as P
+    g = np.load(f"{golden_dir}/probes_seq.npz")
+    seqs = [torch.from_numpy(e).cuda() for e in g["seqs"]]
+    tr = P.TransformerProbe(None, [], 19, feature_mode=True, input_dim=[(40, 128)] * 3, aggregation="none", num_heads=4, attention_dim=192,
+                            num_layers=2, dropout_rate=0.0, max_sequence_length=64, use_positional_encoding=True)
+    tr.load_state_dict(_sd(g, "tr"))
+    assert rel_l2(tr(seqs).cpu().numpy(), g["tr.logits"]) < 1e-5
+    pad = torch.from_numpy(g["pad"]).cuda()
+    assert rel_l2(tr(seqs, padding_mask=pad).cpu().numpy(), g["tr.logits_pad"]) < 1e-5
+    tr1 = P.TransformerProbe(None, [], 19, feature_mode=True, input_dim=(40, 128), aggregation="none", num_heads=12, attention_dim=96,
+                             num_layers=1, dropout_rate=0.1)
+    assert tr1.num_heads == int(g["tr1.num_heads"]) == 8
+    tr1.load_state_dict(_sd(g, "tr1"))
+    assert rel_l2(tr1(seqs[0]).cpu().numpy(), g["tr1.logits"]) < 1e-5
+    ls = P.LSTMProbe(None, [], 19, feature_mode=True, input_dim=[(40, 128)] * 3, aggregation="none", lstm_hidden_size=64, num_layers=2,
+                     bidirectional=False, dropout_rate=0.0)
+    ls.load_state_dict(_sd(g, "lstm"))
+    assert rel_l2(ls(seqs).cpu().numpy(), g["lstm.logits"]) < 1e-5
+    bi = P.LSTMProbe(None, [], 19, feature_mode=True, input_dim=[(40, 128)] * 3, aggregation="none", lstm_hidden_size=64, num_layers=2,
+                     bidirectional=True, dropout_rate=0.0, max_sequence_length=64, use_positional_encoding=True)
+    bi.load_state_dict(_sd(g, "bilstm"))
+    assert rel_l2(bi(seqs).cpu().numpy(), g["bilstm.logits"]) < 1e-5
+
+
+def test_lstm_layer_long_sequence(built_lib):
+    """The recurrence kernel at the probe's real size (496 steps, 256 units, a batch that is no multiple of the clips per workgroup)
+    against torch.nn.LSTM in fp64 on the host."""
+    from avex_amd import kernels as K
+    torch.manual_seed(3)
+    B, T, D, H = 6, 496, 96, 256
+    lstm = torch.nn.LSTM(D, H, batch_first=True, bidirectional=True).double().eval()
+    x = torch.randn(B, T, D)
+    with torch.no_grad():
+        ref, _ = lstm(x.double())
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device="cuda")
+    for di, sfx in enumerate(("", "_reverse")):
+        w_ih, w_hh = getattr(lstm, f"weight_ih_l0{sfx}").float().cuda(), getattr(lstm, f"weight_hh_l0{sfx}").float().cuda()
+        b = (getattr(lstm, f"bias_ih_l0{sfx}") + getattr(lstm, f"bias_hh_l0{sfx}")).float().cuda()
+        xg = K.dense_f32(x.cuda(), w_ih, b)
+        K.lstm_layer(xg, w_hh.t().contiguous(), out, col=di * H, reverse=bool(di))
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 2e-5

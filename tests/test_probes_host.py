@@ -30,6 +30,18 @@ def test_state_dict_keys_match_reference(golden_dir):
     assert "Number of layers: 3" in att.get_learned_weights_table()
 
 
+def test_sequence_probe_keys_match_reference(golden_dir):
+    g = np.load(f"{golden_dir}/probes_seq.npz")
+    tr = P.TransformerProbe(None, [], 19, device="cpu", feature_mode=True, input_dim=[(40, 128)] * 3, aggregation="none", num_heads=4,
+                            attention_dim=192, num_layers=2, max_sequence_length=64, use_positional_encoding=True)
+    assert {k: tuple(v.shape) for k, v in tr.state_dict().items()} == {k[6:]: g[k].shape for k in g.files if k.startswith("tr.sd.")}
+    ls = P.LSTMProbe(None, [], 19, device="cpu", feature_mode=True, input_dim=[(40, 128)] * 3, aggregation="none", lstm_hidden_size=64,
+                     num_layers=2, bidirectional=True, max_sequence_length=64, use_positional_encoding=True)
+    assert {k: tuple(v.shape) for k, v in ls.state_dict().items()} == {k[10:]: g[k].shape for k in g.files if k.startswith("bilstm.sd.")}
+    with pytest.raises(ValueError):          # 100 units: not a multiple of 64 (the recurrence kernel's thread layout)
+        P.LSTMProbe(None, [], 3, device="cpu", feature_mode=True, input_dim=(40, 128), aggregation="none", lstm_hidden_size=100)
+
+
 def test_refusals():
     lin = P.LinearProbe(None, [], 5, device="cpu", feature_mode=True, input_dim=32)
     with pytest.raises(NotImplementedError):
