@@ -67,6 +67,11 @@ class EatConfig(C.Structure):
                 ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32), ("residual_dtype", C.c_int32)]
 
 
+class StackConfig(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("ffn_dim", C.c_int32), ("norm_eps", C.c_float),
+                ("activation", C.c_int32), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32), ("residual_dtype", C.c_int32)]
+
+
 class AvesConfig(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("ffn_dim", C.c_int32),
                 ("pos_conv_kernel", C.c_int32), ("pos_conv_groups", C.c_int32), ("n_conv_layers", C.c_int32),
@@ -118,6 +123,11 @@ SYMBOLS = {
     "avexhip_layer_mix": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_int64, _P, _P]),
     "avexhip_dense_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "avexhip_mha_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "avexhip_stack_create": (_P, [_P, _P, C.c_int]),
+    "avexhip_stack_destroy": (None, [_P]),
+    "avexhip_stack_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
+    "avexhip_stack_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
+    "avexhip_stack_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
     "avexhip_lstm_layer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
     "avexhip_fbank_forward_padded": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),

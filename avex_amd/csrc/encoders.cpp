@@ -281,6 +281,106 @@ extern "C" int avexhip_eat_last_profile(const avexhip_eat* h, const char* const*
 }
 
 // =============================================================================================
+// A stack of post-LN transformer layers on caller-provided token rows (the TransformerProbe's nn.TransformerEncoder)
+// =============================================================================================
+struct avexhip_stack : avxh::HandleBase {
+    avexhip_stack_config cfg;
+    CoreCfg core;
+    int chunk = 256;
+    std::vector<Layer> layers;
+};
+
+namespace {
+// torch.nn.TransformerEncoderLayer's parameter names, with in_proj_weight / in_proj_bias passed as in_proj.weight / in_proj.bias
+const avxh::LayerNames STACK_NAMES = {"layers.%d.self_attn.in_proj", nullptr, nullptr, nullptr, "layers.%d.self_attn.out_proj", "layers.%d.norm1",
+                                      "layers.%d.linear1", "layers.%d.linear2", "layers.%d.norm2", nullptr, nullptr};
+struct StackWs { CoreWs core; size_t total; };
+StackWs stack_carve(const avexhip_stack* h, char* base, size_t M) {
+    StackWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    w.core = avxh::carve_core(h->core, M, take);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" avexhip_stack* avexhip_stack_create(const avexhip_stack_config* cfg, const avexhip_tensor* tensors, int n_tensors) {
+    if (!cfg || !tensors || n_tensors <= 0) { avexhip_set_error("stack_create: null config or empty weight table"); return nullptr; }
+    if (avexhip_device_count() <= 0) { avexhip_set_error("stack_create: no HIP device visible (this path has no CPU fallback)"); return nullptr; }
+    const avexhip_stack_config& c = *cfg;
+    if (c.num_heads <= 0 || c.embed_dim != 64 * c.num_heads) { avexhip_set_error("stack_create: head_dim must be 64 (E=%d, H=%d)", c.embed_dim, c.num_heads); return nullptr; }
+    if (c.embed_dim % 128 || c.ffn_dim % 128 || c.ffn_dim <= 0) { avexhip_set_error("stack_create: dims must be MFMA-tile multiples (E=%d F=%d)", c.embed_dim, c.ffn_dim); return nullptr; }
+    if (c.num_layers < 1 || c.num_layers > 32) { avexhip_set_error("stack_create: num_layers=%d out of range", c.num_layers); return nullptr; }
+    if (c.activation != 1 && c.activation != 3) { avexhip_set_error("stack_create: activation %d (1 = erf GELU, 3 = ReLU)", c.activation); return nullptr; }
+    if (c.operand_dtype != AVEXHIP_F16 && c.operand_dtype != AVEXHIP_BF16) { avexhip_set_error("stack_create: unknown operand dtype %d", c.operand_dtype); return nullptr; }
+    avexhip_stack* h = new avexhip_stack();
+    h->who = "stack_create";
+    h->cfg = c;
+    h->dtype = c.operand_dtype;
+    h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.num_layers;
+    h->core.alpha = 1.0f; h->core.eps = c.norm_eps > 0.f ? c.norm_eps : 1e-5f; h->core.hook_site = 0;
+    h->core.fast = c.residual_dtype != 0;
+    h->core.act = c.activation;
+    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
+    if (c.activation != 1) h->core.fold = false;      // the folded epilogues know GELU only
+    h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
+    if (h->init_alarm() != AVEXHIP_OK) { delete h; return nullptr; }
+    const Table tb{tensors, n_tensors};
+    h->layers.resize(h->core.L);
+    for (int i = 0; i < h->core.L; ++i)
+        if (avxh::build_layer(h, tb, STACK_NAMES, h->core, h->layers, i) != AVEXHIP_OK) { delete h; return nullptr; }
+    if (hipDeviceSynchronize() != hipSuccess) { avexhip_set_error("stack_create: upload failed"); delete h; return nullptr; }
+    return h;
+}
+
+extern "C" void avexhip_stack_destroy(avexhip_stack* h) { delete h; }
+
+extern "C" size_t avexhip_stack_workspace_bytes(const avexhip_stack* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    return stack_carve(h, nullptr, (size_t)chunk_for(h->chunk, B, T) * T).total;
+}
+
+extern "C" int avexhip_stack_forward(avexhip_stack* h, const float* x, int B, int T, const uint8_t* key_pad, float* features_out, float* pooled_out,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+    AVX_REQUIRE(h && x && B > 0 && T > 0, "stack_forward: null handle / input or empty batch");
+    AVX_REQUIRE(features_out || pooled_out, "stack_forward: no output requested");
+    const int E = h->core.E, dt = h->dtype;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = chunk_for(h->chunk, B, T);
+    const StackWs need = stack_carve(h, nullptr, (size_t)chunk * T);
+    if (!workspace || ws_bytes < need.total) {
+        avexhip_set_error("stack_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total);
+        return AVEXHIP_ERR_WORKSPACE;
+    }
+    Prof prof{h, s};
+    int rc;
+    for (int c0 = 0; c0 < B; c0 += chunk) {
+        const int Bc = (B - c0) < chunk ? (B - c0) : chunk;
+        const StackWs w = stack_carve(h, (char*)workspace, (size_t)chunk * T);
+        const float* xc = x + (size_t)c0 * T * E;
+        const size_t n = (size_t)Bc * T * E;
+        prof.begin("cast", 0.0);
+        rc = avx::cast_to_half(xc, w.core.xh, (int64_t)n, dt, s);
+        if (rc != AVEXHIP_OK) return rc;
+        if (!h->core.fast) AVX_HIP_CHECK(hipMemcpyAsync(w.core.x, xc, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+        prof.end();
+        CoreIo io;
+        io.Bc = Bc; io.Tt = T; io.c0 = (size_t)c0; io.pad = key_pad ? key_pad + (size_t)c0 * T : nullptr;
+        io.features_out = features_out; io.pooled_out = pooled_out;
+        rc = avxh::run_layers(h, h->core, h->layers, w.core, io, prof, s);
+        if (rc != AVEXHIP_OK) return rc;
+    }
+    { const int rc2 = h->mirror_alarm(s); if (rc2 != AVEXHIP_OK) return rc2; }
+    return prof.collect();
+}
+
+extern "C" int avexhip_stack_overflow_count(avexhip_stack* h, uint32_t* events, void* sync_stream, int synchronize) {
+    AVX_REQUIRE(h && events, "stack_overflow_count: null argument");
+    return h->overflow_count(events, (hipStream_t)sync_stream, synchronize);
+}
+
+// =============================================================================================
 // AVES (wav2vec2-base)
 // =============================================================================================
 struct avexhip_aves : avxh::HandleBase {

@@ -445,6 +445,34 @@ int avexhip_beats_last_profile(const avexhip_beats* h, const char* const** names
                                const double** flops, int* count);
 
 /* ------------------------------------------------------------------------------------------
+ * A stack of post-LN transformer layers on caller-provided token rows: what torch.nn.TransformerEncoder (norm_first = False,
+ * batch_first = True) does inside the reference's TransformerProbe (avex/models/probes/transformer_probe.py:65-72, 112), on the half-
+ * precision kernels of the encoders (f16 / bf16 operands, fp32 accumulate: 1e-3 of the fp32 module, ten times its speed).
+ * Weight table keys: layers.{i}.self_attn.in_proj.{weight,bias} (PyTorch's in_proj_weight / in_proj_bias under these names),
+ * layers.{i}.self_attn.out_proj.*, layers.{i}.norm1.*, layers.{i}.linear1.*, layers.{i}.linear2.*, layers.{i}.norm2.*.
+ * head_dim 64, widths multiples of 128.  x [B, T, E] fp32; key_pad [B, T] (1 = masked key) or NULL; features_out [B, T, E] fp32
+ * (the last norm2) and / or pooled_out [B, E] (its plain mean over the T rows).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct avexhip_stack avexhip_stack;
+typedef struct {
+    int32_t embed_dim;        /* 768 */
+    int32_t num_heads;        /* 12 (head_dim 64) */
+    int32_t num_layers;       /* 4 */
+    int32_t ffn_dim;          /* dim_feedforward (the probe's attention_dim: 768) */
+    float   norm_eps;         /* 1e-5 */
+    int32_t activation;       /* avexhip_gemm_args.gelu code of the feed-forward: 3 ReLU (PyTorch's default), 1 erf GELU */
+    int32_t operand_dtype;
+    int32_t max_chunk_clips;  /* 0 = 256 (scaled down for sequences longer than 512) */
+    int32_t residual_dtype;   /* as avexhip_beats_config */
+} avexhip_stack_config;
+avexhip_stack* avexhip_stack_create(const avexhip_stack_config* cfg, const avexhip_tensor* tensors, int n_tensors);
+void avexhip_stack_destroy(avexhip_stack* h);
+size_t avexhip_stack_workspace_bytes(const avexhip_stack* h, int B, int T);
+int avexhip_stack_forward(avexhip_stack* h, const float* x_dev, int B, int T, const uint8_t* key_pad, float* features_out, float* pooled_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int avexhip_stack_overflow_count(avexhip_stack* h, uint32_t* events, void* sync_stream, int synchronize);
+
+/* ------------------------------------------------------------------------------------------
  * EAT encoder handle: what EATHFModel.forward does per batch (avex/models/eat_hf.py:241-289) --
  * EATAudioProcessor's kaldi fbank image (avex/models/eat/audio_processor.py:72-143) and the HF remote Data2Vec-multi image
  * encoder (backbone.extract_features): 16 x 16 patch rows -> local_encoder -> class token + fixed positions + pre_norm ->

@@ -220,3 +220,32 @@ def test_lstm_layer_long_sequence(built_lib):
         xg = K.dense_f32(x.cuda(), w_ih, b)
         K.lstm_layer(xg, w_hh.t().contiguous(), out, col=di * H, reverse=bool(di))
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_transformer_probe_half_precision_stack(built_lib, monkeypatch):
+    """At the probe's default shape (768 channels, 12 heads of 64, feed-forward 768) the encoder part runs on the half-precision layer kernels
+    (avexhip_stack_*): against the same probe on the fp32 kernels and against the oracle, with and without a key padding mask; a
+    reloaded state dict rebuilds the handle."""
+    from avex_amd import probes as P
+    torch.manual_seed(9)
+    B, T, D, C = 5, 80, 768, 23
+    x = torch.randn(B, T, D).cuda()
+    pr = P.TransformerProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none", num_layers=2, dropout_rate=0.0)
+    gen = torch.Generator().manual_seed(4)
+    sd = {k: (torch.randn(v.shape, generator=gen) * (0.3 if v.dim() == 1 else v.shape[-1] ** -0.5)) for k, v in pr.state_dict().items()}
+    pr.load_state_dict(sd)
+    pad = torch.zeros(B, T, dtype=torch.bool); pad[2, 50:] = True
+    ref = PO.transformer_probe(x.cpu().numpy(), {k: v.numpy() for k, v in sd.items()}, num_heads=12)
+    ref_pad = PO.transformer_probe(x.cpu().numpy(), {k: v.numpy() for k, v in sd.items()}, num_heads=12, key_pad=pad.numpy())
+    fast, fast_pad = pr(x).cpu().numpy(), pr(x, padding_mask=pad.cuda()).cpu().numpy()
+    assert pr._stack is not None                                    # the half-precision handle ran
+    monkeypatch.setenv("AVEX_AMD_PROBE_PRECISION", "fp32")
+    slow = pr(x).cpu().numpy()
+    monkeypatch.delenv("AVEX_AMD_PROBE_PRECISION")
+    assert rel_l2(slow, ref) < 1e-5
+    assert rel_l2(fast, ref) < 2e-3 and rel_l2(fast_pad, ref_pad) < 2e-3
+    assert rel_l2(fast_pad, fast) > 1e-3                            # the mask changed something
+    sd2 = {k: v * 1.5 if k.endswith("linear2.weight") else v for k, v in sd.items()}
+    pr.load_state_dict(sd2)
+    ref2 = PO.transformer_probe(x.cpu().numpy(), {k: v.numpy() for k, v in sd2.items()}, num_heads=12)
+    assert rel_l2(pr(x).cpu().numpy(), ref2) < 2e-3                 # new weights -> new handle
