@@ -512,3 +512,55 @@ class LSTMProbe(_DeviceProbe):
 
 
 PROBES: Dict[str, type] = {"linear": LinearProbe, "mlp": MLPProbe, "attention": AttentionProbe, "transformer": TransformerProbe, "lstm": LSTMProbe}
+
+
+# ---- the reference's probe registry / factory (models/probes/utils/registry.py:28-93, factory.py:24-186) ---------------------------------
+def get_probe_class(name: str) -> Optional[type]:
+    return PROBES.get(str(name).lower())
+
+
+def list_probe_classes() -> List[str]:
+    return list(PROBES)
+
+
+_PROBE_PARAMS = ("hidden_dims", "dropout_rate", "activation", "lstm_hidden_size", "num_layers", "bidirectional", "max_sequence_length",
+                 "use_positional_encoding", "num_heads", "attention_dim")      # factory.py:35-46
+
+
+def build_probe_from_config(probe_config, num_classes: int, device: str, base_model=None, input_dim=None, target_length: Optional[int] = None,
+                            **kwargs):
+    """``build_probe_from_config`` of the reference (factory.py:56-186) over the device probes: ``probe_config`` is the reference's
+    ``ProbeConfig`` (or any object / mapping with its fields: probe_type, target_layers, aggregation, input_processing, freeze_backbone,
+    target_length and the probe-specific ones); exactly one of ``base_model`` (online) and ``input_dim`` (offline, feature mode).  Hooks
+    are registered on the base model, probe-specific fields that are set are passed on, everything is filtered by the probe class's
+    signature -- the same steps, the same errors."""
+    import inspect
+    from collections.abc import Mapping
+
+    def field(name, default=None):
+        return probe_config.get(name, default) if isinstance(probe_config, Mapping) else getattr(probe_config, name, default)
+
+    if base_model is not None and input_dim is not None:
+        raise ValueError("Cannot specify both 'base_model' and 'input_dim'. Use 'base_model' for online mode or 'input_dim' for offline mode.")
+    if base_model is None and input_dim is None:
+        raise ValueError("Must specify either 'base_model' (for online mode) or 'input_dim' (for offline mode).")
+    feature_mode = base_model is None
+    probe_type = str(field("probe_type")).lower()
+    cls = get_probe_class(probe_type)
+    if cls is None:
+        raise ValueError(f"Probe class '{probe_type}' is not registered. Available classes: {list_probe_classes()}")
+    frozen = bool(field("freeze_backbone", True)) if not feature_mode else True
+    layers = list(field("target_layers", []) or [])
+    if field("input_processing", "pooled") == "sequence" and probe_type not in ("lstm", "attention", "transformer"):
+        raise ValueError(f"Sequence input processing is not compatible with {probe_type} probe")
+    if not feature_mode and hasattr(base_model, "register_hooks_for_layers"):
+        layers = base_model.register_hooks_for_layers(layers)
+    init = {"base_model": base_model, "layers": layers, "num_classes": num_classes, "device": device, "feature_mode": feature_mode,
+            "input_dim": input_dim, "aggregation": field("aggregation", "mean"),
+            "target_length": target_length if target_length is not None else field("target_length"), "freeze_backbone": frozen, **kwargs}
+    for name in _PROBE_PARAMS:
+        value = field(name)
+        if value is not None and value != "":
+            init[name] = value
+    valid = set(inspect.signature(cls.__init__).parameters)
+    return cls(**{k: v for k, v in init.items() if k in valid})

@@ -72,3 +72,26 @@ def test_embedding_projectors_match_reference(golden_dir):
     # no majority sequence length -> the target is the longest (40), so the two 24-long taps get 128 -> 128 projectors too
     assert [m is None for m in att.embedding_projectors] == [False, False, False, True]
     att.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("att.sd.")})
+
+
+def test_probe_factory_mirrors_reference():
+    """build_probe_from_config (models/probes/utils/factory.py:56-186): mode selection, errors, probe-specific fields, signature filtering;
+    a plain mapping stands in for the reference's ProbeConfig (the live reference object is exercised by tests/test_binding_contract.py)."""
+    cfg = dict(probe_type="MLP", target_layers=["last_layer"], aggregation="mean", input_processing="pooled", freeze_backbone=True,
+               hidden_dims=[32, 8], dropout_rate=0.0, activation="gelu", num_heads=4, lstm_hidden_size=None, target_length=None)
+    pr = P.build_probe_from_config(cfg, num_classes=7, device="cpu", input_dim=64)
+    assert isinstance(pr, P.MLPProbe) and pr.feature_mode and set(pr.state_dict()) == {"mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
+                                                                                      "mlp.4.weight", "mlp.4.bias"}
+    seq = dict(probe_type="lstm", target_layers=["last_layer"], aggregation="none", input_processing="sequence", lstm_hidden_size=64,
+               num_layers=1, bidirectional=True)
+    ls = P.build_probe_from_config(seq, num_classes=3, device="cpu", input_dim=(40, 128))
+    assert isinstance(ls, P.LSTMProbe) and ls.bidirectional and ls.hidden == 64
+    assert set(P.list_probe_classes()) == {"linear", "mlp", "attention", "lstm", "transformer"} and P.get_probe_class("Transformer") is P.TransformerProbe
+    with pytest.raises(ValueError):
+        P.build_probe_from_config(cfg, num_classes=7, device="cpu")                                   # neither base_model nor input_dim
+    with pytest.raises(ValueError):
+        P.build_probe_from_config(cfg, num_classes=7, device="cpu", base_model=object(), input_dim=64) # both
+    with pytest.raises(ValueError):
+        P.build_probe_from_config(dict(cfg, probe_type="svm"), num_classes=7, device="cpu", input_dim=64)
+    with pytest.raises(ValueError):
+        P.build_probe_from_config(dict(cfg, input_processing="sequence"), num_classes=7, device="cpu", input_dim=64)
