@@ -203,12 +203,12 @@ def test_sequence_probes_match_reference_goldens(built_lib, golden_dir):
     assert rel_l2(bi(seqs).cpu().numpy(), g["bilstm.logits"]) < 1e-5
 
 
-def test_lstm_layer_long_sequence(built_lib):
-    """The recurrence kernel at the probe's real size (496 steps, 256 units, a batch that is no multiple of the clips per workgroup)
-    against torch.nn.LSTM in fp64 on the host."""
+@pytest.mark.parametrize("B,T,D,H", [(5, 496, 64, 128), (6, 64, 96, 256), (3, 48, 64, 320), (2, 24, 64, 576)])
+def test_lstm_layer_long_sequence(built_lib, B, T, D, H):
+    """The recurrence kernel at the probe's real length (496 steps) and in its three thread layouts (four / two / one thread per hidden unit:
+    H <= 256, <= 512, <= 1024), batches that are no multiple of the clips per workgroup, both directions, against torch.nn.LSTM in fp64."""
     from avex_amd import kernels as K
     torch.manual_seed(3)
-    B, T, D, H = 6, 496, 96, 256
     lstm = torch.nn.LSTM(D, H, batch_first=True, bidirectional=True).double().eval()
     x = torch.randn(B, T, D)
     with torch.no_grad():
