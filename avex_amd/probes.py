@@ -474,8 +474,8 @@ class LSTMProbe(_DeviceProbe):
 
     def build_head(self, d: int) -> None:
         hs = int(max(int((self.max_sequence_length or 4) / 4), self.lstm_hidden_size))      # lstm_probe.py:60
-        if hs % 64 or hs > 1024:
-            raise ValueError(f"LSTMProbe on the device needs a hidden size that is a multiple of 64 and at most 1024, got {hs}")
+        if hs > 1024:
+            raise ValueError(f"LSTMProbe on the device takes at most 1024 hidden units, got {hs}")
         self.hidden = hs
         dirs = 2 if self.bidirectional else 1
         for layer in range(self.num_layers):

@@ -197,7 +197,7 @@ int avexhip_dense_f32(const float* x_dev, int64_t ldx, const float* w_dev, int64
 int avexhip_mha_f32(const float* qkv_dev, int B, int T, int E, int H, const uint8_t* key_pad_dev, float* out_dev, void* stream);
 /* One direction of one nn.LSTM layer (batch first, zero initial state; lstm_probe.py:61-68, 100): xg [B, T, 4H] = x W_ih^T + b_ih + b_hh
  * (gate order i, f, g, o), w_hhT [H, 4H] = W_hh transposed, out[b, t, 0..H) at row stride ldo (2H with a column offset for the
- * reverse direction of a bidirectional layer), reverse != 0 walks t = T-1 .. 0.  H a multiple of 64, <= 1024; fp32. */
+ * reverse direction of a bidirectional layer), reverse != 0 walks t = T-1 .. 0.  1 <= H <= 1024; fp32. */
 int avexhip_lstm_layer(const float* xg_dev, const float* w_hhT_dev, int B, int T, int H, int reverse, float* out_dev, int64_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -203,7 +203,7 @@ def test_sequence_probes_match_reference_goldens(built_lib, golden_dir):
     assert rel_l2(bi(seqs).cpu().numpy(), g["bilstm.logits"]) < 1e-5
 
 
-@pytest.mark.parametrize("B,T,D,H", [(5, 496, 64, 128), (6, 64, 96, 256), (3, 48, 64, 320), (2, 24, 64, 576)])
+@pytest.mark.parametrize("B,T,D,H", [(5, 496, 64, 128), (6, 64, 96, 256), (3, 48, 64, 320), (2, 24, 64, 576), (5, 40, 64, 300), (3, 30, 32, 100)])
 def test_lstm_layer_long_sequence(built_lib, B, T, D, H):
     """The recurrence kernel at the probe's real length (496 steps) and in its three thread layouts (four / two / one thread per hidden unit:
     H <= 256, <= 512, <= 1024), batches that are no multiple of the clips per workgroup, both directions, against torch.nn.LSTM in fp64."""
@@ -220,6 +220,40 @@ def test_lstm_layer_long_sequence(built_lib, B, T, D, H):
         xg = K.dense_f32(x.cuda(), w_ih, b)
         K.lstm_layer(xg, w_hh.t().contiguous(), out, col=di * H, reverse=bool(di))
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_lstm_probe_shipped_config_shape(built_lib):
+    """The LSTM probe as the reference's evaluation configs build it (lstm_hidden_size 128, max_sequence_length 1200 -> 300 units, two
+    layers) against the oracle (pinned to the reference's class at other sizes)."""
+    from avex_amd import probes as P
+    cfg = dict(probe_type="lstm", target_layers=["last_layer"], aggregation="none", input_processing="sequence", lstm_hidden_size=128, num_layers=2,
+               bidirectional=False, max_sequence_length=1200, use_positional_encoding=False, dropout_rate=0.3)
+    pr = P.build_probe_from_config(cfg, num_classes=11, device="cuda", input_dim=(60, 256))
+    assert pr.hidden == 300
+    gen = torch.Generator().manual_seed(8)
+    sd = {k: (torch.randn(v.shape, generator=gen) * (0.3 if v.dim() == 1 else v.shape[-1] ** -0.5)) for k, v in pr.state_dict().items()}
+    pr.load_state_dict(sd)
+    x = torch.randn(4, 60, 256, generator=gen)
+    ref = PO.lstm_probe(x.numpy(), {k: v.numpy() for k, v in sd.items()})
+    assert rel_l2(pr(x.cuda()).cpu().numpy(), ref) < 2e-5
+
+
+def test_transformer_probe_shipped_config_shape(built_lib):
+    """The transformer probe as the reference's evaluation configs build it behind BEATs (768 channels, 8 heads -> head_dim 96, feed-forward
+    128, one layer, no positions): head_dim 96 keeps it on the fp32 kernels; against the oracle, with a key padding mask."""
+    from avex_amd import probes as P
+    cfg = dict(probe_type="transformer", target_layers=["last_layer"], aggregation="none", input_processing="sequence", num_heads=8, attention_dim=128,
+               num_layers=1, max_sequence_length=1200, use_positional_encoding=False, dropout_rate=0.3)
+    pr = P.build_probe_from_config(cfg, num_classes=11, device="cuda", input_dim=(100, 768))
+    assert pr.num_heads == 8 and not pr._stack_ok(768)
+    gen = torch.Generator().manual_seed(18)
+    sd = {k: (torch.randn(v.shape, generator=gen) * (0.3 if v.dim() == 1 else v.shape[-1] ** -0.5)) for k, v in pr.state_dict().items()}
+    pr.load_state_dict(sd)
+    x = torch.randn(3, 100, 768, generator=gen)
+    pad = torch.zeros(3, 100, dtype=torch.bool); pad[0, 70:] = True
+    npsd = {k: v.numpy() for k, v in sd.items()}
+    assert rel_l2(pr(x.cuda()).cpu().numpy(), PO.transformer_probe(x.numpy(), npsd, num_heads=8)) < 1e-5
+    assert rel_l2(pr(x.cuda(), padding_mask=pad.cuda()).cpu().numpy(), PO.transformer_probe(x.numpy(), npsd, num_heads=8, key_pad=pad.numpy())) < 1e-5
 
 
 def test_transformer_probe_half_precision_stack(built_lib, monkeypatch):

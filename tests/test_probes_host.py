@@ -38,8 +38,11 @@ def test_sequence_probe_keys_match_reference(golden_dir):
     ls = P.LSTMProbe(None, [], 19, device="cpu", feature_mode=True, input_dim=[(40, 128)] * 3, aggregation="none", lstm_hidden_size=64,
                      num_layers=2, bidirectional=True, max_sequence_length=64, use_positional_encoding=True)
     assert {k: tuple(v.shape) for k, v in ls.state_dict().items()} == {k[10:]: g[k].shape for k in g.files if k.startswith("bilstm.sd.")}
-    with pytest.raises(ValueError):          # 100 units: not a multiple of 64 (the recurrence kernel's thread layout)
-        P.LSTMProbe(None, [], 3, device="cpu", feature_mode=True, input_dim=(40, 128), aggregation="none", lstm_hidden_size=100)
+    # the shipped evaluation configs: lstm_hidden_size below max_sequence_length / 4 = 300 units (lstm_probe.py:60)
+    big = P.LSTMProbe(None, [], 3, device="cpu", feature_mode=True, input_dim=(40, 128), aggregation="none", lstm_hidden_size=128, max_sequence_length=1200)
+    assert big.hidden == 300 and big.state_dict()["lstm.weight_hh_l0"].shape == (1200, 300)
+    with pytest.raises(ValueError):          # more units than threads of a workgroup
+        P.LSTMProbe(None, [], 3, device="cpu", feature_mode=True, input_dim=(40, 128), aggregation="none", lstm_hidden_size=2048)
 
 
 def test_refusals():
