@@ -22,7 +22,8 @@ __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restric
     float* part = lds + LR * H;
     const int j = threadIdx.x % H, q = threadIdx.x / H;
     const int b0 = blockIdx.x * LR;
-    const int k0 = q * (H / KS), k1 = k0 + H / KS;
+    const int kq = (H + KS - 1) / KS;                          // this thread's share of the contraction (the last share may be shorter)
+    const int k0 = q * kq, k1 = k0 + kq < H ? k0 + kq : H;
     float c[(LR + KS - 1) / KS];
 #pragma unroll
     for (int i = 0; i < (LR + KS - 1) / KS; ++i) c[i] = 0.f;
@@ -80,6 +81,10 @@ extern "C" int avexhip_lstm_layer(const float* xg, const float* w_hhT, int B, in
         const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)4 * LR * 4 * H);
         AVX_ENSURE_LDS(lstm_layer_kernel<4>, 96 * 1024);
         lstm_layer_kernel<4><<<grid, dim3(4 * H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo);
+    } else if (H <= 341) {      // (the reference's shipped configs: 300 units)
+        const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)3 * LR * 4 * H);
+        AVX_ENSURE_LDS(lstm_layer_kernel<3>, 96 * 1024);
+        lstm_layer_kernel<3><<<grid, dim3(3 * H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo);
     } else if (H <= 512) {
         const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)2 * LR * 4 * H);
         AVX_ENSURE_LDS(lstm_layer_kernel<2>, 96 * 1024);

@@ -26,8 +26,13 @@ probes = {
     "lstm (2 layers, 256 units)": P.LSTMProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none"),
     "lstm (2 layers, 256 units, bidirectional)": P.LSTMProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none", bidirectional=True),
 }
+# the shapes of the reference's shipped evaluation configs (configs/evaluation_configs/*: 8 heads, attention_dim 128, 1 layer; 128 units -> 300)
+probes["transformer, shipped config (8 heads of 96, ff 128, 1 layer)"] = P.TransformerProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none",
+                                                                                             num_heads=8, attention_dim=128, num_layers=1, max_sequence_length=1200)
+probes["lstm, shipped config (2 layers, 300 units)"] = P.LSTMProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none", lstm_hidden_size=128,
+                                                                    num_layers=2, max_sequence_length=1200)
 for name, pr in probes.items():
     for k, v in pr.state_dict().items():
         if v.dtype == torch.float32 and "norm" not in k:
             v.normal_(0, 0.03)
-    print(f"{name:44s} {timeit(lambda: pr(x)):8.2f} ms per {B} clips")
+    print(f"{name:62s} {timeit(lambda: pr(x)):8.2f} ms per {B} clips")
