@@ -59,39 +59,47 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 }
 
 #ifndef DW_PIX
-#define DW_PIX 8      // 4: 13.5 ms per 256 clips, 8: 12.8, 12: 13.2, 16: 14.1 (fewer L2 reads per output against registers)
+#define DW_PIX 8      // output pixels along x per thread
 #endif
-// one thread: 8 channels, PIX consecutive output pixels along x of one row; squeeze sums via atomics
+#ifndef DW_PY
+#define DW_PY 1       // output rows per thread
+#endif
+// one thread: 8 channels, PIX consecutive output pixels along x of PY consecutive output rows; squeeze sums via atomics.  The kernel is
+// bound by its 16-byte loads from L2 (every input element is wanted by KS x KS outputs): a 1 x 4 tile makes 4.5 loads per output at 3 x 3
+// (13.5 ms per 256 clips of EfficientNet-B0 at the time), 1 x 8 3.75 (12.8 ms); wider tiles lose to their registers (1 x 12: 13.2, 1 x 16:
+// 14.1 ms), and two-row tiles, fewer loads still, do not pay either (on the final tree: 1 x 8 10.5 ms, 2 x 4 11.0, 2 x 6 10.6, 2 x 8 10.9).
+// Every output adds its taps in (ky, kx) order whatever the tile: the tile shape does not change a bit of the result.
 template <typename T, int KS, int ST>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
                                                      const float* __restrict__ w /*[KS*KS][Cp]*/, const float* __restrict__ bias,
                                                      T* __restrict__ out, float* __restrict__ pool /*[B][Cp]*/) {
     typedef typename Half<T>::v8 v8;
-    constexpr int PAD = (KS - 1) / 2, PIX = DW_PIX;
+    constexpr int PAD = (KS - 1) / 2, PIX = DW_PIX, PY = DW_PY;
+    constexpr int NCOL = (PIX - 1) * ST + KS, NROW = (PY - 1) * ST + KS;
     const int cg = Cp >> 3;
-    const int xg = (Wo + PIX - 1) / PIX;
+    const int xg = (Wo + PIX - 1) / PIX, yg = (Ho + PY - 1) / PY;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    const bool active = idx < (int64_t)Ho * xg * cg;
+    const bool active = idx < (int64_t)yg * xg * cg;
     const int c8 = (int)(idx % cg) * 8;
     const int64_t t = idx / cg;
-    const int oy = (int)(t / xg), ox0 = (int)(t - (int64_t)oy * xg) * PIX;
+    const int oy0 = (int)(t / xg) * PY, ox0 = (int)(t - (int64_t)(t / xg) * xg) * PIX;
     float psum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) psum[e] = 0.f;
     if (active) {
-        float acc[PIX][8];
+        float acc[PY][PIX][8];
 #pragma unroll
-        for (int p = 0; p < PIX; ++p)
+        for (int py = 0; py < PY; ++py)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+            for (int p = 0; p < PIX; ++p)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[py][p][e] = 0.f;
         const T* src = in + (int64_t)b * H * W * Cp + c8;
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-            const int iy = oy * ST + ky - PAD;
+        for (int r = 0; r < NROW; ++r) {
+            const int iy = oy0 * ST - PAD + r;
             if (iy < 0 || iy >= H) continue;
-            // the input columns this thread touches: ox0*ST - PAD .. (ox0+PIX-1)*ST - PAD + KS - 1
-            constexpr int NCOL = (PIX - 1) * ST + KS;
             v8 col[NCOL];
 #pragma unroll
             for (int q = 0; q < NCOL; ++q) {
@@ -103,32 +111,42 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, i
                 }
             }
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const f32x4 w0 = *(const f32x4*)(w + (ky * KS + kx) * Cp + c8), w1 = *(const f32x4*)(w + (ky * KS + kx) * Cp + c8 + 4);
+            for (int py = 0; py < PY; ++py) {
+                const int ky = r - py * ST;                 // compile-time after unrolling
+                if (ky < 0 || ky >= KS) continue;
 #pragma unroll
-                for (int p = 0; p < PIX; ++p) {
-                    const v8 x = col[p * ST + kx];
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f32x4 w0 = *(const f32x4*)(w + (ky * KS + kx) * Cp + c8), w1 = *(const f32x4*)(w + (ky * KS + kx) * Cp + c8 + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[p][e] = __builtin_fmaf((float)x[e], w0[e], acc[p][e]);
-                        acc[p][4 + e] = __builtin_fmaf((float)x[4 + e], w1[e], acc[p][4 + e]);
+                    for (int p = 0; p < PIX; ++p) {
+                        const v8 x = col[p * ST + kx];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[py][p][e] = __builtin_fmaf((float)x[e], w0[e], acc[py][p][e]);
+                            acc[py][p][4 + e] = __builtin_fmaf((float)x[4 + e], w1[e], acc[py][p][4 + e]);
+                        }
                     }
                 }
             }
         }
         const f32x4 b0 = *(const f32x4*)(bias + c8), b1 = *(const f32x4*)(bias + c8 + 4);
 #pragma unroll
-        for (int p = 0; p < PIX; ++p) {
-            const int ox = ox0 + p;
-            if (ox >= Wo) break;
-            v8 h;
+        for (int py = 0; py < PY; ++py) {
+            const int oy = oy0 + py;
+            if (oy >= Ho) break;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float y = silu1(acc[p][e] + (e < 4 ? b0[e] : b1[e - 4]));
-                h[e] = Half<T>::from(y);
-                psum[e] += (float)h[e];                    // the pool sees what the next layer will read
+            for (int p = 0; p < PIX; ++p) {
+                const int ox = ox0 + p;
+                if (ox >= Wo) break;
+                v8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = silu1(acc[py][p][e] + (e < 4 ? b0[e] : b1[e - 4]));
+                    h[e] = Half<T>::from(y);
+                    psum[e] += (float)h[e];                    // the pool sees what the next layer will read
+                }
+                *(v8*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * Cp + c8) = h;
             }
-            *(v8*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * Cp + c8) = h;
         }
     }
     // squeeze: lanes of a wave hold different channel groups when cg < 64, the same group every cg lanes
@@ -216,7 +234,7 @@ template <typename T>
 static int dw_launch(const void* in, int B, int H, int W, int Cp, int k, int st, const float* w, const float* bias, void* out, float* pool, hipStream_t s) {
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
-    const int64_t n = (int64_t)Ho * ((Wo + DW_PIX - 1) / DW_PIX) * (Cp / 8);
+    const int64_t n = (int64_t)((Ho + DW_PY - 1) / DW_PY) * ((Wo + DW_PIX - 1) / DW_PIX) * (Cp / 8);
     const dim3 grid((unsigned)((n + 255) / 256), B);
     if (pool) AVX_HIP_CHECK(hipMemsetAsync(pool, 0, sizeof(float) * (size_t)B * Cp, s));
 #define AVX_DW(KS, ST) hipLaunchKernelGGL((dwconv_kernel<T, KS, ST>), grid, dim3(256), 0, s, (const T*)in, H, W, Ho, Wo, Cp, w, bias, (T*)out, pool)
