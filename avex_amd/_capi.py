@@ -104,7 +104,8 @@ SYMBOLS = {
     "avexhip_melspec_num_bins": (C.c_int, [_P]),
     "avexhip_melspec_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P]),
     "avexhip_effnet_stem": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
-    "avexhip_effnet_dwconv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
+    "avexhip_effnet_dwconv_part_bytes": (C.c_size_t, [C.c_int] * 6),
+    "avexhip_effnet_dwconv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "avexhip_effnet_se": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "avexhip_resample_plan_create": (_P, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
     "avexhip_resample_interp_plan_create": (_P, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),

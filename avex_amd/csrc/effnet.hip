@@ -6,7 +6,7 @@
 //                  (efficientnet.py:133-135: x.repeat(1, 3, 1, 1)), i.e. a 1-channel convolution with channel-summed weights,
 //                  + folded BatchNorm + SiLU, fp32 [B, H, W] in -> NHWC half out
 //   dwconv         depthwise k x k (3 or 5), stride 1 or 2, "same" padding, folded BatchNorm + SiLU, and the
-//                  squeeze-excitation average pool accumulated on the way out (fp32 atomics per clip and channel)
+//                  squeeze-excitation average pool accumulated on the way out (one row of partial sums per workgroup, added in order)
 //   se_fc          the two tiny fully connected layers of squeeze-excitation per clip: sigmoid(W2 silu(W1 mean + b1) + b2)
 //   scale_channels x[b, p, c] *= s[b, c] (the excitation), in place
 #include "common.h"
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 #ifndef DW_PY
 #define DW_PY 1       // output rows per thread
 #endif
-// one thread: 8 channels, PIX consecutive output pixels along x of PY consecutive output rows; squeeze sums via atomics.  The kernel is
+// one thread: 8 channels, PIX consecutive output pixels along x of PY consecutive output rows; squeeze sums leave as per-workgroup partials.  The kernel is
 // bound by its 16-byte loads from L2 (every input element is wanted by KS x KS outputs): a 1 x 4 tile makes 4.5 loads per output at 3 x 3
 // (13.5 ms per 256 clips of EfficientNet-B0 at the time), 1 x 8 3.75 (12.8 ms); wider tiles lose to their registers (1 x 12: 13.2, 1 x 16:
 // 14.1 ms), and two-row tiles, fewer loads still, do not pay either (on the final tree: 1 x 8 10.5 ms, 2 x 4 11.0, 2 x 6 10.6, 2 x 8 10.9).
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 template <typename T, int KS, int ST>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
                                                      const float* __restrict__ w /*[KS*KS][Cp]*/, const float* __restrict__ bias,
-                                                     T* __restrict__ out, float* __restrict__ pool /*[B][Cp]*/) {
+                                                     T* __restrict__ out, float* __restrict__ part /*[B][gridDim.x][Cp]*/) {
     typedef typename Half<T>::v8 v8;
     constexpr int PAD = (KS - 1) / 2, PIX = DW_PIX, PY = DW_PY;
     constexpr int NCOL = (PIX - 1) * ST + KS, NROW = (PY - 1) * ST + KS;
@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, i
             }
         }
     }
-    // squeeze: lanes of a wave hold different channel groups when cg < 64, the same group every cg lanes
-    if (pool) {
+    // squeeze: lanes of a wave hold different channel groups when cg < 64, the same group every cg lanes.  Each workgroup leaves ONE row of
+    // partial sums (cg <= 256, so its 256 consecutive threads meet every channel group); pool_sum_kernel adds the rows in index order, so the
+    // pool - and with it the whole network - repeats bit for bit from run to run (float atomics here made it depend on arrival order).
+    if (part) {
         __shared__ float red[256 * 8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = psum[e];
@@ -163,9 +165,22 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, i
             float s = 0.f;
             for (int q = g; q < 256; q += cg) s += red[q * 8 + e];
             const int grp = (first + g) % cg;
-            if (s != 0.f) atomicAdd(pool + (int64_t)b * Cp + grp * 8 + e, s);
+            part[((int64_t)b * gridDim.x + blockIdx.x) * Cp + grp * 8 + e] = s;
         }
     }
+}
+
+// pool[b][c] = sum over the depthwise kernel's workgroups, in workgroup order
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ part, int nblk, int Cp, float* __restrict__ pool) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cp) return;
+    const float* p = part + (int64_t)b * nblk * Cp + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= nblk; i += 4) { s0 += p[(int64_t)i * Cp]; s1 += p[(int64_t)(i + 1) * Cp]; s2 += p[(int64_t)(i + 2) * Cp]; s3 += p[(int64_t)(i + 3) * Cp]; }
+    for (; i < nblk; ++i) s0 += p[(int64_t)i * Cp];
+    pool[(int64_t)b * Cp + c] = (s0 + s1) + (s2 + s3);
 }
 
 // s[b][c] = sigmoid(W2[c,:] . silu(W1 mean_b + b1) + b2[c]);   one workgroup per clip
@@ -230,30 +245,50 @@ extern "C" int avexhip_effnet_stem(const float* img_dev, int B, int H, int W, co
     return AVEXHIP_OK;
 }
 
-template <typename T>
-static int dw_launch(const void* in, int B, int H, int W, int Cp, int k, int st, const float* w, const float* bias, void* out, float* pool, hipStream_t s) {
+static int64_t dw_blocks(int H, int W, int Cp, int k, int st) {
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
     const int64_t n = (int64_t)((Ho + DW_PY - 1) / DW_PY) * ((Wo + DW_PIX - 1) / DW_PIX) * (Cp / 8);
-    const dim3 grid((unsigned)((n + 255) / 256), B);
-    if (pool) AVX_HIP_CHECK(hipMemsetAsync(pool, 0, sizeof(float) * (size_t)B * Cp, s));
-#define AVX_DW(KS, ST) hipLaunchKernelGGL((dwconv_kernel<T, KS, ST>), grid, dim3(256), 0, s, (const T*)in, H, W, Ho, Wo, Cp, w, bias, (T*)out, pool)
+    return (n + 255) / 256;
+}
+
+template <typename T>
+static int dw_launch(const void* in, int B, int H, int W, int Cp, int k, int st, const float* w, const float* bias, void* out, float* pool,
+                     float* part, hipStream_t s) {
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
+    const dim3 grid((unsigned)dw_blocks(H, W, Cp, k, st), B);
+    if (!pool) part = nullptr;
+#define AVX_DW(KS, ST) hipLaunchKernelGGL((dwconv_kernel<T, KS, ST>), grid, dim3(256), 0, s, (const T*)in, H, W, Ho, Wo, Cp, w, bias, (T*)out, part)
     if (k == 3 && st == 1) AVX_DW(3, 1);
     else if (k == 3 && st == 2) AVX_DW(3, 2);
     else if (k == 5 && st == 1) AVX_DW(5, 1);
     else if (k == 5 && st == 2) AVX_DW(5, 2);
     else { avexhip_set_error("effnet_dwconv: kernel %d stride %d not built (3 or 5, stride 1 or 2)", k, st); return AVEXHIP_ERR_INVALID; }
 #undef AVX_DW
+    if (pool) hipLaunchKernelGGL(pool_sum_kernel, dim3((Cp + 255) / 256, B), dim3(256), 0, s, part, (int)grid.x, Cp, pool);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
 
+extern "C" size_t avexhip_effnet_dwconv_part_bytes(int B, int H, int W, int Cp, int k, int stride) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return 0;
+    return sizeof(float) * (size_t)B * (size_t)dw_blocks(H, W, Cp, k, stride) * Cp;
+}
+
 extern "C" int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, int Cp, int k, int stride, const float* w_dev,
-                                     const float* bias_dev, void* out_dev, float* pool_dev, int dtype, void* stream) {
+                                     const float* bias_dev, void* out_dev, float* pool_dev, float* part_dev, size_t part_bytes, int dtype,
+                                     void* stream) {
     AVX_REQUIRE(in_dev && w_dev && bias_dev && out_dev, "effnet_dwconv: null argument");
     AVX_REQUIRE(B > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "effnet_dwconv: bad shape");
-    if (dtype == AVEXHIP_BF16) return dw_launch<__bf16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, (hipStream_t)stream);
-    return dw_launch<_Float16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, (hipStream_t)stream);
+    if (pool_dev) {
+        AVX_REQUIRE(Cp <= 2048, "effnet_dwconv: the pooled form wants at most 2048 padded channels, got %d", Cp);
+        AVX_REQUIRE(part_dev && part_bytes >= avexhip_effnet_dwconv_part_bytes(B, H, W, Cp, k, stride),
+                    "effnet_dwconv: the pooled form wants avexhip_effnet_dwconv_part_bytes() = %zu bytes of scratch, got %zu",
+                    avexhip_effnet_dwconv_part_bytes(B, H, W, Cp, k, stride), part_bytes);
+    }
+    if (dtype == AVEXHIP_BF16) return dw_launch<__bf16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, part_dev, (hipStream_t)stream);
+    return dw_launch<_Float16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, part_dev, (hipStream_t)stream);
 }
 
 extern "C" int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, int Cs, const float* w1_dev, const float* b1_dev,

@@ -194,8 +194,8 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
 inline int conv_out(int n, int k, int s) { const int pad = (k - 1) / 2; return (n + 2 * pad - k) / s + 1; }
 
 struct EffWs {
-    char* act[4]; float* raw; float* pool; float* scale; float* headf;
-    size_t total;
+    char* act[4]; float* raw; float* pool; float* scale; float* headf; float* part;
+    size_t total, part_bytes;
 };
 
 // worst-case buffers for a chunk of Bc clips of H x W: four activation buffers (block input / expanded / depthwise output / block output
@@ -206,8 +206,11 @@ EffWs eff_carve(const avexhip_effnet* h, char* base, int Bc, int H, int W) {
     max_act = (size_t)hh * ww * h->cp0 * 2;
     max_raw = (size_t)hh * ww * h->cp0 * 4;
     int cpmax = h->cp0;
+    size_t max_part = 0;                                   // the depthwise kernel's rows of partial squeeze sums
     for (const Block& b : h->blocks) {
         if ((size_t)hh * ww * b.cp_exp * 2 > max_act) max_act = (size_t)hh * ww * b.cp_exp * 2;
+        const size_t part = avexhip_effnet_dwconv_part_bytes(Bc, hh, ww, b.cp_exp, b.k, b.stride);
+        if (part > max_part) max_part = part;
         hh = conv_out(hh, b.k, b.stride); ww = conv_out(ww, b.k, b.stride);
         if ((size_t)hh * ww * b.cp_exp * 2 > max_act) max_act = (size_t)hh * ww * b.cp_exp * 2;
         if ((size_t)hh * ww * b.cp_out * 2 > max_act) max_act = (size_t)hh * ww * b.cp_out * 2;      // (the first block widens: 64 padded channels in, 128 out)
@@ -224,6 +227,8 @@ EffWs eff_carve(const avexhip_effnet* h, char* base, int Bc, int H, int W) {
     w.pool = (float*)take((size_t)Bc * cpmax * 4);
     w.scale = (float*)take((size_t)Bc * cpmax * 4);
     w.headf = (float*)take((size_t)Bc * headf);
+    w.part = (float*)take(max_part);
+    w.part_bytes = max_part;
     w.total = off;
     return w;
 }
@@ -332,7 +337,7 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             const int dw = (in_buf + 2) & 3;
             const int h2 = conv_out(hh, b.k, b.stride), w2 = conv_out(ww, b.k, b.stride);
             prof.begin("dwconv", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k);
-            RC(avexhip_effnet_dwconv(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.pool, dt, s));
+            RC(avexhip_effnet_dwconv(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.pool, w.part, w.part_bytes, dt, s));
             prof.end();
             const int M2 = Bc * h2 * w2;
             const int out = (in_buf + 3) & 3;

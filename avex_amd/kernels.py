@@ -257,7 +257,9 @@ def effnet_dwconv(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, k: int, 
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((B, Ho, Wo, Cp), dtype=x.dtype, device=x.device)
     pool = torch.empty((B, Cp), dtype=torch.float32, device=x.device) if want_pool else None
-    check(lib().avexhip_effnet_dwconv(_ptr(x), B, H, W, Cp, k, stride, _ptr(w.contiguous()), _ptr(bias), _ptr(out), _ptr(pool), code, _stream()), "effnet_dwconv")
+    nbytes = int(lib().avexhip_effnet_dwconv_part_bytes(B, H, W, Cp, k, stride)) if want_pool else 0
+    part = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device) if want_pool else None     # one row of partial sums per workgroup
+    check(lib().avexhip_effnet_dwconv(_ptr(x), B, H, W, Cp, k, stride, _ptr(w.contiguous()), _ptr(bias), _ptr(out), _ptr(pool), _ptr(part), nbytes, code, _stream()), "effnet_dwconv")
     return out, pool
 
 

@@ -121,13 +121,17 @@ int avexhip_melspec_forward(const avexhip_melspec_plan* plan, const float* wav_d
  *          Conv2d(3->32, 3x3, s2, p1) with channel-summed, BN-folded weights w [9, Cp] + bias [Cp] + SiLU -> [B, Ho, Wo, Cp];
  *          raw_dev (optional, fp32 [B, Ho, Wo, Cp]) receives the pre-activation values.
  *  dwconv: depthwise k x k (3 | 5), stride (1 | 2), padding (k-1)/2, w [k*k, Cp] BN-folded, + SiLU; pool_dev [B, Cp] fp32
- *          (optional) receives the per-clip channel sums of the output (squeeze of squeeze-excitation).
+ *          (optional) receives the per-clip channel sums of the output (squeeze of squeeze-excitation); that form wants part_dev,
+ *          avexhip_effnet_dwconv_part_bytes() bytes of scratch: every workgroup leaves one row of partial sums there and a second
+ *          small kernel adds the rows in order, so the sums (and everything after them) repeat bit for bit from run to run.
  *  se:     scale[b, c] = sigmoid(W2 silu(W1 (pool / hw) + b1) + b2), then x[b, :, c] *= scale[b, c] in place (x_dev NULL: the scale
  *          vector only -- the EfficientNet handle applies it inside the projection that follows when that runs in the skinny kernel). */
 int avexhip_effnet_stem(const float* img_dev, int B, int H, int W, const float* w_dev, const float* bias_dev, int Cp,
                         void* out_dev, float* raw_dev, int dtype, void* stream);
+size_t avexhip_effnet_dwconv_part_bytes(int B, int H, int W, int Cp, int k, int stride);
 int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, int Cp, int k, int stride, const float* w_dev,
-                          const float* bias_dev, void* out_dev, float* pool_dev, int dtype, void* stream);
+                          const float* bias_dev, void* out_dev, float* pool_dev, float* part_dev, size_t part_bytes, int dtype,
+                          void* stream);
 int avexhip_effnet_se(const float* pool_dev, int B, int64_t hw, int C, int Cp, int Cs, const float* w1_dev, const float* b1_dev,
                       const float* w2_dev, const float* b2_dev, float* scale_dev, void* x_dev, int dtype, void* stream);
 

@@ -791,6 +791,8 @@ def test_effnet_blocks_match_oracle(built_lib):
         o = out.float().cpu().numpy()
         assert o.shape[:3] == r.shape[:3] and rel_l2(o[..., :C], r) < 6e-4 and np.all(o[..., C:] == 0)
         assert np.allclose(pool.cpu().numpy()[:, :C], o[..., :C].sum((1, 2)), rtol=1e-4, atol=1e-2)
+        for _ in range(3):                                  # ordered partial sums, not atomics: the squeeze repeats bit for bit
+            assert torch.equal(K.effnet_dwconv(_dev(x, torch.float16), _dev(wdp), _dev(bdp), k, s)[1], pool)
         Cs = 10
         w1 = synth.normal("ese1", (Cs, C), 0.3); b1 = synth.normal("ese1b", (Cs,), 0.1); w2 = synth.normal("ese2", (C, Cs), 0.5); b2 = synth.normal("ese2b", (C,), 0.3)
         xs = out.clone()
@@ -840,3 +842,6 @@ def test_effnet_b0_matches_oracle(built_lib):
     allr = enc.forward(_dev(mel), hook_layers=names, want_features=False)
     for n in names[1:]:
         assert rel_l2(allr["hooks"][n].cpu().numpy(), taps[n]) < 1.5e-3, n
+    again = enc.forward(_dev(mel), hook_layers=[names[-1]], want_features=True, want_pooled=True)      # no float atomics anywhere: bit for bit
+    assert torch.equal(again["features"], r["features"]) and torch.equal(again["pooled"], r["pooled"])
+    assert torch.equal(again["hooks"][names[-1]], r["hooks"][names[-1]])
