@@ -143,6 +143,7 @@ SYMBOLS = {
     "avexhip_layernorm": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P, C.c_int64, _P,
                                     C.c_int64, C.c_int, _P]),
     "avexhip_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "avexhip_attention_hd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "avexhip_posconv_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "avexhip_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     "avexhip_mean_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -328,6 +328,7 @@ int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const flo
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
               hipStream_t s, int q_log2e = 0);
+int attention_hd(const void* qkv, int B, int T, int H, int head_dim, const uint8_t* key_pad, void* out, int dtype, hipStream_t s, int q_log2e = 0);
 int posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed, int dtype,
                  hipStream_t s);
 // residual = x_f32 if non-null else x_half; writes out_f32 and/or out_half

@@ -309,8 +309,12 @@ extern "C" avexhip_stack* avexhip_stack_create(const avexhip_stack_config* cfg, 
     if (!cfg || !tensors || n_tensors <= 0) { avexhip_set_error("stack_create: null config or empty weight table"); return nullptr; }
     if (avexhip_device_count() <= 0) { avexhip_set_error("stack_create: no HIP device visible (this path has no CPU fallback)"); return nullptr; }
     const avexhip_stack_config& c = *cfg;
-    if (c.num_heads <= 0 || c.embed_dim != 64 * c.num_heads) { avexhip_set_error("stack_create: head_dim must be 64 (E=%d, H=%d)", c.embed_dim, c.num_heads); return nullptr; }
-    if (c.embed_dim % 128 || c.ffn_dim % 128 || c.ffn_dim <= 0) { avexhip_set_error("stack_create: dims must be MFMA-tile multiples (E=%d F=%d)", c.embed_dim, c.ffn_dim); return nullptr; }
+    const int hd = c.num_heads > 0 ? c.embed_dim / c.num_heads : 0;
+    if (c.num_heads <= 0 || c.embed_dim != hd * c.num_heads || (hd != 32 && hd != 64 && hd != 96 && hd != 128)) {
+        avexhip_set_error("stack_create: head width must be 32, 64, 96 or 128 (E=%d, H=%d)", c.embed_dim, c.num_heads);
+        return nullptr;
+    }
+    if (c.embed_dim % 128 || c.ffn_dim % 128 || c.ffn_dim < 0) { avexhip_set_error("stack_create: dims must be MFMA-tile multiples (E=%d F=%d)", c.embed_dim, c.ffn_dim); return nullptr; }
     if (c.num_layers < 1 || c.num_layers > 32) { avexhip_set_error("stack_create: num_layers=%d out of range", c.num_layers); return nullptr; }
     if (c.activation != 1 && c.activation != 3) { avexhip_set_error("stack_create: activation %d (1 = erf GELU, 3 = ReLU)", c.activation); return nullptr; }
     if (c.operand_dtype != AVEXHIP_F16 && c.operand_dtype != AVEXHIP_BF16) { avexhip_set_error("stack_create: unknown operand dtype %d", c.operand_dtype); return nullptr; }
@@ -318,12 +322,12 @@ extern "C" avexhip_stack* avexhip_stack_create(const avexhip_stack_config* cfg, 
     h->who = "stack_create";
     h->cfg = c;
     h->dtype = c.operand_dtype;
-    h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.num_layers;
+    h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.num_layers; h->core.head_dim = hd;
     h->core.alpha = 1.0f; h->core.eps = c.norm_eps > 0.f ? c.norm_eps : 1e-5f; h->core.hook_site = 0;
     h->core.fast = c.residual_dtype != 0;
     h->core.act = c.activation;
     avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
-    if (c.activation != 1) h->core.fold = false;      // the folded epilogues know GELU only
+    if (c.activation != 1 || c.ffn_dim == 0) h->core.fold = false;      // the folded epilogues know GELU only
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     if (h->init_alarm() != AVEXHIP_OK) { delete h; return nullptr; }
     const Table tb{tensors, n_tensors};

@@ -292,7 +292,8 @@ inline std::string fmt_name(const char* pattern, int i, const char* suffix) {
 }
 
 struct CoreCfg {
-    int E = 0, F = 0, H = 0, L = 0;
+    int E = 0, F = 0, H = 0, L = 0;   // F = 0: attention-only blocks, x = LN1(x + attn(x)) (the attention probe's layers, attention_probe.py:127-130)
+    int head_dim = 64;                // 64: attention.hip (relative bias, gate, streaming); 32 / 96 / 128: attention_hd.hip (plain softmax attention)
     float alpha = 1.f, eps = 1e-5f;
     int hook_site = 0;            // 0: fc2's raw output, 1: the attention output projection's raw output
     bool fast = false;            // residual stream / pre-LN sums in the operand type
@@ -356,6 +357,7 @@ inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, con
     }
     RC(dev_f32(h, tb, fmt_name(nm.ln1, i, ".weight"), E, &ly.ln1_w));
     RC(dev_f32(h, tb, fmt_name(nm.ln1, i, ".bias"), E, &ly.ln1_b));
+    if (F == 0) return AVEXHIP_OK;         // attention-only block
     const int F1 = c.glu ? 2 * F : F;      // GLU_Linear keeps its Linear(E, 2F) under ".linear"
     RC(dev_half(h, tb, fmt_name(nm.fc1, i, c.glu ? ".linear.weight" : ".weight"), (int64_t)F1 * E, &ly.w_fc1));
     RC(dev_f32(h, tb, fmt_name(nm.fc1, i, c.glu ? ".linear.bias" : ".bias"), F1, &ly.b_fc1));
@@ -464,6 +466,12 @@ inline int tap_finish(const Tap& t, const CoreCfg& c, const CoreWs& w, const Cor
     return avx::agg_pool(w.raw, io.Bc, io.Tt, c.E, io.hook_pooled, t.out, cs);
 }
 
+inline int self_attention(HandleBase* h, const CoreCfg& c, const Layer& ly, const CoreWs& w, const CoreIo& io, hipStream_t cs) {
+    if (c.head_dim == 64)
+        return avx::attention(w.qkv, io.Bc, io.Tt, c.H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, h->dtype, cs, h->q_log2e ? 1 : 0);
+    return avx::attention_hd(w.qkv, io.Bc, io.Tt, c.H, c.head_dim, io.pad, w.ah, h->dtype, cs, h->q_log2e ? 1 : 0);
+}
+
 // fc1 (+ activation) of a prepared GemmArgs `g` (A, W, bias, fold fields set; N = F, output w.hh): plain, or the gated linear unit
 inline int ffn_hidden(HandleBase* h, const CoreCfg& c, const CoreWs& w, avx::GemmArgs& g, int M, Prof& prof, hipStream_t cs) {
     const double flops = 2.0 * (double)M * (c.glu ? 2 * c.F : c.F) * c.E;
@@ -504,7 +512,7 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         RC(avx::gemm(g, dt, cs));
         prof.end();
         prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
-        RC(avx::attention(w.qkv, Bc, Tt, H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, dt, cs, h->q_log2e ? 1 : 0));
+        RC(self_attention(h, c, ly, w, io, cs));
         prof.end();
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = c.alpha;
@@ -573,7 +581,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
     // "fold": the two LayerNorms of a layer never run as kernels.  y1 = x*alpha + attn (preh) and y2 = x1*alpha + ffn (xh) stay raw
     // in the operand type with per-row partial statistics from the epilogue that wrote them; fc1 / the next QKV read them
     // through LayerNorm-folded weights, out_proj / fc2 apply LayerNorm to their residual on the fly (GemmArgs, gemm.hip).
-    const bool fold = fast && c.fold && M >= c.fold_min_rows;      // default: any M, the same arithmetic whatever the chunking
+    const bool fold = fast && c.fold && F > 0 && M >= c.fold_min_rows;      // default: any M, the same arithmetic whatever the chunking
     const int nseg = E / 64;
     avx::GemmArgs g;
     io.final_f32 = nullptr;
@@ -588,7 +596,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         RC(avx::gemm(g, dt, cs));
         prof.end();
         prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
-        RC(avx::attention(w.qkv, Bc, Tt, H, io.bias_tab, ly.grep_w, ly.grep_b, ly.grep_a, io.pad, w.ah, dt, cs, h->q_log2e ? 1 : 0));
+        RC(self_attention(h, c, ly, w, io, cs));
         prof.end();
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.ah; g.lda = E; g.W = ly.w_o; g.ldw = E; g.M = M; g.N = E; g.K = E; g.bias = ly.b_o; g.alpha = c.alpha;
@@ -607,6 +615,22 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         RC(avx::gemm(g, dt, cs));
         prof.end();
         RC(tap_finish(tap_o, c, w, io, cs));
+        if (F == 0) {      // attention-only block: LN1 closes it
+            const bool last_a = i == L - 1;
+            float* xa = last_a ? (io.features_out ? io.features_out + io.c0 * Tt * E : x32) : (fast ? nullptr : x32);
+            prof.begin("layernorm", 0.0);
+            RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, c.eps, M, E, xa, E, last_a ? nullptr : w.xh, E, dt, cs));
+            prof.end();
+            if (last_a) {
+                io.final_f32 = xa;
+                if (io.pooled_out) {
+                    prof.begin("mean_pool", 0.0);
+                    RC(avx::mean_pool(xa, Bc, Tt, E, nullptr, io.pooled_out + io.c0 * E, cs));
+                    prof.end();
+                }
+            }
+            continue;
+        }
         if (fold) {
             prof.begin("ln_rowstats", 0.0);
             RC(avx::ln_rowstats(w.st1, M, nseg, c.eps, w.r1, cs));

@@ -528,6 +528,17 @@ def attention(qkv: torch.Tensor, B: int, T: int, H: int, bias_tab: Optional[torc
     return out
 
 
+def attention_hd(qkv: torch.Tensor, B: int, T: int, H: int, head_dim: int, key_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Plain multi-head self-attention on half ``[B*T, 3*H*head_dim]`` rows (q | k | v) for head widths 32 / 64 / 96 / 128: what
+    ``torch.nn.MultiheadAttention`` computes inside the reference's sequence probes.  ``key_pad``: ``[B, T]`` uint8, 1 = padded key."""
+    _need_cuda(qkv)
+    code = _capi.F16 if qkv.dtype == torch.float16 else _capi.BF16
+    qkv = qkv.contiguous()
+    out = torch.empty((B * T, H * head_dim), dtype=qkv.dtype, device=qkv.device)
+    check(lib().avexhip_attention_hd(_ptr(qkv), B, T, H, head_dim, _ptr(key_pad), _ptr(out), code, _stream()), "attention_hd")
+    return out
+
+
 def posconv_pack(g: torch.Tensor, v: torch.Tensor, groups: int, half_dtype="f16") -> torch.Tensor:
     _need_cuda(g, v)
     code = dtype_code(half_dtype)

@@ -216,6 +216,60 @@ class _DeviceProbe(nn.Module):
     def _p(self, name: str) -> torch.Tensor:
         return self.get_buffer(name)
 
+    # -- the encoders' half-precision layer kernels (avexhip_stack_*) for the sequence probes' attention layers --
+    @staticmethod
+    def _stack_ok(d: int, heads: int, ffn: int) -> bool:
+        """Shapes the layer-stack handle takes: head width 32 / 64 / 96 / 128, widths multiples of 128 (``ffn`` 0 = attention-only
+        blocks).  ``AVEX_AMD_PROBE_PRECISION=fp32`` keeps the fp32 composition."""
+        import os
+        return (os.environ.get("AVEX_AMD_PROBE_PRECISION", "half") != "fp32" and d % heads == 0 and d // heads in (32, 64, 96, 128)
+                and d % 128 == 0 and ffn % 128 == 0)
+
+    def _stack_table(self) -> dict:                                 # avexhip_stack's parameter name -> this module's buffer name
+        raise NotImplementedError
+
+    def _stack_forward(self, h: torch.Tensor, padding_mask: Optional[torch.Tensor], heads: int, layers: int, ffn: int) -> torch.Tensor:
+        """``layers`` post-LN blocks on f16 operands with fp32 accumulation (the transformer probe's default width, 768 / 12 heads / 4
+        layers: 4.6 ms per 256 x 496 tokens instead of 46 ms on the fp32 kernels; logits within 1e-3 of them)."""
+        import ctypes as C
+        from . import _capi
+        names = self._stack_table()
+        version = tuple(self.get_buffer(n)._version for n in names.values()) + (str(h.device),)
+        if getattr(self, "_stack", None) is None or self._stack_version != version:
+            self._stack_close()
+            cfg = _capi.StackConfig()
+            cfg.embed_dim, cfg.num_heads, cfg.num_layers, cfg.ffn_dim = h.shape[-1], heads, layers, ffn
+            cfg.norm_eps, cfg.activation, cfg.operand_dtype, cfg.max_chunk_clips, cfg.residual_dtype = 1e-5, 3, _capi.F16, 0, 1
+            table = {k: self.get_buffer(n).detach().to(device=h.device, dtype=torch.float32).contiguous() for k, n in names.items()}
+            arr, n, keep = K.tensor_table(table)
+            self._stack = _capi.lib().avexhip_stack_create(C.byref(cfg), arr, n)
+            del keep
+            if not self._stack:
+                raise _capi.AvexHipError(f"stack_create failed: {_capi.last_error()}")
+            self._stack_version = version
+        B, T, D = h.shape
+        need = int(_capi.lib().avexhip_stack_workspace_bytes(self._stack, B, T))
+        ws = getattr(self, "_stack_ws", None)
+        if ws is None or ws.numel() < need or ws.device != h.device:
+            self._stack_ws = ws = torch.empty((need,), dtype=torch.uint8, device=h.device)
+        pad = None if padding_mask is None else padding_mask.to(device=h.device, dtype=torch.uint8).contiguous()
+        out = torch.empty_like(h)
+        _capi.check(_capi.lib().avexhip_stack_forward(self._stack, K._ptr(h), B, T, K._ptr(pad), K._ptr(out), None, K._ptr(ws), ws.numel(), K._stream()),
+                    "stack_forward")
+        return out
+
+    def _stack_close(self) -> None:
+        if getattr(self, "_stack", None):
+            from . import _capi
+            _capi.lib().avexhip_stack_destroy(self._stack)
+        self._stack = None
+
+    def __del__(self) -> None:
+        try:
+            self._stack_close()
+        except Exception:  # noqa: BLE001
+            pass
+
 
 class LinearProbe(_DeviceProbe):
     """linear_probe.py:16-68: ``classifier = Linear(inferred_dim, num_classes)`` on the combined embedding."""
@@ -316,6 +370,9 @@ class AttentionProbe(_DeviceProbe):
             h = h + self.pos_encoding[:, :T]
         if padding_mask is not None and padding_mask.shape[1] != T:   # attention_probe.py:124-125
             padding_mask = None
+        if self._stack_ok(D, self.num_heads, 0):
+            h = self._stack_forward(h.contiguous(), padding_mask, self.num_heads, self.num_layers, 0)
+            return K.dense_f32(K.mean_pool(h), self._p("classifier.weight"), self._p("classifier.bias"))
         for i in range(self.num_layers):
             qkv = K.dense_f32(h, self._p(f"attention_layers.{i}.in_proj_weight"), self._p(f"attention_layers.{i}.in_proj_bias"))
             att = K.mha_f32(qkv, self.num_heads, padding_mask)
@@ -324,6 +381,15 @@ class AttentionProbe(_DeviceProbe):
                             want_f32=True, want_half=False)[0].reshape(B, T, D)
         pooled = K.mean_pool(h)
         return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))
+
+    def _stack_table(self) -> dict:
+        t = {}
+        for i in range(self.num_layers):
+            for leaf in ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias"):
+                t[f"layers.{i}.self_attn." + leaf.replace("in_proj_", "in_proj.")] = f"attention_layers.{i}.{leaf}"
+            for leaf in ("weight", "bias"):
+                t[f"layers.{i}.norm1.{leaf}"] = f"layer_norms.{i}.{leaf}"
+        return t
 
 
 class TransformerProbe(_DeviceProbe):
@@ -382,8 +448,8 @@ class TransformerProbe(_DeviceProbe):
             h = h + self.pos_encoding[:, :T]
         if padding_mask is not None and padding_mask.shape[1] != T:   # transformer_probe.py:109-110
             padding_mask = None
-        if self._stack_ok(D):
-            h = self._stack_forward(h.contiguous(), padding_mask)
+        if self._stack_ok(D, self.num_heads, self.attention_dim):
+            h = self._stack_forward(h.contiguous(), padding_mask, self.num_heads, self.num_layers, self.attention_dim)
             if padding_mask is not None:
                 h = h * (~padding_mask.to(device=h.device, dtype=torch.bool)).unsqueeze(-1).to(h.dtype)
             return K.dense_f32(K.mean_pool(h.contiguous()), self._p("classifier.weight"), self._p("classifier.bias"))
@@ -401,56 +467,9 @@ class TransformerProbe(_DeviceProbe):
         pooled = K.mean_pool(h.contiguous())
         return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))
 
-
-    # -- the encoder's half-precision layer kernels (avexhip_stack_*) for the shapes they take: head_dim 64, widths multiples of 128 --
-    def _stack_ok(self, d: int) -> bool:
-        import os
-        return (os.environ.get("AVEX_AMD_PROBE_PRECISION", "half") != "fp32" and d == 64 * self.num_heads and d % 128 == 0
-                and self.attention_dim % 128 == 0)
-
-    def _stack_forward(self, h: torch.Tensor, padding_mask: Optional[torch.Tensor]) -> torch.Tensor:
-        """The ``nn.TransformerEncoder`` part on f16 operands with fp32 accumulation (the probe's default width, 768 / 12 heads / 4 layers:
-        4.6 ms per 256 x 496 tokens instead of 46 ms on the fp32 kernels; logits within 1e-3 of them).  ``AVEX_AMD_PROBE_PRECISION=fp32``
-        keeps the fp32 composition."""
-        import ctypes as C
-        from . import _capi
-        names = [n for n, _ in self.named_buffers() if n.startswith("transformer.layers.")]
-        version = tuple(self.get_buffer(n)._version for n in names) + (str(h.device),)
-        if getattr(self, "_stack", None) is None or self._stack_version != version:
-            self._stack_close()
-            cfg = _capi.StackConfig()
-            cfg.embed_dim, cfg.num_heads, cfg.num_layers, cfg.ffn_dim = h.shape[-1], self.num_heads, self.num_layers, self.attention_dim
-            cfg.norm_eps, cfg.activation, cfg.operand_dtype, cfg.max_chunk_clips, cfg.residual_dtype = 1e-5, 3, _capi.F16, 0, 1
-            table = {n[len("transformer."):].replace("in_proj_weight", "in_proj.weight").replace("in_proj_bias", "in_proj.bias"):
-                     self.get_buffer(n).detach().to(device=h.device, dtype=torch.float32).contiguous() for n in names}
-            arr, n, keep = K.tensor_table(table)
-            self._stack = _capi.lib().avexhip_stack_create(C.byref(cfg), arr, n)
-            del keep
-            if not self._stack:
-                raise _capi.AvexHipError(f"stack_create failed: {_capi.last_error()}")
-            self._stack_version = version
-        B, T, D = h.shape
-        need = int(_capi.lib().avexhip_stack_workspace_bytes(self._stack, B, T))
-        ws = getattr(self, "_stack_ws", None)
-        if ws is None or ws.numel() < need or ws.device != h.device:
-            self._stack_ws = ws = torch.empty((need,), dtype=torch.uint8, device=h.device)
-        pad = None if padding_mask is None else padding_mask.to(device=h.device, dtype=torch.uint8).contiguous()
-        out = torch.empty_like(h)
-        _capi.check(_capi.lib().avexhip_stack_forward(self._stack, K._ptr(h), B, T, K._ptr(pad), K._ptr(out), None, K._ptr(ws), ws.numel(), K._stream()),
-                    "stack_forward")
-        return out
-
-    def _stack_close(self) -> None:
-        if getattr(self, "_stack", None):
-            from . import _capi
-            _capi.lib().avexhip_stack_destroy(self._stack)
-        self._stack = None
-
-    def __del__(self) -> None:
-        try:
-            self._stack_close()
-        except Exception:  # noqa: BLE001
-            pass
+    def _stack_table(self) -> dict:
+        return {n[len("transformer."):].replace("in_proj_weight", "in_proj.weight").replace("in_proj_bias", "in_proj.bias"): n
+                for n, _ in self.named_buffers() if n.startswith("transformer.layers.")}
 
 
 class LSTMProbe(_DeviceProbe):

@@ -291,6 +291,12 @@ int avexhip_attention(const void* qkv_dev, int B, int T, int H, const float* bia
                       const float* grep_w, const float* grep_b, const float* grep_a,
                       const uint8_t* key_pad, void* out_dev, int dtype, void* stream);
 
+/* Plain multi-head self-attention for the other head widths (32, 96, 128; 64 too): softmax(q k^T / sqrt(head_dim) [+ -inf on padded
+ * keys]) v, what torch.nn.MultiheadAttention computes inside the reference's sequence probes (attention_probe.py:60-70: 768 / 8 heads;
+ * transformer_probe.py:66-75).  Same qkv / key_pad / out layout as avexhip_attention with head h at columns h*head_dim of each third. */
+int avexhip_attention_hd(const void* qkv_dev, int B, int T, int H, int head_dim, const uint8_t* key_pad, void* out_dev, int dtype,
+                         void* stream);
+
 /* Convolutional positional embedding (backbone.py:52-68,172-174): grouped Conv1d(E,E,k=128,
  * pad=64,groups=16) + drop-last + GELU, fused with the residual add:
  *   out[b,t,:] = x[b,t,:] + gelu(conv(x_half)[b,t,:] + bias)     (x = x_f32 if given, else x_half;
@@ -454,15 +460,17 @@ int avexhip_beats_last_profile(const avexhip_beats* h, const char* const** names
  * precision kernels of the encoders (f16 / bf16 operands, fp32 accumulate: 1e-3 of the fp32 module, ten times its speed).
  * Weight table keys: layers.{i}.self_attn.in_proj.{weight,bias} (PyTorch's in_proj_weight / in_proj_bias under these names),
  * layers.{i}.self_attn.out_proj.*, layers.{i}.norm1.*, layers.{i}.linear1.*, layers.{i}.linear2.*, layers.{i}.norm2.*.
- * head_dim 64, widths multiples of 128.  x [B, T, E] fp32; key_pad [B, T] (1 = masked key) or NULL; features_out [B, T, E] fp32
- * (the last norm2) and / or pooled_out [B, E] (its plain mean over the T rows).
+ * Head width embed_dim / num_heads = 32, 64, 96 or 128 (the probe configs the reference ships use 8 heads of 96), widths multiples of
+ * 128.  ffn_dim = 0: attention-only blocks x = norm1(x + attn(x)) -- the AttentionProbe's layers (attention_probe.py:60-70, 127-130),
+ * whose parameters go under the same layers.{i}.self_attn.* / layers.{i}.norm1.* names.  x [B, T, E] fp32; key_pad [B, T] (1 = masked
+ * key) or NULL; features_out [B, T, E] fp32 (the last norm) and / or pooled_out [B, E] (its plain mean over the T rows).
  * ------------------------------------------------------------------------------------------ */
 typedef struct avexhip_stack avexhip_stack;
 typedef struct {
     int32_t embed_dim;        /* 768 */
-    int32_t num_heads;        /* 12 (head_dim 64) */
+    int32_t num_heads;        /* 12 (head width 64) */
     int32_t num_layers;       /* 4 */
-    int32_t ffn_dim;          /* dim_feedforward (the probe's attention_dim: 768) */
+    int32_t ffn_dim;          /* dim_feedforward (the probe's attention_dim: 768); 0 = no feed-forward half */
     float   norm_eps;         /* 1e-5 */
     int32_t activation;       /* avexhip_gemm_args.gelu code of the feed-forward: 3 ReLU (PyTorch's default), 1 erf GELU */
     int32_t operand_dtype;
@@ -489,7 +497,7 @@ int avexhip_stack_overflow_count(avexhip_stack* h, uint32_t* events, void* sync_
 typedef struct avexhip_eat avexhip_eat;
 typedef struct {
     int32_t embed_dim;        /* 768 */
-    int32_t num_heads;        /* 12 (head_dim 64) */
+    int32_t num_heads;        /* 12 (head width 64) */
     int32_t depth;            /* 12 */
     int32_t ffn_dim;          /* 3072 */
     int32_t patch_size;       /* 16 */

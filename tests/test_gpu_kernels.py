@@ -393,6 +393,50 @@ def test_attention(built_lib, dtype, T, variant, monkeypatch):
     assert rel_l2(out.float().cpu().numpy(), ref) < tol
 
 
+def _plain_attention_ref(qkv, B, T, H, D, key_pad=None):
+    E = H * D
+    q, k, v = [qkv[:, i * E:(i + 1) * E].reshape(B, T, H, D).transpose(0, 2, 1, 3).astype(np.float64) for i in range(3)]
+    s = q @ k.transpose(0, 1, 3, 2) / np.sqrt(D)
+    if key_pad is not None:
+        s = np.where(key_pad[:, None, None, :], -np.inf, s)
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    o = (e / e.sum(-1, keepdims=True)) @ v
+    return o.transpose(0, 2, 1, 3).reshape(B * T, E)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D,H", [(96, 8), (32, 4), (128, 3), (64, 5)])
+@pytest.mark.parametrize("T", [496, 37, 128, 300, 513, 1])
+def test_attention_other_head_widths(built_lib, dtype, D, H, T):
+    """attention_hd.hip (the sequence probes' torch.nn.MultiheadAttention: 8 heads of 96 in the shipped configs) against fp64 on the same
+    rounded operands: chunk boundaries (128 keys), partial key tiles, more than one query block, a key padding mask."""
+    from avex_amd import kernels as K
+    B = 3
+    qkv = round_half(synth.normal(f"qkvhd{T}{D}", (B * T, 3 * H * D), 1.0), dtype)
+    tol = 1.5e-3 if dtype == "f16" else 1.2e-2
+    plain = K.attention_hd(_dev(qkv, _tdt(dtype)), B, T, H, D).float().cpu().numpy()
+    assert rel_l2(plain, _plain_attention_ref(qkv, B, T, H, D)) < tol
+    if T > 1:
+        pad = np.zeros((B, T), bool); pad[1, T // 2:] = True; pad[2, :min(3, T - 1)] = True
+        out = K.attention_hd(_dev(qkv, _tdt(dtype)), B, T, H, D, key_pad=_dev(pad.astype(np.uint8), torch.uint8))
+        assert rel_l2(out.float().cpu().numpy(), _plain_attention_ref(qkv, B, T, H, D, key_pad=pad)) < tol
+    if D == 64:      # the encoders' kernel without a bias table computes the same thing
+        enc = K.attention(_dev(qkv, _tdt(dtype)), B, T, H, None, None, None, None)
+        assert rel_l2(plain, enc.float().cpu().numpy()) < tol
+
+
+def test_attention_other_head_widths_large_logits(built_lib):
+    """Scores far outside the softmax's comfortable range (|s| ~ 300) and one dominating key per row: no overflow, no NaN."""
+    from avex_amd import kernels as K
+    B, T, H, D = 2, 260, 2, 96
+    qkv = round_half(synth.normal("qkvhdbig", (B * T, 3 * H * D), 1.0), "f16")
+    qkv[:, :2 * H * D] *= 6.0
+    qkv = round_half(qkv, "f16")
+    out = K.attention_hd(_dev(qkv, torch.float16), B, T, H, D).float().cpu().numpy()
+    assert np.isfinite(out).all() and rel_l2(out, _plain_attention_ref(qkv, B, T, H, D)) < 3e-3
+
+
 def test_attention_key_padding_and_plain_bias(built_lib):
     from avex_amd import kernels as K
     B, H, T = 2, 12, 96

@@ -68,7 +68,18 @@ def test_mha_f32(built_lib, B, T, E, H):
         assert rel_l2(out.cpu().numpy(), ref.numpy()) < 3e-6
 
 
-def test_probes_match_reference_goldens(built_lib, golden_dir):
+HALF_BAR = 3e-3      # the sequence probes' attention layers on f16 operands (avexhip_stack_*) against the fp32 reference
+
+
+def _fp32_and_half(monkeypatch, call):
+    """call() on the fp32 kernels (AVEX_AMD_PROBE_PRECISION=fp32: the reference's own precision) and on the default path."""
+    monkeypatch.setenv("AVEX_AMD_PROBE_PRECISION", "fp32")
+    exact = call().cpu().numpy()
+    monkeypatch.delenv("AVEX_AMD_PROBE_PRECISION")
+    return exact, call().cpu().numpy()
+
+
+def test_probes_match_reference_goldens(built_lib, golden_dir, monkeypatch):
     from avex_amd import probes as P
     g = np.load(f"{golden_dir}/probes.npz")
     embs = [torch.from_numpy(e).cuda() for e in g["embs"]]
@@ -86,7 +97,9 @@ def test_probes_match_reference_goldens(built_lib, golden_dir):
     att = P.AttentionProbe(None, [], 37, feature_mode=True, input_dim=[(24, 128)] * 3, aggregation="none", num_heads=4, num_layers=2,
                            dropout_rate=0.0, max_sequence_length=64, use_positional_encoding=True)
     att.load_state_dict(_sd(g, "att"))
-    assert rel_l2(att(seqs).cpu().numpy(), g["att.logits"]) < 1e-5
+    exact, half = _fp32_and_half(monkeypatch, lambda: att(seqs))
+    assert rel_l2(exact, g["att.logits"]) < 1e-5
+    assert att._stack is not None and rel_l2(half, g["att.logits"]) < HALF_BAR      # 4 heads of 32: the half-precision layer kernels
 
 
 @pytest.fixture(scope="module")
@@ -98,7 +111,7 @@ def beats_model(built_lib, tmp_path_factory):
     return avex_amd.load_model("esp_aves2_sl_beats_all", device="cuda", checkpoint_path=str(path), return_features_only=True).eval()
 
 
-def test_probe_with_base_model(built_lib, beats_model):
+def test_probe_with_base_model(built_lib, beats_model, monkeypatch):
     """The online-probing shape: the BEATs model mirror as base_model, hooks on three layers, logits without leaving the device;
     checked against the probe oracle applied to the same device embeddings."""
     from avex_amd import probes as P
@@ -120,16 +133,17 @@ def test_probe_with_base_model(built_lib, beats_model):
         sd = {k: (torch.randn(v.shape, generator=gen) * (0.5 if v.dim() == 1 else v.shape[-1] ** -0.5)) for k, v in att.state_dict().items()
               if not k.startswith("base_model.")}
         att.load_state_dict({k: v.cuda() for k, v in sd.items()}, strict=False)
-        logits = att(wav)
+        exact, half = _fp32_and_half(monkeypatch, lambda: att(wav))
         taps = beats_model.extract_embeddings(wav, aggregation="none")
         assert isinstance(taps, list) and len(taps) == len(layers)
         ref = PO.attention_probe([t.cpu().numpy() for t in taps], {k: v.numpy() for k, v in sd.items()}, num_heads=8)
-        assert rel_l2(logits.cpu().numpy(), ref) < 1e-5
+        assert rel_l2(exact, ref) < 1e-5
+        assert att._stack is not None and rel_l2(half, ref) < HALF_BAR      # 8 heads of 96
     finally:
         beats_model.deregister_all_hooks()
 
 
-def test_attention_probe_padding_mask(built_lib, golden_dir):
+def test_attention_probe_padding_mask(built_lib, golden_dir, monkeypatch):
     """key_padding_mask path of the attention probe (attention_probe.py:124-128): a mask of the sequence length masks keys, a mask of any
     other length is dropped; against the oracle on the golden weights."""
     from avex_amd import probes as P
@@ -141,14 +155,14 @@ def test_attention_probe_padding_mask(built_lib, golden_dir):
     sd = {k[7:]: g[k] for k in g.files if k.startswith("att.sd.")}
     pad = np.zeros((3, 24), bool); pad[1, 15:] = True; pad[2, :3] = True
     ref = PO.attention_probe(list(g["seqs"]), sd, num_heads=4, key_pad=pad)
-    out = att(seqs, padding_mask=torch.from_numpy(pad).cuda())
-    assert rel_l2(out.cpu().numpy(), ref) < 1e-5
-    assert rel_l2(out.cpu().numpy(), g["att.logits"]) > 1e-3                       # the mask changed something
-    dropped = att(seqs, padding_mask=torch.zeros(3, 160000, dtype=torch.bool).cuda())   # sample-level mask: ignored, as in the reference
-    assert rel_l2(dropped.cpu().numpy(), g["att.logits"]) < 1e-5
+    out, half = _fp32_and_half(monkeypatch, lambda: att(seqs, padding_mask=torch.from_numpy(pad).cuda()))
+    assert rel_l2(out, ref) < 1e-5 and rel_l2(half, ref) < HALF_BAR
+    assert rel_l2(out, g["att.logits"]) > 1e-2 and rel_l2(half, g["att.logits"]) > 1e-2      # the mask changed something
+    dropped, dropped_half = _fp32_and_half(monkeypatch, lambda: att(seqs, padding_mask=torch.zeros(3, 160000, dtype=torch.bool).cuda()))
+    assert rel_l2(dropped, g["att.logits"]) < 1e-5 and rel_l2(dropped_half, g["att.logits"]) < HALF_BAR   # sample-level mask: ignored, as in the reference
 
 
-def test_projectors_and_interpolation_match_reference(built_lib, golden_dir):
+def test_projectors_and_interpolation_match_reference(built_lib, golden_dir, monkeypatch):
     """Embedding projectors (base_probes.py:254-289,333-367) and the linear resampling of longer taps to the shortest sequence
     (:398-411) on the device against the reference's own probe classes (probes_proj.npz)."""
     from avex_amd import probes as P
@@ -164,8 +178,8 @@ def test_projectors_and_interpolation_match_reference(built_lib, golden_dir):
     seqs = [torch.from_numpy(g[f"att.seq{i}"]).cuda() for i in range(4)]
     comb = att._combine(seqs)
     assert comb.shape == (3, 24, 128) and rel_l2(comb.cpu().numpy(), g["att.combined"]) < 5e-6
-    out = att({f"l{i}": s for i, s in enumerate(seqs)})
-    assert rel_l2(out.cpu().numpy(), g["att.logits"]) < 2e-5
+    out, half = _fp32_and_half(monkeypatch, lambda: att({f"l{i}": s for i, s in enumerate(seqs)}))
+    assert rel_l2(out, g["att.logits"]) < 2e-5 and rel_l2(half, g["att.logits"]) < HALF_BAR
     # the resampling kernel alone against torch's own interpolate, up- and down-sampling, odd ratios
     for tin, tout in ((40, 24), (31, 24), (24, 40), (7, 7), (100, 1), (3, 17)):
         x = torch.from_numpy(synth.normal(f"itp{tin}", (2, tin, 96), 1.0))
@@ -238,22 +252,27 @@ def test_lstm_probe_shipped_config_shape(built_lib):
     assert rel_l2(pr(x.cuda()).cpu().numpy(), ref) < 2e-5
 
 
-def test_transformer_probe_shipped_config_shape(built_lib):
+def test_transformer_probe_shipped_config_shape(built_lib, monkeypatch):
     """The transformer probe as the reference's evaluation configs build it behind BEATs (768 channels, 8 heads -> head_dim 96, feed-forward
-    128, one layer, no positions): head_dim 96 keeps it on the fp32 kernels; against the oracle, with a key padding mask."""
+    128, one layer, no positions): heads of 96 run on attention_hd.hip inside the layer-stack handle; both precisions against the oracle,
+    with a key padding mask."""
     from avex_amd import probes as P
     cfg = dict(probe_type="transformer", target_layers=["last_layer"], aggregation="none", input_processing="sequence", num_heads=8, attention_dim=128,
                num_layers=1, max_sequence_length=1200, use_positional_encoding=False, dropout_rate=0.3)
     pr = P.build_probe_from_config(cfg, num_classes=11, device="cuda", input_dim=(100, 768))
-    assert pr.num_heads == 8 and not pr._stack_ok(768)
+    assert pr.num_heads == 8 and pr._stack_ok(768, 8, 128)
     gen = torch.Generator().manual_seed(18)
     sd = {k: (torch.randn(v.shape, generator=gen) * (0.3 if v.dim() == 1 else v.shape[-1] ** -0.5)) for k, v in pr.state_dict().items()}
     pr.load_state_dict(sd)
     x = torch.randn(3, 100, 768, generator=gen)
     pad = torch.zeros(3, 100, dtype=torch.bool); pad[0, 70:] = True
     npsd = {k: v.numpy() for k, v in sd.items()}
-    assert rel_l2(pr(x.cuda()).cpu().numpy(), PO.transformer_probe(x.numpy(), npsd, num_heads=8)) < 1e-5
-    assert rel_l2(pr(x.cuda(), padding_mask=pad.cuda()).cpu().numpy(), PO.transformer_probe(x.numpy(), npsd, num_heads=8, key_pad=pad.numpy())) < 1e-5
+    exact, half = _fp32_and_half(monkeypatch, lambda: pr(x.cuda()))
+    ref = PO.transformer_probe(x.numpy(), npsd, num_heads=8)
+    assert rel_l2(exact, ref) < 1e-5 and pr._stack is not None and rel_l2(half, ref) < HALF_BAR
+    exact, half = _fp32_and_half(monkeypatch, lambda: pr(x.cuda(), padding_mask=pad.cuda()))
+    ref_pad = PO.transformer_probe(x.numpy(), npsd, num_heads=8, key_pad=pad.numpy())
+    assert rel_l2(exact, ref_pad) < 1e-5 and rel_l2(half, ref_pad) < HALF_BAR and rel_l2(ref_pad, ref) > 1e-3
 
 
 def test_transformer_probe_half_precision_stack(built_lib, monkeypatch):
