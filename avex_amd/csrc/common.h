@@ -325,6 +325,8 @@ int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const flo
                    hipStream_t s);
 // q_log2e != 0: the Q columns of qkv already carry log2(e) (folded into W_q / b_q in fp32 by the handles); the kernel then scales by the
 // exact 1/8 only and feeds the gate with weights divided by log2(e)
+// avx::gemm's choice for a plain product (variant 0, no folded LayerNorm, no pooled tap): the 256-tile streaming kernel (true) or the 128-tile one
+bool gemm_streams(int M, int N);
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
               hipStream_t s, int q_log2e = 0);

@@ -1079,7 +1079,12 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         variant = 5;
     }
     if (variant == 0) { static const char* fv = getenv("AVEX_AMD_GEMM_VARIANT"); if (fv) variant = atoi(fv); }
-    if (variant == 0) variant = (a.N % T2 == 0 && a.M >= 1024) ? 5 : 3;
+    if (variant == 0) {
+        // the 256-tile streaming kernel wants enough tiles to occupy the chip: from about half a tile per CU it wins (K = 768 -> N = 2304 at
+        // 3 968 rows, 144 tiles: 26 us against 41), below that the 128-tile kernel does -- four times the tiles, split-K for long contractions
+        // (K = 3072 -> N = 768 at 3 968 rows, 48 tiles: 44 us against 66; scripts/gemm_midsize.py, profiles/r03r_midsize.txt)
+        variant = avx::gemm_streams(a.M, a.N) ? 5 : 3;
+    }
     if (variant == 2) variant = 5;
     if (variant == 5 && (a.K < 2 * BK || a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
     if (variant == 5) {
@@ -1140,6 +1145,12 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 namespace avx {
+
+bool gemm_streams(int M, int N) {
+    static const int min_tiles = getenv("AVEX_AMD_GEMM_256_MIN_TILES") ? atoi(getenv("AVEX_AMD_GEMM_256_MIN_TILES")) : 128;
+    const int t256 = ((M + T2 - 1) / T2) * (N / T2);
+    return N % T2 == 0 && M >= 1024 && t256 >= min_tiles;
+}
 
 int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     AVX_REQUIRE(a.A && a.W, "gemm: A and W must be non-null");

@@ -298,7 +298,7 @@ struct CoreCfg {
     int hook_site = 0;            // 0: fc2's raw output, 1: the attention output projection's raw output
     bool fast = false;            // residual stream / pre-LN sums in the operand type
     bool fold = false;            // fast mode: the LayerNorms between the GEMMs folded into their epilogues (post-LN, GELU / SiLU FFN only)
-    int fold_min_rows = 0;        // ... for chunks of at least this many token rows (default 1024; AVEX_AMD_LN_FOLD=1: 0 = always, so that a
+    int fold_min_rows = 0;        // ... for chunks of at least this many token rows (default 4096; AVEX_AMD_LN_FOLD=1: 0 = always, so that a
                                   // clip's result never depends on the batch it came in)
     int act = 1;                  // GemmArgs::gelu code of the FFN activation (0 none, 1 erf GELU, 2 SiLU, 3 ReLU, 4 tanh GELU, 5 tanh)
     bool glu = false;             // fc1 is the reference's GLU_Linear(E, F, "swish"): one Linear to 2F, then value * swish(gate) (backbone.py:296-297)
@@ -307,15 +307,16 @@ struct CoreCfg {
 };
 
 // AVEX_AMD_LN_FOLD, read when a handle is created.  Unset / "auto": the encoder's LayerNorms are folded into the GEMMs around them (dims
-// permitting) for chunks of >= 1024 token rows; smaller chunks run LayerNorm kernels.  Below that size the fold's 256-tile streaming kernel
-// has a handful of tiles for 256 CUs and the 128-tile kernel is quicker (one 10 s clip: 2.17 -> 1.70 ms, profiles/r03d_small_batch.txt).
+// permitting) for chunks of >= 4096 token rows; smaller chunks run LayerNorm kernels.  Below that size the fold's 256-tile streaming kernel
+// has a handful of tiles for 256 CUs and the 128-tile kernel (split-K for fc2) is quicker: one 10 s clip 2.17 -> 1.40 ms, four clips
+// 2.22 -> 1.66, eight 2.28 -> 2.00; from sixteen clips on (7 936 rows) the fold is level or ahead (profiles/r03r_midsize.txt).
 // "1": fold whatever the size -- a clip's embedding is then bit-identical whether it came alone or in a batch of 256 (with "auto" the two
 // differ in their last bits, both inside the parity bar).  "0": never fold.
 inline void fold_policy(bool fast, int E, int F, bool* fold, int* min_rows) {
     const char* e = getenv("AVEX_AMD_LN_FOLD");
     const bool is_auto = !e || e[0] == 'a' || e[0] == 'A';
     *fold = fast && E % 256 == 0 && F % 256 == 0 && !(e && !is_auto && atoi(e) == 0);
-    int rows = 1024;
+    int rows = 4096;
     if (e && is_auto) { const char* c = strchr(e, ':'); if (c && atoi(c + 1) > 0) rows = atoi(c + 1); }      // "auto:4096": another threshold (experiments)
     *min_rows = is_auto ? rows : 0;
 }
@@ -453,7 +454,10 @@ inline Tap tap_begin(const CoreCfg& c, const CoreWs& w, const CoreIo& io, int la
     t.out = io.hook_out[io.hook_bit0 + layer] + io.c0 * per_clip;
     static const bool no_fuse = getenv("AVEX_AMD_POOL_FUSE") && atoi(getenv("AVEX_AMD_POOL_FUSE")) == 0;
     // io.hook_pooled: 1 mean, 2 max, 3 first token over a clip's rows (extract_embeddings' aggregations, beats_model.py:403-417)
-    t.fused = io.hook_pooled && io.Tt >= 64 && c.E % 256 == 0 && g.K >= 128 && !no_fuse;
+    // ... where that kernel is the one the product takes anyway (a folded LayerNorm, or enough tiles): a pooled tap must not change which
+    // kernel computes the layer, or its max / first-token values would differ in their last bits from the same reduction of the full tap
+    const bool streams = g.ln_rows || g.lnr_y || g.stats_out || avx::gemm_streams(g.M, g.N);
+    t.fused = io.hook_pooled && io.Tt >= 64 && c.E % 256 == 0 && g.K >= 128 && streams && !no_fuse;
     if (t.fused) {
         g.pool_T = io.Tt; g.pool_mode = io.hook_pooled - 1;
         g.pool_part = io.hook_pooled == 3 ? t.out : w.pool;      // the first rows go straight to the caller's [B, E]

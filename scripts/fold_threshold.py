@@ -9,7 +9,7 @@ from avex_amd import synth, kernels as K
 cfg = synth.BEATS_BASE_CFG
 sd = synth.beats_state_dict(cfg, seed=0)
 print("batch: " + "  ".join(f"{b:7d}" for b in (1, 2, 4, 8, 16, 32, 64)))
-for thr in ("1", "auto:1024", "auto:2048", "auto:4096", "auto:8192", "auto:16384", "auto:32768"):
+for thr in (sys.argv[1:] or ("1", "auto:1024", "auto:2048", "auto:4096", "auto:8192", "auto:16384", "auto:32768")):
     os.environ["AVEX_AMD_LN_FOLD"] = thr
     enc = K.BeatsEncoder(cfg, sd, operand_dtype="f16", residual="half")
     row = []
@@ -19,5 +19,5 @@ for thr in ("1", "auto:1024", "auto:2048", "auto:4096", "auto:8192", "auto:16384
         torch.cuda.synchronize(); t0 = time.perf_counter(); n = 30
         for _ in range(n): enc.forward(wav, want_features=False, want_pooled=True)
         torch.cuda.synchronize(); row.append((time.perf_counter() - t0) / n * 1e3)
-    print(f"{thr:11s}: " + "  ".join(f"{t:7.3f}" for t in row) + "  ms per call")
+    print(f"{thr:11s} min_tiles {os.environ.get('AVEX_AMD_GEMM_256_MIN_TILES', '0'):>4s}: " + "  ".join(f"{t:7.3f}" for t in row) + "  ms per call")
     enc.close()

@@ -110,14 +110,19 @@ def test_eat_model_on_gpu(built_lib, tmp_path):
     assert out.shape == (2, 513, 768) and torch.isfinite(out).all()
 
 
-def test_config_c3_full_size(built_lib):
+def test_config_c3_full_size(built_lib, monkeypatch):
     """BASELINE config C3 at its real size (512 clips x 5 s): finite, and clips are independent -- rows of the big batch equal the
-    same clips run in a batch of 3 (bit-identical: every kernel treats clips separately and the GEMMs accumulate in the same order)."""
+    same clips run in a batch of 3.  Default policy: the small batch runs LayerNorm kernels + the 128-tile GEMM, the big one the folded
+    streaming kernel (other roundings of the same arithmetic); with the fold at every size the two take the same kernels."""
     from avex_amd.eat_encoder import EatEncoder
-    enc = EatEncoder(synth.EAT_BASE_CFG, synth.eat_state_dict(), operand_dtype="f16")
     wav = torch.from_numpy(synth.noise_clips(512, 80000, seed=16)).cuda()
-    full = enc.forward(wav, want_features=False, pooling="mean")["pooled"]
-    assert full.shape == (512, 768) and torch.isfinite(full).all()
     rows = [0, 300, 511]
-    small = enc.forward(wav[rows].contiguous(), want_features=False, pooling="mean")["pooled"]
-    assert rel_l2(small.cpu().numpy(), full[rows].cpu().numpy()) < 2e-5
+    for fold, bar in ((None, 5e-4), ("1", 2e-5)):
+        if fold:
+            monkeypatch.setenv("AVEX_AMD_LN_FOLD", fold)
+        enc = EatEncoder(synth.EAT_BASE_CFG, synth.eat_state_dict(), operand_dtype="f16")
+        full = enc.forward(wav, want_features=False, pooling="mean")["pooled"]
+        assert full.shape == (512, 768) and torch.isfinite(full).all()
+        small = enc.forward(wav[rows].contiguous(), want_features=False, pooling="mean")["pooled"]
+        assert rel_l2(small.cpu().numpy(), full[rows].cpu().numpy()) < bar, fold
+        del enc
