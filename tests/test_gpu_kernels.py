@@ -223,6 +223,30 @@ def test_gemm_split_k(built_lib, dtype, M, N, Kd):
     assert torch.equal(r8b["f32"], r8["f32"])          # partials are added in split order: reproducible
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", [(496, 768, 768), (496, 2304, 768), (130, 128, 64), (130, 128, 128), (700, 256, 192), (496, 768, 256),
+                                    (1984, 768, 768), (496, 768, 3072)])
+def test_gemm_lds_dma_equals_register_staging(built_lib, dtype, M, N, Kd):
+    """The 128-tile kernel's LDS-DMA form (variant 3: what few-tile products take) and its register-staged form (variant 1) build the same
+    LDS image and issue the same MFMAs in the same order: bit-identical, for one to 48 K-steps and partial row tiles; split-K against fp64.
+    (A four-stage LDS pipeline for launches of fewer workgroups than CUs was tried here and measured level -- 24.5 against 22.4 us for one
+    clip's out_proj: such launches are bound by dispatch, not by load latency -- and dropped.)"""
+    from avex_amd import kernels as K
+    td = _tdt(dtype)
+    a = _dev(round_half(synth.normal(f"dpA{M}{Kd}", (M, Kd), 1.0), dtype), td)
+    w = _dev(round_half(synth.normal(f"dpW{N}{Kd}", (N, Kd), 0.05), dtype), td)
+    bias = _dev(synth.normal("dpb", (N,), 0.3))
+    kw = dict(bias=bias, out_f32=True, out_half=True)
+    r1 = K.gemm(a, w, variant=1, **kw)
+    r3 = K.gemm(a, w, variant=3, **kw)
+    assert torch.equal(r3["f32"], r1["f32"]) and torch.equal(r3["half"], r1["half"])
+    want = (a.double() @ w.double().T + bias.double()).cpu().numpy()
+    assert rel_l2(r3["f32"].cpu().numpy(), want) < 1e-5
+    if Kd >= 1024:
+        rs = K.gemm(a, w, variant=3, splitk=True, **kw)
+        assert rel_l2(rs["f32"].cpu().numpy(), want) < 1e-5
+
+
 def test_gemm_pooled_tap_refuses_short_clips(built_lib):
     from avex_amd import kernels as K
     from avex_amd._capi import AvexHipError
