@@ -169,11 +169,7 @@ __global__ __launch_bounds__(512) void attention_hd_kernel(const T* __restrict__
 
 template <typename T, int D>
 int launch_hd(const void* qkv, int B, int Tn, int H, const uint8_t* key_pad, void* out, int q_log2e, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        AVX_HIP_CHECK(hipFuncSetAttribute((const void*)attention_hd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, hd_lds<D>()));
-        attr_set = true;
-    }
+    AVX_ENSURE_LDS((attention_hd_kernel<T, D>), hd_lds<D>());      // per device, behind a mutex (api.cpp)
     const int nqb = (Tn + 255) / 256;
     const float sscale = (q_log2e ? 1.0f : 1.4426950408889634f) / sqrtf((float)D);
     hipLaunchKernelGGL((attention_hd_kernel<T, D>), dim3((unsigned)((int64_t)B * H * nqb)), dim3(512), hd_lds<D>(), s, (const T*)qkv, Tn, H, nqb, key_pad,

@@ -593,7 +593,8 @@ extern "C" int avexhip_aves_forward(avexhip_aves* h, const float* wav, int B, in
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = cur; g.lda = (int64_t)h->cs[l] * CC; g.W = h->wc[l]; g.ldw = (int64_t)h->ck[l] * CC; g.M = Bc * P[l]; g.N = CC; g.K = h->ck[l] * CC;
             g.bias = h->zero_bias; g.gelu = 1; g.out_half = out; g.ldh = CC;
-            prof.begin("gemm.conv", 2.0 * Bc * F[l] * (double)CC * h->ck[l] * CC);
+            static const char* const conv_names[8] = {"gemm.conv0", "gemm.conv1", "gemm.conv2", "gemm.conv3", "gemm.conv4", "gemm.conv5", "gemm.conv6", "gemm.conv7"};
+            prof.begin(conv_names[l & 7], 2.0 * Bc * F[l] * (double)CC * h->ck[l] * CC);
             RC(avx::gemm(g, dt, s));
             AVX_HIP_CHECK(hipMemsetAsync(out + (size_t)Bc * P[l] * CC * 2, 0, (size_t)SLACK * CC * 2, s));
             prof.end();

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised checks of the GEMM (every kernel variant and epilogue the model uses, ragged M, forced small grids) and of the attention
-kernels (random token counts on both sides of 512, heads, key padding, bias on / off, gate on / off) against fp64 / NumPy.
+kernels (random token counts on both sides of 512, heads, key padding, bias on / off, gate on / off; the plain attention for heads of
+32 / 64 / 96 / 128) against fp64 / NumPy.
     python tests/tools/fuzz_kernels.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +18,7 @@ def rnd_half(x, dt):
     t = torch.from_numpy(x).to(torch.float16 if dt == "f16" else torch.bfloat16)
     return t.float().numpy(), t
 
-worst = {"gemm": 0.0, "attention": 0.0}
+worst = {"gemm": 0.0, "attention": 0.0, "attention_hd": 0.0}
 for c in range(cases):
     dt = ["f16", "bf16"][int(rng.integers(0, 4) == 0)]
     # ---------------- GEMM ----------------
@@ -134,7 +135,27 @@ for c in range(cases):
     refo = (p @ v).transpose(0, 2, 1, 3).reshape(B * T, E)
     ea = rel(out, refo) / (2e-3 if dt == "f16" else 1.2e-2)
     worst["attention"] = max(worst["attention"], ea)
-    print(msg + f" | attention T={T} H={H} B={B} bias={int(use_bias)} gate={int(use_gate)} pad={int(use_pad)} err/tol {ea:.2f}", flush=True)
-    if not (e < 1 and ea < 1 and np.isfinite(out).all()):
+    # ---------------- attention for the other head widths (attention_hd.hip: the sequence probes' nn.MultiheadAttention) ----------------
+    D = int(rng.choice([32, 64, 96, 128])); Th = int(rng.choice([rng.integers(1, 130), rng.integers(130, 700)])); Hh = int(rng.integers(1, 6))
+    qkvh, qhd = rnd_half(rng.standard_normal((B * Th, 3 * Hh * D)).astype(np.float32), dt)
+    padh = None
+    if use_pad:
+        padh = np.zeros((B, Th), bool)
+        for b in range(B):
+            padh[b, int(rng.integers(1, Th + 1)):] = True
+    outh = K.attention_hd(qhd.cuda(), B, Th, Hh, D, key_pad=dev(padh.astype(np.uint8)) if padh is not None else None).float().cpu().numpy()
+    xh = qkvh.reshape(B, Th, 3, Hh, D).astype(np.float64)
+    qh, kh, vh = xh[:, :, 0].transpose(0, 2, 1, 3), xh[:, :, 1].transpose(0, 2, 1, 3), xh[:, :, 2].transpose(0, 2, 1, 3)
+    sh = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(D)
+    if padh is not None:
+        sh = np.where(padh[:, None, None, :], -np.inf, sh)
+    sh = sh - sh.max(-1, keepdims=True)
+    ph = np.exp(sh); ph /= ph.sum(-1, keepdims=True)
+    refh = (ph @ vh).transpose(0, 2, 1, 3).reshape(B * Th, Hh * D)
+    eh = rel(outh, refh) / (2e-3 if dt == "f16" else 1.2e-2)
+    worst["attention_hd"] = max(worst["attention_hd"], eh)
+    print(msg + f" | attention T={T} H={H} B={B} bias={int(use_bias)} gate={int(use_gate)} pad={int(use_pad)} err/tol {ea:.2f}"
+          + f" | attention_hd T={Th} H={Hh} D={D} err/tol {eh:.2f}", flush=True)
+    if not (e < 1 and ea < 1 and eh < 1 and np.isfinite(out).all() and np.isfinite(outh).all()):
         print("VIOLATION"); sys.exit(1)
 print(f"{cases} cases, worst error / tolerance: {worst}")
