@@ -130,6 +130,7 @@ SYMBOLS = {
     "avexhip_stack_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
     "avexhip_stack_overflow_count": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, C.c_int]),
     "avexhip_lstm_layer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
+    "avexhip_lstm_layer_pair": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "avexhip_clip_mean": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P]),
     "avexhip_fbank_forward_padded": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P]),
     "avexhip_fbank_forward_patches": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, C.c_int, _P, C.c_int, _P]),

@@ -11,13 +11,21 @@
 // the quarter k in [q H / KS, (q + 1) H / KS) of h_{t-1} W_hh^T for hidden unit j's four gates (rows i, f, g, o of W_hh -- read TRANSPOSED,
 // w_hhT [H][4H], so that the threads of a wave read consecutive addresses; h_{t-1} from LDS as broadcasts); the partial sums meet in LDS, and
 // thread (q, j) finishes clip r = q (+ KS, ...) of the workgroup: adds the KS partials in order, applies the cell (its c stays in a register),
-// writes h_t to LDS and to out[b][t][..].  fp32 throughout; W_hh (1 MB at H = 256) streams from L2 every step, which is what bounds a step:
-// sixteen waves per CU keep four times the loads in flight of the one-thread-per-unit form (11 -> 6 ms per layer at 256 clips x 496 steps x 256 units).
-constexpr int LR = 4;
-template <int KS>
+// writes h_t to LDS and to out[b][t][..].  fp32 throughout.  A step is bound by W_hh (1 MB at H = 256) streaming from L2 into ONE CU -- 6.8 us
+// at 64 bytes per clock -- plus the workgroup's multiply-adds (another 6.8 us at four clips): sixteen waves per CU keep the stream busy
+// (11 -> 6 ms per layer at 256 clips x 496 steps x 256 units), fewer clips per workgroup where CUs are free cut the arithmetic (12 -> 10 us
+// per step), and the two directions of a bidirectional layer run side by side (gridDim.y = 2).  Measured level: unrolling the K loop 8 x,
+// asking for the step's xg values before the contraction (kept).  What would halve the step again is a W_hh that does not stream (half
+// precision weights split between LDS and registers, or the hidden units split over CUs with a per-step exchange): not built.
+#ifndef LSTM_UNROLL
+#define LSTM_UNROLL 8      // K-steps whose W_hh loads are in flight together (a step is bound by the latency of that stream, not its bytes)
+#endif
+template <int KS, int LR>
 __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restrict__ xg, const float* __restrict__ w_hhT, int B, int T, int H, int reverse,
-                                                           float* __restrict__ out, int64_t ldo) {
+                                                           float* __restrict__ out, int64_t ldo, const float* __restrict__ xg_rev,
+                                                           const float* __restrict__ w_hhT_rev, float* __restrict__ out_rev) {
     extern __shared__ float lds[];                 // [LR][H] h_{t-1}, then [KS][LR][4][H] partial gate sums
+    if (blockIdx.y) { xg = xg_rev; w_hhT = w_hhT_rev; out = out_rev; reverse = 1; }      // gridDim.y = 2: both directions of a bidirectional layer side by side
     float* hs = lds;
     float* part = lds + LR * H;
     const int j = threadIdx.x % H, q = threadIdx.x / H;
@@ -31,9 +39,22 @@ __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restric
     __syncthreads();
     for (int s = 0; s < T; ++s) {
         const int t = reverse ? T - 1 - s : s;
+        // the input half of this step's gates for the clips this thread finishes: asked for now, wanted after the contraction
+        float gin[(LR + KS - 1) / KS][4];
+#pragma unroll
+        for (int ci = 0; ci < (LR + KS - 1) / KS; ++ci) {
+            const int r = q + ci * KS;
+            if (r < LR) {
+                const int b = b0 + r < B ? b0 + r : B - 1;
+                const float* gx = xg + ((int64_t)b * T + t) * 4 * H + j;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gin[ci][g] = gx[g * H];
+            }
+        }
         float acc[LR][4];
 #pragma unroll
         for (int r = 0; r < LR; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; acc[r][2] = 0.f; acc[r][3] = 0.f; }
+#pragma unroll LSTM_UNROLL
         for (int k = k0; k < k1; ++k) {
             const float* wr = w_hhT + (int64_t)k * 4 * H + j;
             const float w0 = wr[0], w1 = wr[H], w2 = wr[2 * H], w3 = wr[3 * H];
@@ -49,14 +70,14 @@ __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) part[((q * LR + r) * 4 + g) * H + j] = acc[r][g];
         __syncthreads();                           // partial sums complete; every thread has finished reading h_{t-1}
-        int ci = 0;
-        for (int r = q; r < LR; r += KS, ++ci) {
-            const int b = b0 + r < B ? b0 + r : B - 1;
-            const float* gx = xg + ((int64_t)b * T + t) * 4 * H + j;
+#pragma unroll
+        for (int ci = 0; ci < (LR + KS - 1) / KS; ++ci) {
+            const int r = q + ci * KS;
+            if (r >= LR) break;
             float gsum[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v = gx[g * H];
+                float v = gin[ci][g];
                 for (int qq = 0; qq < KS; ++qq) v += part[((qq * LR + r) * 4 + g) * H + j];
                 gsum[g] = v;
             }
@@ -71,29 +92,53 @@ __global__ __launch_bounds__(1024) void lstm_layer_kernel(const float* __restric
     }
 }
 
+template <int KS, int LR>
+static int lstm_launch_t(const float* xg, const float* w_hhT, int B, int T, int H, int reverse, float* out, int64_t ldo, const float* xg_rev,
+                         const float* w_hhT_rev, float* out_rev, hipStream_t s) {
+    const dim3 grid((B + LR - 1) / LR, xg_rev ? 2 : 1);
+    const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)KS * LR * 4 * H);
+    AVX_ENSURE_LDS((lstm_layer_kernel<KS, LR>), 96 * 1024);
+    lstm_layer_kernel<KS, LR><<<grid, dim3(KS * H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo, xg_rev, w_hhT_rev, out_rev);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+
+// Clips per workgroup: a step costs a workgroup its share of the multiply-adds (LR x 4H x H on the vector ALUs: 6.8 us at LR = 4, H = 256)
+// plus the W_hh stream (1 MB from L2, the same whatever LR), so fewer clips per workgroup shorten the step for as long as there are CUs for
+// the extra workgroups: 4 clips when that already fills the chip, else 2, else 1 (AVEX_AMD_LSTM_LR overrides, for experiments).
+static int lstm_launch(const float* xg, const float* w_hhT, int B, int T, int H, int reverse, float* out, int64_t ldo, const float* xg_rev,
+                       const float* w_hhT_rev, float* out_rev, hipStream_t s) {
+    int n_cu = 256;
+    { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
+    static const int lr_env = getenv("AVEX_AMD_LSTM_LR") ? atoi(getenv("AVEX_AMD_LSTM_LR")) : 0;
+    const int dirs = xg_rev ? 2 : 1;
+    int lr = 4;
+    while (lr > 1 && ((B + lr / 2 - 1) / (lr / 2)) * dirs <= n_cu) lr >>= 1;
+    if (lr_env == 1 || lr_env == 2 || lr_env == 4) lr = lr_env;
+#define AVX_LSTM(KS)                                                                                                              \
+    (lr == 4 ? lstm_launch_t<KS, 4>(xg, w_hhT, B, T, H, reverse, out, ldo, xg_rev, w_hhT_rev, out_rev, s)                         \
+             : lr == 2 ? lstm_launch_t<KS, 2>(xg, w_hhT, B, T, H, reverse, out, ldo, xg_rev, w_hhT_rev, out_rev, s)               \
+                       : lstm_launch_t<KS, 1>(xg, w_hhT, B, T, H, reverse, out, ldo, xg_rev, w_hhT_rev, out_rev, s))
+    if (H <= 256) return AVX_LSTM(4);
+    if (H <= 341) return AVX_LSTM(3);      // (the reference's shipped configs: 300 units)
+    if (H <= 512) return AVX_LSTM(2);
+    return AVX_LSTM(1);
+#undef AVX_LSTM
+}
+
 extern "C" int avexhip_lstm_layer(const float* xg, const float* w_hhT, int B, int T, int H, int reverse, float* out, int64_t ldo, void* stream) {
     AVX_REQUIRE(xg && w_hhT && out && B >= 0 && T >= 1, "lstm_layer: bad arguments");
     AVX_REQUIRE(H >= 1 && H <= 1024 && ldo >= H, "lstm_layer: hidden size %d (1 .. 1024)", H);      // any width: the reference's max(hidden, max_sequence_length / 4) gives 300 for its shipped configs
     if (B == 0) return AVEXHIP_OK;
-    const dim3 grid((B + LR - 1) / LR);
-    hipStream_t s = (hipStream_t)stream;
-    if (H <= 256) {
-        const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)4 * LR * 4 * H);
-        AVX_ENSURE_LDS(lstm_layer_kernel<4>, 96 * 1024);
-        lstm_layer_kernel<4><<<grid, dim3(4 * H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo);
-    } else if (H <= 341) {      // (the reference's shipped configs: 300 units)
-        const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)3 * LR * 4 * H);
-        AVX_ENSURE_LDS(lstm_layer_kernel<3>, 96 * 1024);
-        lstm_layer_kernel<3><<<grid, dim3(3 * H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo);
-    } else if (H <= 512) {
-        const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)2 * LR * 4 * H);
-        AVX_ENSURE_LDS(lstm_layer_kernel<2>, 96 * 1024);
-        lstm_layer_kernel<2><<<grid, dim3(2 * H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo);
-    } else {
-        const size_t lds = sizeof(float) * ((size_t)LR * H + (size_t)1 * LR * 4 * H);
-        AVX_ENSURE_LDS(lstm_layer_kernel<1>, 96 * 1024);
-        lstm_layer_kernel<1><<<grid, dim3(H), lds, s>>>(xg, w_hhT, B, T, H, reverse, out, ldo);
-    }
-    AVX_LAUNCH_CHECK();
-    return AVEXHIP_OK;
+    return lstm_launch(xg, w_hhT, B, T, H, reverse, out, ldo, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// Both directions of a bidirectional layer in one launch (twice the workgroups, side by side on the chip: the two recurrences are independent
+// and each leaves three quarters of the CUs idle at 256 clips).  Forward: xg / w_hhT -> out; backward: xg_rev / w_hhT_rev -> out_rev.
+extern "C" int avexhip_lstm_layer_pair(const float* xg, const float* w_hhT, const float* xg_rev, const float* w_hhT_rev, int B, int T, int H,
+                                       float* out, float* out_rev, int64_t ldo, void* stream) {
+    AVX_REQUIRE(xg && w_hhT && xg_rev && w_hhT_rev && out && out_rev && B >= 0 && T >= 1, "lstm_layer_pair: bad arguments");
+    AVX_REQUIRE(H >= 1 && H <= 1024 && ldo >= H, "lstm_layer_pair: hidden size %d (1 .. 1024)", H);
+    if (B == 0) return AVEXHIP_OK;
+    return lstm_launch(xg, w_hhT, B, T, H, 0, out, ldo, xg_rev, w_hhT_rev, out_rev, (hipStream_t)stream);
 }

@@ -354,6 +354,20 @@ def lstm_layer(xg: torch.Tensor, w_hh_t: torch.Tensor, out: torch.Tensor, col: i
     check(lib().avexhip_lstm_layer(_ptr(xg), _ptr(w_hh_t), B, T, H, int(bool(reverse)), int(out.data_ptr()) + 4 * col, out.shape[2], _stream()), "lstm_layer")
 
 
+def lstm_layer_pair(xg: torch.Tensor, w_hh_t: torch.Tensor, xg_rev: torch.Tensor, w_hh_t_rev: torch.Tensor, out: torch.Tensor) -> None:
+    """Both directions of a bidirectional ``nn.LSTM`` layer in one launch: forward -> ``out[:, :, :H]``, backward -> ``out[:, :, H:2H]``
+    (``out [B, T, 2H]`` contiguous).  Same arithmetic as two :func:`lstm_layer` calls."""
+    _need_cuda(xg, w_hh_t, xg_rev, w_hh_t_rev, out)
+    B, T, G = xg.shape
+    H = G // 4
+    ok = (xg_rev.shape == xg.shape and w_hh_t.shape == (H, 4 * H) and w_hh_t_rev.shape == (H, 4 * H) and out.shape == (B, T, 2 * H)
+          and all(t.is_contiguous() and t.dtype == torch.float32 for t in (xg, xg_rev, w_hh_t, w_hh_t_rev, out)))
+    if not ok:
+        raise ValueError("lstm_layer_pair: shapes")
+    check(lib().avexhip_lstm_layer_pair(_ptr(xg), _ptr(w_hh_t), _ptr(xg_rev), _ptr(w_hh_t_rev), B, T, H, _ptr(out), int(out.data_ptr()) + 4 * H,
+                                        2 * H, _stream()), "lstm_layer_pair")
+
+
 def mha_f32(qkv: torch.Tensor, num_heads: int, key_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention core of ``nn.MultiheadAttention`` (eval, self attention): ``qkv [B, T, 3E]`` -> ``[B, T, E]``."""
     _need_cuda(qkv)

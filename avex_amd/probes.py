@@ -521,10 +521,15 @@ class LSTMProbe(_DeviceProbe):
         hs, dirs = self.hidden, (2 if self.bidirectional else 1)
         for layer in range(self.num_layers):
             out = torch.empty((B, T, hs * dirs), dtype=torch.float32, device=h.device)
-            for di, suffix in enumerate(("", "_reverse")[:dirs]):
+            xgs, whs = [], []
+            for suffix in ("", "_reverse")[:dirs]:
                 k = f"l{layer}{suffix}"
-                xg = K.dense_f32(h.contiguous(), self._p(f"lstm.weight_ih_{k}"), self._p(f"lstm.bias_ih_{k}") + self._p(f"lstm.bias_hh_{k}"))
-                K.lstm_layer(xg, self._p(f"lstm.weight_hh_{k}").t().contiguous(), out, col=di * hs, reverse=bool(di))
+                xgs.append(K.dense_f32(h.contiguous(), self._p(f"lstm.weight_ih_{k}"), self._p(f"lstm.bias_ih_{k}") + self._p(f"lstm.bias_hh_{k}")))
+                whs.append(self._p(f"lstm.weight_hh_{k}").t().contiguous())
+            if dirs == 2:      # the two recurrences are independent: one launch, side by side on the chip
+                K.lstm_layer_pair(xgs[0], whs[0], xgs[1], whs[1], out)
+            else:
+                K.lstm_layer(xgs[0], whs[0], out)
             h = out
         pooled = K.mean_pool(h)
         return K.dense_f32(pooled, self._p("classifier.weight"), self._p("classifier.bias"))

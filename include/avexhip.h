@@ -203,6 +203,10 @@ int avexhip_mha_f32(const float* qkv_dev, int B, int T, int E, int H, const uint
  * (gate order i, f, g, o), w_hhT [H, 4H] = W_hh transposed, out[b, t, 0..H) at row stride ldo (2H with a column offset for the
  * reverse direction of a bidirectional layer), reverse != 0 walks t = T-1 .. 0.  1 <= H <= 1024; fp32. */
 int avexhip_lstm_layer(const float* xg_dev, const float* w_hhT_dev, int B, int T, int H, int reverse, float* out_dev, int64_t ldo, void* stream);
+/* Both directions of a bidirectional layer in ONE launch (the two recurrences are independent and each fills a quarter of the chip at 256
+ * clips): forward xg / w_hhT -> out, backward xg_rev / w_hhT_rev -> out_rev (normally out + H), same ldo.  Same arithmetic as two calls. */
+int avexhip_lstm_layer_pair(const float* xg_dev, const float* w_hhT_dev, const float* xg_rev_dev, const float* w_hhT_rev_dev, int B, int T, int H,
+                            float* out_dev, float* out_rev_dev, int64_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Building blocks (exported so every kernel can be parity-tested in isolation through the ABI).

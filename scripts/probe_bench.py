@@ -29,6 +29,8 @@ probes = {
 # the shapes of the reference's shipped evaluation configs (configs/evaluation_configs/*: 8 heads, attention_dim 128, 1 layer; 128 units -> 300)
 probes["transformer, shipped config (8 heads of 96, ff 128, 1 layer)"] = P.TransformerProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none",
                                                                                              num_heads=8, attention_dim=128, num_layers=1, max_sequence_length=1200)
+probes["lstm, shipped offline config (1 layer, 300 units, bidirectional)"] = P.LSTMProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none", lstm_hidden_size=64,
+                                                                                            num_layers=1, bidirectional=True, max_sequence_length=1200)
 probes["lstm, shipped config (2 layers, 300 units)"] = P.LSTMProbe(None, [], C, feature_mode=True, input_dim=(T, D), aggregation="none", lstm_hidden_size=128,
                                                                     num_layers=2, max_sequence_length=1200)
 for name, pr in probes.items():

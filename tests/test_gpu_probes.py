@@ -228,12 +228,17 @@ def test_lstm_layer_long_sequence(built_lib, B, T, D, H):
     with torch.no_grad():
         ref, _ = lstm(x.double())
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device="cuda")
+    parts = []
     for di, sfx in enumerate(("", "_reverse")):
         w_ih, w_hh = getattr(lstm, f"weight_ih_l0{sfx}").float().cuda(), getattr(lstm, f"weight_hh_l0{sfx}").float().cuda()
         b = (getattr(lstm, f"bias_ih_l0{sfx}") + getattr(lstm, f"bias_hh_l0{sfx}")).float().cuda()
         xg = K.dense_f32(x.cuda(), w_ih, b)
         K.lstm_layer(xg, w_hh.t().contiguous(), out, col=di * H, reverse=bool(di))
+        parts.append((xg, w_hh.t().contiguous()))
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 2e-5
+    both = torch.full_like(out, float("nan"))      # both directions in one launch: the same arithmetic
+    K.lstm_layer_pair(parts[0][0], parts[0][1], parts[1][0], parts[1][1], both)
+    assert torch.equal(both, out)
 
 
 def test_lstm_probe_shipped_config_shape(built_lib):
