@@ -287,6 +287,13 @@ struct GemmArgs {
     // 128-tile LDS-DMA kernel: scratch for split-K (fp32 partial products [S][M][N]), or NULL.  With it a product of <= 64 tiles and
     // K >= 1024 is split S <= 8 ways along K and finished by splitk_epilogue_kernel (partials added in order).
     float* splitk_ws; size_t splitk_bytes;
+    // A LayerNorm of the output rows y (after bias / residual) in the same pass: the workspace path above with an epilogue kernel that owns
+    // whole rows (one wave per row, N <= 1024, N % 256 == 0, no activation): post_ln_out_* = LN(y) * post_ln_w + post_ln_b; y itself still
+    // goes to out_f32 / out_half when those are set.  post_ln_round: y is rounded to the operand type before the statistics -- what a
+    // LayerNorm kernel reading a half residual stream sees.  For the few-row products of one to eight clips, where a kernel less per
+    // LayerNorm is 13 us less (avx::gemm_post_ln_ok says whether a product qualifies).
+    const float* post_ln_w; const float* post_ln_b; float post_ln_eps; int post_ln_round;
+    float* post_ln_out_f32; int64_t post_ln_ldo; void* post_ln_out_half; int64_t post_ln_ldh;
     // sticky range alarm: the number of (lane, launch) pairs that rounded at least one |value| > 65504 to an f16 output is added
     // here (one atomic per wave at most, at the end of the kernel); NULL = not counted.  bf16 outputs cannot overflow.
     unsigned int* ovf;
@@ -327,6 +334,8 @@ int layernorm_pool(const void* in_half, int64_t ld_in, const float* w, const flo
 // exact 1/8 only and feeds the gate with weights divided by log2(e)
 // avx::gemm's choice for a plain product (variant 0, no folded LayerNorm, no pooled tap): the 256-tile streaming kernel (true) or the 128-tile one
 bool gemm_streams(int M, int N);
+// whether a product (M, N, K set; splitk_ws lent) can take GemmArgs::post_ln_*
+bool gemm_post_ln_ok(const GemmArgs& a);
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
               hipStream_t s, int q_log2e = 0);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
-    if (GLDS && gridDim.y > 1) {      // split-K: the raw partial tile
+    if (GLDS && (gridDim.y > 1 || p.post_ln_w)) {      // split-K (or a row-owning epilogue kernel behind it): the raw partial tile
         float* part = p.splitk_ws + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -222,6 +222,78 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, i
                 h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
                 *(v4*)((T*)p.out_half + (int64_t)m * p.ldh + n) = h;
             }
+        }
+    }
+    ovf_commit<T>(p.ovf, ovf_mx);
+}
+
+// ... and with a LayerNorm of the finished rows (GemmArgs::post_ln_*): one wave per row, lane l holds columns 256 c + 4 l .. + 3 of chunk c.
+// Same per-row arithmetic as layernorm_half_kernel (two-pass statistics in registers, (v - mean) * rstd * w + b).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_ln_epilogue_kernel(avx::GemmArgs p, int S) {
+    typedef typename Half<T>::v4 v4;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;                          // wave-uniform
+    const int nch = p.N >> 8;
+    f32x4 v[4];
+    float ovf_mx = 0.f, s = 0.f;
+    const bool zero_row = p.row_zero != nullptr && p.row_zero[m] != 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        v[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c >= nch) continue;
+        const int n = c * 256 + lane * 4;
+        f32x4 a = *(const f32x4*)(p.splitk_ws + (int64_t)m * p.N + n);
+        for (int sp = 1; sp < S; ++sp) a += *(const f32x4*)(p.splitk_ws + ((int64_t)sp * p.M + m) * p.N + n);
+        if (p.bias) a += *(const f32x4*)(p.bias + n);
+        if (zero_row) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.out_raw) *(f32x4*)(p.out_raw + (int64_t)m * p.ldraw + n) = a;
+        if (p.resid) {
+            const f32x4 r = *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
+            a = r * p.alpha + a;
+        } else if (p.resid_half) {
+            const v4 rh = *(const v4*)((const T*)p.resid_half + (int64_t)m * p.ldrh + n);
+            const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+            a = r * p.alpha + a;
+        }
+        if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = a;
+        if (p.out_half || p.post_ln_round) {
+            ovf_see4<T>(ovf_mx, a);
+            v4 h;
+            h[0] = Half<T>::from(a[0]); h[1] = Half<T>::from(a[1]); h[2] = Half<T>::from(a[2]); h[3] = Half<T>::from(a[3]);
+            if (p.out_half) *(v4*)((T*)p.out_half + (int64_t)m * p.ldh + n) = h;
+            if (p.post_ln_round) a = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+        v[c] = a;
+        s += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)p.N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= nch) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[c][e] -= mean; q += v[c][e] * v[c][e]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)p.N + p.post_ln_eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= nch) continue;
+        const int n = c * 256 + lane * 4;
+        const f32x4 w = *(const f32x4*)(p.post_ln_w + n), b = *(const f32x4*)(p.post_ln_b + n);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = v[c][e] * rstd * w[e] + b[e];
+        if (p.post_ln_out_f32) *(f32x4*)(p.post_ln_out_f32 + (int64_t)m * p.post_ln_ldo + n) = y;
+        if (p.post_ln_out_half) {
+            v4 h;
+            h[0] = Half<T>::from(y[0]); h[1] = Half<T>::from(y[1]); h[2] = Half<T>::from(y[2]); h[3] = Half<T>::from(y[3]);
+            *(v4*)((T*)p.post_ln_out_half + (int64_t)m * p.post_ln_ldh + n) = h;
         }
     }
     ovf_commit<T>(p.ovf, ovf_mx);
@@ -1085,6 +1157,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         // (K = 3072 -> N = 768 at 3 968 rows, 48 tiles: 44 us against 66; scripts/gemm_midsize.py, profiles/r03r_midsize.txt)
         variant = avx::gemm_streams(a.M, a.N) ? 5 : 3;
     }
+    if (a.post_ln_w) variant = 3;      // (the caller checked gemm_post_ln_ok)
     if (variant == 2) variant = 5;
     if (variant == 5 && (a.K < 2 * BK || a.N % T2 != 0 || (a.out_half && a.ldh % 8) || (a.resid_half && a.ldrh % 8))) variant = 3;
     if (variant == 5) {
@@ -1125,14 +1198,18 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     } else {
         // split-K when the caller lent a workspace and the product is few tiles of a long contraction (one clip's fc2: 24 tiles, K = 3072)
         int S = 1;
-        if (a.splitk_ws && a.K >= 1024) {
+        if (a.post_ln_w) AVX_REQUIRE(avx::gemm_post_ln_ok(a), "gemm: post_ln_* needs the 128-tile kernel's workspace path (N %% 256 == 0, N <= 1024, no activation, splitk_ws >= M N floats)");
+        if (a.splitk_ws && (a.K >= 1024 || a.post_ln_w)) {
             int n_cu = 256;
             { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
-            S = 8;      // as many splits as keep the launch within two workgroups per CU
-            while (S > 1 && (tiles * S > 2 * n_cu || a.K % (S * BK) != 0 || (size_t)S * a.M * a.N * sizeof(float) > a.splitk_bytes)) S >>= 1;
+            S = 8;      // as many splits as keep the launch within two workgroups per CU (and leave every split at least two K-steps)
+            while (S > 1 && (tiles * S > 2 * n_cu || a.K % (S * BK) != 0 || a.K / S < 2 * BK || (size_t)S * a.M * a.N * sizeof(float) > a.splitk_bytes)) S >>= 1;
         }
         hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3(tiles, S), dim3(256), lds, s, a);
-        if (S > 1) {
+        if (a.post_ln_w) {
+            AVX_LAUNCH_CHECK();
+            hipLaunchKernelGGL((splitk_ln_epilogue_kernel<T>), dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a, S);
+        } else if (S > 1) {
             AVX_LAUNCH_CHECK();
             const int64_t nthr = (int64_t)a.M * (a.N / 4);
             hipLaunchKernelGGL((splitk_epilogue_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a, S);
@@ -1152,6 +1229,14 @@ bool gemm_streams(int M, int N) {
     return N % T2 == 0 && M >= 1024 && t256 >= min_tiles;
 }
 
+bool gemm_post_ln_ok(const GemmArgs& a) {
+    const char* e = getenv("AVEX_AMD_POST_LN");      // read per call (24 per forward): tests switch it within a process
+    const bool off = e && atoi(e) == 0;
+    return !off && a.splitk_ws && a.N % 256 == 0 && a.N <= 1024 && a.K % BK == 0 && !a.gelu && !a.ln_rows && !a.lnr_y && !a.stats_out && !a.pool_part &&
+           !(a.n_store > 0 && a.n_store < a.N) && (size_t)a.M * a.N * sizeof(float) <= a.splitk_bytes && !gemm_streams(a.M, a.N) &&
+           (a.variant == 0 || a.variant == 3);
+}
+
 int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     AVX_REQUIRE(a.A && a.W, "gemm: A and W must be non-null");
     AVX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -1159,7 +1244,7 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
                 "gemm: N=%d must be a multiple of %d (64 columns: the skinny streaming kernel only, >= 32768 rows)", a.N, BN);
     AVX_REQUIRE(a.K % BK == 0 || (a.K % 32 == 0 && a.variant == 7), "gemm: K=%d must be a multiple of %d (of 32 with the skinny kernel, variant 7)", a.K, BK);
     AVX_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
-    AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw, "gemm: no output buffer");
+    AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw || (a.post_ln_w && (a.post_ln_out_f32 || a.post_ln_out_half)), "gemm: no output buffer");
     AVX_REQUIRE((!a.out_f32 || a.ldo % 4 == 0) && (!a.out_half || a.ldh % 4 == 0) &&
                     (!a.out_raw || a.ldraw % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&
                     (!a.resid_half || a.ldrh % 4 == 0),

@@ -615,6 +615,17 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         }
         Tap tap_o;
         if (c.hook_site == 1) tap_o = tap_begin(c, w, io, i, g);
+        // few rows, no fold: LayerNorm 1 rides in the split-K epilogue of the product (one kernel less per layer; x32 / xh are read as the
+        // residual and rewritten row by row by the same wave)
+        bool ln1_fused = false;
+        if (!fold && F > 0 && M <= 8192) {
+            g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes;
+            if (avx::gemm_post_ln_ok(g)) {
+                g.post_ln_w = ly.ln1_w; g.post_ln_b = ly.ln1_b; g.post_ln_eps = c.eps; g.post_ln_round = fast ? 1 : 0;
+                g.post_ln_out_f32 = fast ? nullptr : x32; g.post_ln_ldo = E; g.post_ln_out_half = w.xh; g.post_ln_ldh = E;
+                ln1_fused = true;
+            } else { g.splitk_ws = nullptr; g.splitk_bytes = 0; }
+        }
         prof.begin("gemm.out_proj", 2.0 * Md * E * E);
         RC(avx::gemm(g, dt, cs));
         prof.end();
@@ -639,7 +650,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             prof.begin("ln_rowstats", 0.0);
             RC(avx::ln_rowstats(w.st1, M, nseg, c.eps, w.r1, cs));
             prof.end();
-        } else {
+        } else if (!ln1_fused) {
             prof.begin("layernorm", 0.0);
             RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, c.eps, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));
             prof.end();
@@ -662,6 +673,19 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         }
         Tap tap_f;
         if (c.hook_site == 0) tap_f = tap_begin(c, w, io, i, g);
+        // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
+        float* xo = nullptr;
+        if (last) xo = io.features_out ? io.features_out + io.c0 * Tt * E : ((io.pooled_out || !fast) ? x32 : nullptr);
+        else if (!fast) xo = x32;
+        // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
+        const bool fused_pool = last && io.pooled_out && !io.features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
+        // few rows, no fold: LayerNorm 2 in the split-K epilogue (as LayerNorm 1 above)
+        bool ln2_fused = false;
+        if (!fold && !fused_pool && (xo || !last) && avx::gemm_post_ln_ok(g)) {
+            g.post_ln_w = ly.ln2_w; g.post_ln_b = ly.ln2_b; g.post_ln_eps = c.eps; g.post_ln_round = fast ? 1 : 0;
+            g.post_ln_out_f32 = xo; g.post_ln_ldo = E; g.post_ln_out_half = last ? nullptr : w.xh; g.post_ln_ldh = E;
+            ln2_fused = true;
+        }
         prof.begin("gemm.fc2", 2.0 * Md * E * F);
         RC(avx::gemm(g, dt, cs));
         prof.end();
@@ -671,19 +695,13 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             RC(avx::ln_rowstats(w.st2, M, nseg, c.eps, w.r2, cs));
             prof.end();
         }
-        // the last LayerNorm produces the fp32 features (caller's buffer, or scratch when only pooling)
-        float* xo = nullptr;
-        if (last) xo = io.features_out ? io.features_out + io.c0 * Tt * E : ((io.pooled_out || !fast) ? x32 : nullptr);
-        else if (!fast) xo = x32;
-        // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
-        const bool fused_pool = last && io.pooled_out && !io.features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
         if (fused_pool) {      // the pre-LayerNorm sums y2 sit in preh, with the fold in xh
             prof.begin("layernorm+mean_pool", 0.0);
             RC(avx::layernorm_pool(fold ? w.xh : preh, E, ly.ln2_w, ly.ln2_b, c.eps, Bc, Tt, E, io.pooled_out + io.c0 * E, dt, cs));
             prof.end();
         } else if (!fold) {
             prof.begin("layernorm", 0.0);
-            if (xo || !last) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, c.eps, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
+            if ((xo || !last) && !ln2_fused) RC(avx::layernorm(pre32, preh, E, ly.ln2_w, ly.ln2_b, c.eps, M, E, xo, E, last ? nullptr : w.xh, E, dt, cs));
             prof.end();
         } else if (last && xo) {   // the only LayerNorm of the layer stack that still runs: fp32 features from the raw y2
             prof.begin("layernorm", 0.0);

@@ -93,6 +93,23 @@ def test_pooled_tap_aggregations(encoder):
                     assert torch.equal(r[i], want), (samples, agg, i)
 
 
+def test_layernorm_in_split_k_epilogue(encoder, monkeypatch):
+    """Below the fold threshold the two LayerNorms of a layer ride in the split-K epilogue of out_proj / fc2 (GemmArgs::post_ln_*):
+    against the same forward with LayerNorm kernels (AVEX_AMD_POST_LN=0) -- the same arithmetic on the same rounded sums, another order
+    of the row reductions -- for one clip, three clips, a short clip, hooks and features."""
+    for B, samples in ((1, 160000), (3, 48000), (2, 8000)):
+        wav = torch.from_numpy(synth.noise_clips(B, samples, seed=31)).cuda()
+        a = encoder.forward(wav, hook_layers=[0, 6, 12], want_features=True, want_pooled=True)
+        monkeypatch.setenv("AVEX_AMD_POST_LN", "0")
+        b = encoder.forward(wav, hook_layers=[0, 6, 12], want_features=True, want_pooled=True)
+        monkeypatch.delenv("AVEX_AMD_POST_LN")
+        tol = 2e-4 if encoder.dtype_name == "f16" else 1.5e-3
+        assert rel_l2(a["pooled"].cpu().numpy(), b["pooled"].cpu().numpy()) < tol
+        assert rel_l2(a["features"].cpu().numpy(), b["features"].cpu().numpy()) < 4 * tol
+        for i in (0, 6, 12):
+            assert rel_l2(a["hooks"][i].cpu().numpy(), b["hooks"][i].cpu().numpy()) < 4 * tol
+
+
 def test_chunking_is_invisible(encoder):
     """max_chunk_clips=3 above: a batch of 7 runs as 3+3+1 and must equal per-clip runs."""
     wav = torch.from_numpy(synth.noise_clips(7, 32000, seed=11)).cuda()
