@@ -74,9 +74,11 @@ class PipelinedGather:
     next overwrites it.
     """
 
-    def __init__(self, group=None) -> None:
+    def __init__(self, group=None, force: bool = False) -> None:
         self.group = group
-        self.active = dist.is_initialized() and dist.get_world_size(group) > 1
+        # force: go through the collective with a single rank too (scripts/rccl_one_rank.py: the only way to execute the RCCL leg on a
+        # one-GPU box)
+        self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.active else 1
         self._bufs: List[Optional[torch.Tensor]] = [None, None]
         self._slot = 0
