@@ -346,7 +346,11 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             // them: the rescale pass over the expanded tensor (read + write) disappears
             static const bool no_se_fold = getenv("AVEX_AMD_SE_FOLD") && atoi(getenv("AVEX_AMD_SE_FOLD")) == 0;
             const bool skinny_proj = skinny_enabled() && skinny_dim(b.cp_exp) && pad128(b.cout) * b.cp_exp <= 32768 && (b.cp_out == 64 || b.cp_out == 128 || b.cp_out == 256);
-            const bool se_fold = skinny_proj && (!no_se_fold || hooked);      // (the skinny kernel's raw tap comes with the scale)
+            bool se_fold = skinny_proj && (!no_se_fold || hooked);      // (the skinny kernel's raw tap comes with the scale)
+            // the wider projections (K = 512 ... 1152): the register-staged form of the 128-tile kernel scales its A rows the same way
+            static const bool se_fold_wide = !(getenv("AVEX_AMD_SE_FOLD_WIDE") && atoi(getenv("AVEX_AMD_SE_FOLD_WIDE")) == 0);
+            const bool wide_fold = !skinny_proj && !no_se_fold && se_fold_wide && b.cp_exp % 64 == 0;
+            se_fold = se_fold || wide_fold;
             prof.begin("se", 0.0);
             RC(avexhip_effnet_se(w.pool, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, se_fold ? nullptr : w.act[dw], dt, s));
             prof.end();
@@ -358,6 +362,7 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
                 if (b.cp_out == 64) { g.N = 64; g.n_store = 0; }
                 if (se_fold) { g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
             }
+            if (wide_fold) { g.variant = 1; g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
             if (b.residual) { g.resid_half = w.act[in_buf]; g.ldrh = b.cp_in; }
             g.out_half = w.act[out]; g.ldh = b.cp_out;
             if (hooked) { g.out_raw = w.raw; g.ldraw = b.cp_out; }

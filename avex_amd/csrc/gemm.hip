@@ -118,23 +118,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
             rw##i = *(const uint4*)(W + (int64_t)(n0 + rloc) * p.ldw + (k0) + chunk * 8);      \
             ra##i = *(const uint4*)(A + (int64_t)arow * p.lda + (k0) + chunk * 8);             \
         }
-#define AVX_ST(i, st)                                                                          \
+        // GemmArgs::a_scale (this form only, besides the skinny kernel): the A rows pass through registers here, so the per-(clip, input
+        // channel) rescale of EfficientNet's squeeze-excitation is applied on the way (fp32 product rounded to the operand type: the
+        // arithmetic of scale_channels_kernel) instead of in a pass of its own over the expanded tensor
+#define AVX_ST(i, st, k0)                                                                      \
         {                                                                                      \
             const int c = tid + 256 * i;                                                       \
             const int rloc = c >> 3, chunk = c & 7;                                            \
             const int off = rloc * 128 + ((chunk ^ ((rloc >> 1) & 7)) << 4);                   \
+            if (p.a_scale) {                                                                   \
+                int arow = m0 + rloc;                                                          \
+                arow = arow < p.M ? arow : p.M - 1;                                            \
+                const float* sp = p.a_scale + (int64_t)(arow / p.a_scale_rows) * p.a_scale_ld + (k0) + chunk * 8; \
+                const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);              \
+                v8 x = *(v8*)&ra##i;                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                \
+                    x[e] = Half<T>::from((float)x[e] * s0[e]);                                 \
+                    x[4 + e] = Half<T>::from((float)x[4 + e] * s1[e]);                         \
+                }                                                                              \
+                ra##i = *(uint4*)&x;                                                           \
+            }                                                                                  \
             *(uint4*)(smem + (st) * (2 * TILE_BYTES) + off) = rw##i;                           \
             *(uint4*)(smem + (st) * (2 * TILE_BYTES) + TILE_BYTES + off) = ra##i;              \
         }
         AVX_LD(0, 0) AVX_LD(1, 0) AVX_LD(2, 0) AVX_LD(3, 0)
-        AVX_ST(0, 0) AVX_ST(1, 0) AVX_ST(2, 0) AVX_ST(3, 0)
+        AVX_ST(0, 0, 0) AVX_ST(1, 0, 0) AVX_ST(2, 0, 0) AVX_ST(3, 0, 0)
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
             const int k1 = (kt + 1) * BK;
             if (more) { AVX_LD(0, k1) AVX_LD(1, k1) AVX_LD(2, k1) AVX_LD(3, k1) }
             compute(kt & 1);
-            if (more) { AVX_ST(0, (kt + 1) & 1) AVX_ST(1, (kt + 1) & 1) AVX_ST(2, (kt + 1) & 1) AVX_ST(3, (kt + 1) & 1) }
+            if (more) { AVX_ST(0, (kt + 1) & 1, k1) AVX_ST(1, (kt + 1) & 1, k1) AVX_ST(2, (kt + 1) & 1, k1) AVX_ST(3, (kt + 1) & 1, k1) }
             __syncthreads();
         }
 #undef AVX_LD
@@ -1120,7 +1135,8 @@ static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
 template <typename T>
 int launch(const avx::GemmArgs& a, hipStream_t s) {
     // variant 7 / auto for long thin products: the skinny streaming kernel (W resident in LDS, A rows straight into MFMA operands)
-    AVX_REQUIRE(!a.a_scale || (a.variant == 7 && a.a_scale_rows > 0 && a.a_scale_ld >= a.K && a.a_scale_ld % 4 == 0), "gemm: a_scale is built for the skinny kernel (variant 7)");
+    AVX_REQUIRE(!a.a_scale || ((a.variant == 7 || a.variant == 1) && a.a_scale_rows > 0 && a.a_scale_ld >= a.K && a.a_scale_ld % 4 == 0),
+                "gemm: a_scale is built for the skinny kernel (variant 7) and the register-staged 128-tile kernel (variant 1)");
     if (a.variant == 7) {
         AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K in {32, 64, 96, 128, 160, 256}, N in {64, 96, 128, 160, 256} with N K <= 32768, a half output (N=%d K=%d)", a.N, a.K);
         return launch_skinny_any<T>(a, s);
