@@ -221,6 +221,32 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         // window, reflect padding (torch.stft center=True), pack
         const int64_t base = (int64_t)fa * md.hop - (md.center ? N / 2 : 0);
         bool nza = false, nzb = false;                            // an all-zero frame beside a loud partner: see fbank.hip
+        // (all but the first and last few frame pairs of a clip lie inside it: plain loads at 32-bit offsets.  The reflecting form below
+        // with its 64-bit index arithmetic per sample was 0.47 of the kernel's 1.30 ms per 256 clips)
+        const bool interior = base >= 0 && base + md.hop + N <= T && fa + 1 < frames;
+        if (interior && ((N | md.hop) & 3) == 0 && (((uintptr_t)(src + base) | (uintptr_t)md.win) & 15) == 0) {
+            // ... four samples per lane and load when everything is 16-byte aligned (hop 160, 800 points, rows of 160 000 samples: always)
+            const float* s0 = src + base;
+            const int hop = md.hop;
+            for (int n = 4 * lane; n < N; n += 256) {
+                const f32x4 w = *(const f32x4*)(md.win + n), xa = *(const f32x4*)(s0 + n), xb = *(const f32x4*)(s0 + n + hop);
+                const f32x4 za = xa * w, zb = xb * w;
+                *(f32x4*)(A + n) = (f32x4){za[0], zb[0], za[1], zb[1]};
+                *(f32x4*)(A + n + 2) = (f32x4){za[2], zb[2], za[3], zb[3]};
+                nza = nza || za[0] != 0.f || za[1] != 0.f || za[2] != 0.f || za[3] != 0.f;
+                nzb = nzb || zb[0] != 0.f || zb[1] != 0.f || zb[2] != 0.f || zb[3] != 0.f;
+            }
+        } else if (interior) {
+            const float* s0 = src + base;
+            const int hop = md.hop;
+            for (int n = lane; n < N; n += 64) {
+                const float w = md.win[n];
+                const float2 z = make_float2(s0[n] * w, s0[n + hop] * w);
+                A[n] = z;
+                nza = nza || z.x != 0.f;
+                nzb = nzb || z.y != 0.f;
+            }
+        } else
         for (int n = lane; n < N; n += 64) {
             float2 z;
 #pragma unroll
