@@ -225,8 +225,19 @@ struct avexhip_beats : avxh::HandleBase {
     float* lnE_w = nullptr; float* lnE_b = nullptr;
     std::vector<Layer> layers;
     std::vector<float> rel_table;  // host [num_buckets, H]; empty if no relative position embedding
-    std::map<int, float*> bias_tabs;       // per token count T: [H, 2T-1] Toeplitz rows; at most BIAS_TAB_CACHE entries, least recently used evicted
-    std::vector<int> bias_tab_lru;         // token counts, most recent last
+    // Toeplitz bias tables [H, 2T - 1], one per token count T, built ON THE FORWARD'S STREAM by a kernel from the resident bucket table
+    // (no host build, no hipMalloc / hipMemcpy / hipFree inside a forward: a new clip length costs one 3 us kernel).  They live in an arena
+    // allocated when the handle is created and are NEVER evicted or freed before the handle: a recorded hipGraph may hold a table's
+    // address for as long as the handle lives (round 3's LRU eviction could free a table under a graph).  When the arena is full, a
+    // forward builds its table in the caller's workspace instead (every time: nothing is remembered), so there is no limit on the
+    // number of distinct lengths either.
+    struct BiasTab { float* ptr; hipEvent_t ready; hipStream_t stream; bool done; };
+    float* d_rel_table = nullptr;          // device copy of rel_table
+    int* d_bucket_lut = nullptr;           // T5 bucket of every offset -lut_maxd .. lut_maxd (beyond: saturated), made on the host
+    int lut_maxd = 0;
+    char* bias_arena = nullptr; size_t bias_arena_bytes = 0, bias_arena_used = 0;
+    std::map<int, BiasTab> bias_tabs;
+    std::mutex bias_mu;
 
     CoreCfg core() const {
         CoreCfg c;
@@ -235,7 +246,10 @@ struct avexhip_beats : avxh::HandleBase {
         return c;
     }
     ~avexhip_beats() override {
-        for (auto& kv : bias_tabs) (void)hipFree(kv.second);
+        for (auto& kv : bias_tabs) if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
+        if (bias_arena) (void)hipFree(bias_arena);
+        if (d_rel_table) (void)hipFree(d_rel_table);
+        if (d_bucket_lut) (void)hipFree(d_bucket_lut);
         if (fb) avexhip_fbank_plan_destroy(fb);
         for (int i = 0; i < 3; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (ev_join[i]) (void)hipEventDestroy(ev_join[i]); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -323,47 +337,74 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
         }
         h->rel_table.resize((size_t)c.num_buckets * H);
         AVX_HIP_CHECK(hipMemcpy(h->rel_table.data(), t->data, sizeof(float) * h->rel_table.size(), hipMemcpyDefault));
+        // what the forwards build their bias tables from, resident: the bucket table and the bucket of every offset up to saturation
+        // (the buckets come from avexhip_rel_bucket on the host -- the function the reference's golden buckets pin -- never from a
+        // device logarithm)
+        AVX_HIP_CHECK(hipMalloc((void**)&h->d_rel_table, sizeof(float) * h->rel_table.size()));
+        AVX_HIP_CHECK(hipMemcpy(h->d_rel_table, h->rel_table.data(), sizeof(float) * h->rel_table.size(), hipMemcpyHostToDevice));
+        const int last = c.num_buckets / 2 - 1;
+        int maxd = c.max_distance > 1 ? c.max_distance : 1;
+        while (maxd < (1 << 24) && !(avexhip_rel_bucket(-maxd, c.num_buckets, c.max_distance) == last &&
+                                     avexhip_rel_bucket(maxd, c.num_buckets, c.max_distance) == c.num_buckets / 2 + last)) maxd *= 2;
+        AVX_REQUIRE(maxd < (1 << 24), "beats_create: relative position buckets do not saturate (num_buckets=%d max_distance=%d)", c.num_buckets, c.max_distance);
+        std::vector<int> lut((size_t)2 * maxd + 1);
+        for (int d = -maxd; d <= maxd; ++d) lut[(size_t)(d + maxd)] = avexhip_rel_bucket(d, c.num_buckets, c.max_distance);
+        h->lut_maxd = maxd;
+        AVX_HIP_CHECK(hipMalloc((void**)&h->d_bucket_lut, sizeof(int) * lut.size()));
+        AVX_HIP_CHECK(hipMemcpy(h->d_bucket_lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice));
+        const char* am = getenv("AVEX_AMD_BIAS_ARENA_MB");      // 0: no arena, every forward builds its table in the workspace
+        h->bias_arena_bytes = (size_t)(am ? atoi(am) : 16) << 20;
+        if (h->bias_arena_bytes) AVX_HIP_CHECK(hipMalloc((void**)&h->bias_arena, h->bias_arena_bytes));
     }
 #undef RC
     AVX_HIP_CHECK(hipDeviceSynchronize());
     return AVEXHIP_OK;
 }
 
-// [H, 2T-1] Toeplitz rows of compute_bias (backbone.py:475-492), cached per T
+// [H, 2T-1] Toeplitz rows of compute_bias (backbone.py:475-492) for a forward on stream `s`: the arena's table of this token count (built
+// on `s` the first time it is asked for), or -- arena full -- a table built into `fallback` (the caller's workspace) for this forward only.
+size_t bias_tab_bytes(const avexhip_beats* h, int T) { return h->rel_table.empty() ? 0 : sizeof(float) * (size_t)h->H * (size_t)(2 * T - 1); }
 
-// [H, 2T-1] Toeplitz rows of compute_bias (backbone.py:475-492), cached per T
-int bias_tab_for(avexhip_beats* h, int T, float** out) {
+int bias_tab_for(avexhip_beats* h, int T, hipStream_t s, float* fallback, float** out) {
     *out = nullptr;
     if (h->rel_table.empty()) return AVEXHIP_OK;
-    auto touch = [&](int t) {
-        auto& v = h->bias_tab_lru;
-        for (size_t i = 0; i < v.size(); ++i)
-            if (v[i] == t) { v.erase(v.begin() + (long)i); break; }
-        v.push_back(t);
+    std::lock_guard<std::mutex> lk(h->bias_mu);
+    auto capturing = [&]() {      // is `s` recording a graph right now?  (events of the arena's tables are not recorded into, or waited for inside, a capture)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return st == hipStreamCaptureStatusActive;
     };
     auto it = h->bias_tabs.find(T);
-    if (it != h->bias_tabs.end()) { touch(T); *out = it->second; return AVEXHIP_OK; }
-    // variable-length inference meets a new T per clip length: the cache is bounded (3 MB per entry near T = 32768).  hipFree waits for
-    // the device, so a table still read by a kernel in flight is never pulled from under it.
-    constexpr size_t BIAS_TAB_CACHE = 16;
-    while (h->bias_tabs.size() >= BIAS_TAB_CACHE && !h->bias_tab_lru.empty()) {
-        const int victim = h->bias_tab_lru.front();
-        h->bias_tab_lru.erase(h->bias_tab_lru.begin());
-        auto vit = h->bias_tabs.find(victim);
-        if (vit != h->bias_tabs.end()) { (void)hipFree(vit->second); h->bias_tabs.erase(vit); }
+    bool use_arena = true;
+    if (it != h->bias_tabs.end()) {
+        avexhip_beats::BiasTab& e = it->second;
+        // built on another stream and possibly still in flight: order this stream behind the build (once the build has completed, never again)
+        if (!e.done && e.stream != s) {
+            if (hipEventQuery(e.ready) == hipSuccess) e.done = true;
+            else {
+                (void)hipGetLastError();      // hipErrorNotReady is not an error
+                if (capturing()) use_arena = false;
+                else AVX_HIP_CHECK(hipStreamWaitEvent(s, e.ready, 0));
+            }
+        }
+        if (use_arena) { *out = e.ptr; return AVEXHIP_OK; }
     }
-    const int H = h->H, W = 2 * T - 1;
-    std::vector<float> host((size_t)H * W);
-    for (int r = 0; r < W; ++r) {
-        const int bucket = avexhip_rel_bucket(r - (T - 1), h->cfg.num_buckets, h->cfg.max_distance);
-        for (int hh = 0; hh < H; ++hh) host[(size_t)hh * W + r] = h->rel_table[(size_t)bucket * H + hh];
+    const size_t need = align_up(bias_tab_bytes(h, T));
+    if (use_arena && h->bias_arena_used + need <= h->bias_arena_bytes && !capturing()) {
+        avexhip_beats::BiasTab e{(float*)(h->bias_arena + h->bias_arena_used), nullptr, s, false};
+        AVX_HIP_CHECK(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+        const int rc = avx::bias_toeplitz(h->d_rel_table, h->d_bucket_lut, h->lut_maxd, T, h->H, e.ptr, s);
+        if (rc != AVEXHIP_OK) { (void)hipEventDestroy(e.ready); return rc; }
+        AVX_HIP_CHECK(hipEventRecord(e.ready, s));
+        h->bias_arena_used += need;
+        h->bias_tabs[T] = e;
+        *out = e.ptr;
+        return AVEXHIP_OK;
     }
-    float* d = nullptr;
-    AVX_HIP_CHECK(hipMalloc((void**)&d, sizeof(float) * host.size()));
-    AVX_HIP_CHECK(hipMemcpy(d, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
-    h->bias_tabs[T] = d;
-    touch(T);
-    *out = d;
+    AVX_REQUIRE(fallback, "beats_forward: no room for the relative position bias table (T=%d)", T);
+    const int rc = avx::bias_toeplitz(h->d_rel_table, h->d_bucket_lut, h->lut_maxd, T, h->H, fallback, s);
+    if (rc != AVEXHIP_OK) return rc;
+    *out = fallback;
     return AVEXHIP_OK;
 }
 
@@ -420,13 +461,15 @@ int forward_impl(avexhip_beats* h, const float* wav, const float* fbank_in, int 
     int chunk = 1, lanes = 1;
     plan_chunks(h, B, Tt, &chunk, &lanes);
     const Ws need = carve(h, nullptr, chunk, Tt);
-    if (!workspace || ws_bytes < need.total * (size_t)lanes) {
-        avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, need.total * (size_t)lanes);
+    const size_t ws_need = need.total * (size_t)lanes + align_up(bias_tab_bytes(h, Tt));
+    if (!workspace || ws_bytes < ws_need) {
+        avexhip_set_error("beats_forward: workspace too small (%zu bytes given, %zu needed)", ws_bytes, ws_need);
         return AVEXHIP_ERR_WORKSPACE;
     }
+    float* bias_fallback = bias_tab_bytes(h, Tt) ? (float*)((char*)workspace + need.total * (size_t)lanes) : nullptr;
     if (h->profiling || h->capturing) lanes = 1;   // per-kernel event timing needs the kernels alone on the device; a captured forward is one stream
     float* bias_tab = nullptr;
-    int rc = bias_tab_for(h, Tt, &bias_tab);
+    int rc = bias_tab_for(h, Tt, s, bias_fallback, &bias_tab);
     if (rc != AVEXHIP_OK) return rc;
     const avx::FbankDev* fbd = avexhip_fbank_plan_dev(h->fb);
     Prof prof{h, s};
@@ -670,7 +713,7 @@ extern "C" size_t avexhip_beats_workspace_bytes(const avexhip_beats* h, int B, i
     if (Tt <= 0) return 0;
     int chunk = 1, lanes = 1;
     plan_chunks(h, B, Tt, &chunk, &lanes);
-    return carve(h, nullptr, chunk, Tt).total * (size_t)lanes;
+    return carve(h, nullptr, chunk, Tt).total * (size_t)lanes + align_up(bias_tab_bytes(h, Tt));      // + room for the bias table of a length the arena has no place for
 }
 
 extern "C" int avexhip_beats_forward(avexhip_beats* h, const float* wav, int B, int64_t T, int64_t wav_stride,

@@ -310,6 +310,8 @@ int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo,
 int agg_pool(const float* in, int B, int T, int C, int mode, float* out, hipStream_t s);
 // partial statistics [M][nseg][2] (GemmArgs::stats_out) -> [M][2] (rstd, -mu * rstd), summed in segment order (deterministic)
 int ln_rowstats(const float* stats, int M, int nseg, float eps, float* rows, hipStream_t s);
+// [H, 2T - 1] Toeplitz rows of the relative position bias from the resident [buckets, H] table and the host-made bucket LUT (elementwise.hip)
+int bias_toeplitz(const float* rel_table, const int* lut, int maxd, int T, int H, float* out, hipStream_t s);
 // ga = alpha * gamma, bb = bias + alpha * beta: the column vectors a residual-side fold takes (GemmArgs::lnr_prefolded)
 int lnr_fold(const float* gamma, const float* beta, const float* bias, float alpha, int N, float* ga, float* bb, hipStream_t s);
 // exactly one of in / in_half is non-null

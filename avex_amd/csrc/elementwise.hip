@@ -463,6 +463,22 @@ __global__ __launch_bounds__(256) void agg_pool_kernel(const float* __restrict__
     out[(int64_t)b * C + c] = v;
 }
 
+
+// out[h][r] = rel_table[lut[clamp(r - (T - 1), -maxd, maxd) + maxd]][h]: the [H, 2T - 1] Toeplitz rows of the relative position bias
+// (compute_bias, backbone.py:475-492) from the resident bucket table.  `lut` holds the T5 bucket of every offset up to the distance where
+// the bucket saturates, computed ON THE HOST by avexhip_rel_bucket (the function pinned bit for bit to the reference's buckets): the
+// device never evaluates a logarithm, so the table equals the host-built one exactly.
+__global__ __launch_bounds__(256) void bias_toeplitz_kernel(const float* __restrict__ rel_table, const int* __restrict__ lut, int maxd, int T, int H,
+                                                           float* __restrict__ out) {
+    const int W = 2 * T - 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= H * W) return;
+    const int hh = idx / W, r = idx - hh * W;
+    int d = r - (T - 1);
+    d = d < -maxd ? -maxd : (d > maxd ? maxd : d);
+    out[idx] = rel_table[(size_t)lut[d + maxd] * H + hh];
+}
+
 // column vectors of a residual-side LayerNorm fold: ga = alpha * gamma, bb = bias + alpha * beta (GemmArgs::lnr_prefolded)
 __global__ __launch_bounds__(256) void lnr_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias, float alpha,
                                                         int N, float* __restrict__ ga, float* __restrict__ bb) {
@@ -475,6 +491,13 @@ __global__ __launch_bounds__(256) void lnr_fold_kernel(const float* __restrict__
 }  // namespace
 
 namespace avx {
+
+int bias_toeplitz(const float* rel_table, const int* lut, int maxd, int T, int H, float* out, hipStream_t s) {
+    const int n = H * (2 * T - 1);
+    hipLaunchKernelGGL(bias_toeplitz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rel_table, lut, maxd, T, H, out);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
 
 int lnr_fold(const float* gamma, const float* beta, const float* bias, float alpha, int N, float* ga, float* bb, hipStream_t s) {
     AVX_REQUIRE(gamma && beta && bias && ga && bb && N > 0, "lnr_fold: bad arguments");

@@ -216,6 +216,7 @@ bool parse(avexhip_flac* h, const uint8_t* d, size_t n) {
         else bs = 256 << (bs_code - 8);
         if (sr_code == 12) br.bits(8); else if (sr_code == 13 || sr_code == 14) br.bits(16); else if (sr_code == 15) return fail("invalid sample rate code");
         if (br.bad || (br.pos & 7)) return fail("truncated frame header");
+        if (bs < 1) return fail("empty block");
         const size_t hdr_bytes = br.pos >> 3;
         const uint8_t want8 = (uint8_t)br.bits(8);
         if (crc8(d + pos, hdr_bytes) != want8) return fail("frame header CRC-8 mismatch at byte " + std::to_string(pos));
@@ -253,11 +254,13 @@ bool parse(avexhip_flac* h, const uint8_t* d, size_t n) {
                 for (int t = 0; t < bs; ++t) dst[t] = sample(sbps);
             } else if (type >= 8 && type <= 12) {             // FIXED
                 order = type - 8;
+                if (order > bs) return fail("predictor order exceeds the block size");      // before the warm-up samples are written: dst holds bs values
                 sb.order = order; sb.shift = 0;
                 for (int j = 0; j < order; ++j) sb.coef[j] = FIXED_COEF[order][j];
                 for (int t = 0; t < order; ++t) dst[t] = sample(sbps);
             } else if (type >= 32) {                          // LPC
                 order = type - 31;
+                if (order > bs) return fail("predictor order exceeds the block size");      // (a one-sample block with an order-32 predictor would write 31 values past dst)
                 sb.order = order;
                 for (int t = 0; t < order; ++t) dst[t] = sample(sbps);
                 const int prec = (int)br.bits(4) + 1;
@@ -268,7 +271,6 @@ bool parse(avexhip_flac* h, const uint8_t* d, size_t n) {
             } else {
                 return fail("reserved subframe type " + std::to_string(type));
             }
-            if (order > bs) return fail("predictor order exceeds the block size");
             if (type >= 8) {                                  // residual (FIXED and LPC)
                 const int method = (int)br.bits(2);
                 if (method > 1) return fail("reserved residual coding method");

@@ -398,6 +398,36 @@ static __device__ __forceinline__ void st_out(V* ptr, const V& v, int nt) {
     if (GEMM_NT && (nt & 1)) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(__builtin_bit_cast(i32x4_st, v)) : "memory");   // s_nop 1: the hazard recogniser does not see a store in an asm block; on gfx940+/gfx950 a VMEM store of more than 64 bits followed by a VALU write of its data registers needs TWO wait states
     else *ptr = v;
 }
+// Raw-buffer access for the fast epilogues (EPI 1 / 2): the wave's 64 output rows are ONE buffer whose size ends with the last valid row,
+// so rows past M are dropped (stores) or read as zero (loads) by the hardware's bounds check -- no exec masking, no row clamp -- and an
+// address is a 32-bit lane offset (made once per tile) + a scalar offset per store instead of a 64-bit multiply-add per row.  (As
+// global_store with a per-row "m < M" the epilogue was ~30 basic blocks of 64-bit address arithmetic: v_mul_lo_u32 / v_mad_u64_u32 are
+// quarter-rate instructions.)  AUX 2 = the non-temporal hint (GEMM_NT above).
+typedef int i32x4_buf __attribute__((ext_vector_type(4)));
+typedef int i32x2_buf __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
+    // the inputs ARE wave-uniform (kernel arguments, tile and wave indices); the readfirstlanes make that provable, or every buffer
+    // instruction is wrapped in a "waterfall" loop (4 x v_readfirstlane + compares + exec juggling per store)
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+}
+// The scalar-offset operand of these instructions stays 0, and constant parts of an offset are added to the lane offset (the compiler
+// folds them into the instruction's 12-bit immediate).  With a REGISTER there, hipcc's hazard recogniser assumes that a 128-bit store
+// needs no wait states before a VALU instruction overwrites its data registers (LLVM: "this hazard only exists if the instruction is not
+// using a register in the soffset field") -- on gfx950 it does: `buffer_store_dwordx4 v[48:51], v120, s[28:31], s65 offen nt` directly
+// followed by `v_pk_mul_f32 v[48:49], ...` stored the NEW second dword for lanes 12-15 of every 16 (profiles/r04d_store_hazard.txt).
+template <int AUX, typename V>
+static __device__ __forceinline__ void buf_st16(const V& v, __amdgpu_buffer_rsrc_t r, int voff) {
+    static_assert(sizeof(V) == 16, "16-byte stores only");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_buf, v), r, voff, 0, AUX);
+}
+template <typename V>
+static __device__ __forceinline__ V buf_ld16(__amdgpu_buffer_rsrc_t r, int voff) {
+    static_assert(sizeof(V) == 16, "16-byte loads only");
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
 // AVEX_AMD_GEMM_NT: 0 no hints, 1 (default) non-temporal output stores, 5 = only for outputs wider than 768 columns (diagnostics)
 static int gemm_nt_mode(const avx::GemmArgs& a) {
     static const int mode = getenv("AVEX_AMD_GEMM_NT") ? atoi(getenv("AVEX_AMD_GEMM_NT")) : 1;
@@ -458,12 +488,16 @@ static_assert(L5_ROWS + 4096 <= 32768, "EPI 1 scratch above the stages");
 #define GEMM_XCD_WALK 0
 #endif
 
-template <typename T, int EPI, int LN>
+template <typename T, int EPI, int LN, int ACT>
 __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     static_assert(EPI >= 0 && EPI <= 2 && LN >= 0 && LN <= 3 && (EPI != 1 || LN <= 1), "epilogue selector");      // (EPI 0: LN is the pool mode)
+    // ACT (EPI 1 only): 0 none, 1 exact-erf GELU, 2 SiLU, as a template argument.  As the run-time value p.gelu it put a uniform branch around
+    // every 4-element group of the epilogue: one basic block per group, so the six dependent packed FMAs of a group's polynomial ran
+    // as a bare latency chain (profiles/r04a_epilogue_isa.txt: fc1's epilogue 7.7 us for waves 0-3 and 11 us for waves 4-7 per tile).
+    static_assert(ACT >= 0 && ACT <= 2 && (EPI == 1 || ACT == 0), "activation selector");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;      // wm also selects the stagger group (waves 4-7 lag one barrier)
@@ -659,6 +693,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             }
             constexpr int HP_LD = 72;     // halves per slab row (64 n + 8 pad = 144 B)
             T* slab = (T*)(smem + 2 * STAGE2 + wid * (16 * HP_LD * 2));
+            // this wave's 64 rows x 128 columns of the output as a raw buffer that ends with the last valid row (see buf_rsrc)
+            const int ldh = (int)p.ldh;
+            const int vrows = p.M - (em0 + wn * 64);
+            const __amdgpu_buffer_rsrc_t obuf = buf_rsrc((const T*)p.out_half + (int64_t)(em0 + wn * 64) * p.ldh + en0 + wm * 128,
+                                                         vrows > 0 ? (unsigned)(vrows < 64 ? vrows : 64) * (unsigned)ldh * 2u : 0u);
+            const int ovoff = (er * ldh + 8 * ec) * 2;
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
                 f32x4 bv[4], sv[4];
@@ -668,7 +708,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sv[i] = *(const f32x4*)(lsv + 64 * ih + 16 * i + 4 * lg);
                 }
-                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -682,7 +721,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         } else {
                             v = acc[4 * ih + i][j] + bv[i];
                         }
-                        if (p.gelu) v = act4(v, p.gelu);
+                        if constexpr (ACT == 1) v = gelu_erf4(v);
+                        else if constexpr (ACT == 2) v = silu4(v);
                         ovf_see4<T>(ovf_mx, v);
                         v4 h;
                         h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
@@ -692,9 +732,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) {
                         const int ml = 8 * ps + er;
-                        const int m = em0 + wn * 64 + 16 * j + ml;
                         const v8 h = *(const v8*)(slab + ml * HP_LD + 8 * ec);
-                        if (m < p.M && !GEMM_NOSTORE) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
+                        if (!GEMM_NOSTORE) buf_st16<GEMM_NT ? 2 : 0>(h, obuf, ovoff + (16 * j + 8 * ps) * ldh * 2 + 128 * ih);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next chunk overwrites it
                 }
@@ -707,29 +746,34 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             // The epilogue walks 8 chunks of 16 rows x 64 columns (c = 4 ih + j).  A chunk's residual vectors (and row statistics) are
             // requested three chunks ahead: all of a half up front cost 64 registers this kernel does not have once the fold's vectors are
             // there (it spilled 60), none ahead exposed the memory latency eight times per tile (8-10 us against 3.3 us).
+            // Output, residual and statistics rows are raw buffers that end with the wave's last valid row (buf_rsrc): no row clamp, no
+            // exec masks, scalar offsets.
             const T* __restrict__ resid = (const T*)(LNR ? p.lnr_y : p.resid_half);
             const int ldres = LNR ? p.ldy : (int)p.ldrh;
+            const int ldh = (int)p.ldh;
+            const int row0 = em0 + wn * 64, col0 = en0 + wm * 128;
+            int vrows = p.M - row0;
+            vrows = vrows < 0 ? 0 : (vrows < 64 ? vrows : 64);
+            const __amdgpu_buffer_rsrc_t obuf = buf_rsrc((const T*)p.out_half + (int64_t)row0 * p.ldh + col0, (unsigned)vrows * (unsigned)ldh * 2u);
+            const __amdgpu_buffer_rsrc_t rbuf = buf_rsrc(resid + (int64_t)row0 * ldres + col0, (unsigned)vrows * (unsigned)ldres * 2u);
+            const int ovoff = (er * ldh + 8 * ec) * 2, rvoff = (er * ldres + 8 * ec) * 2;
             constexpr int AHEAD = 3;
             v8 rh[8][2];
             auto request = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    int m = em0 + wn * 64 + 16 * (c & 3) + 8 * ps + er;
-                    m = m < p.M ? m : p.M - 1;
-                    rh[c][ps] = *(const v8*)(resid + (int64_t)m * ldres + en0 + wm * 128 + 64 * (c >> 2) + 8 * ec);
-                }
+                for (int ps = 0; ps < 2; ++ps) rh[c][ps] = buf_ld16<v8>(rbuf, rvoff + (16 * (c & 3) + 8 * ps) * ldres * 2 + 128 * (c >> 2));
             };
             // LNR: lane L keeps the (rstd, -mu rstd) pair of row L of the wave's 64 rows (one coalesced 512-byte read, two registers);
             // the lane that stores row r of a chunk fetches the pair from lane r with ds_bpermute (no LDS memory involved)
             float2 rsl = make_float2(0.f, 0.f);
             if (LNR) {
-                int m = em0 + wn * 64 + le;
+                int m = row0 + le;
                 m = m < p.M ? m : p.M - 1;
                 rsl = ((const float2*)p.lnr_rows)[m];
             }
             f32x4 bb[2][2], ga[2][2];
             auto columns = [&](int ih) __attribute__((always_inline)) {
-                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
+                const int nb = col0 + 64 * ih + 8 * ec;
                 const float* bsrc = LNR ? p.lnr_beta : p.bias;      // LNR: alpha * beta + bias, ready-made
                 bb[ih][0] = *(const f32x4*)(bsrc + nb);
                 bb[ih][1] = *(const f32x4*)(bsrc + nb + 4);
@@ -741,11 +785,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             asm volatile("" ::: "memory");
             float* slab = (float*)(smem + 2 * STAGE2 + wid * 4096);   // 16 rows x 64 floats, 16-byte chunk c of row r at slot c ^ r
             const float alpha = p.alpha;
+            // partial statistics [M][N / 64][2]: this wave's rows x its two 64-column segments; only the lane with ec == 0 of a row
+            // segment stores (the other lanes' offsets are out of the buffer's range)
             const int nseg_out = p.N >> 6;
+            __amdgpu_buffer_rsrc_t sbuf = obuf;
+            int svoff = 0;
+            if constexpr (STATS) {
+                sbuf = buf_rsrc(p.stats_out + ((int64_t)row0 * nseg_out + (col0 >> 6)) * 2, (unsigned)vrows * (unsigned)nseg_out * 8u);
+                svoff = ec == 0 ? er * nseg_out * 8 : 0x7ff00000;
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int ih = c >> 2, j = c & 3;
-                const int nb = en0 + wm * 128 + 64 * ih + 8 * ec;
                 if (c + AHEAD < 8) request(c + AHEAD);
                 if (c == 2) columns(1);
 #pragma unroll
@@ -755,7 +806,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
                     const int ml = 8 * ps + er;
-                    const int m = em0 + wn * 64 + 16 * j + ml;
                     const f32x4 v0 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec) ^ ml) << 4));
                     const f32x4 v1 = *(const f32x4*)((const char*)slab + ml * 256 + (((2 * ec + 1) ^ ml) << 4));
                     f32x4 o0, o1;
@@ -779,7 +829,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     v8 h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
-                    if (m < p.M) st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
+                    buf_st16<GEMM_NT ? 2 : 0>(h, obuf, ovoff + (16 * j + 8 * ps) * ldh * 2 + 128 * ih);
                     if (STATS) {
                         // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
                         // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
@@ -787,8 +837,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         float s1 = (o0[0] + o0[1]) + (o0[2] + o0[3]) + ((o1[0] + o1[1]) + (o1[2] + o1[3]));
                         float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
                         s1 = seg8_sum(s1); s2 = seg8_sum(s2);
-                        if (ec == 0 && m < p.M)
-                            *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((en0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
+                        __builtin_amdgcn_raw_buffer_store_b64((i32x2_buf){__builtin_bit_cast(int, s1), __builtin_bit_cast(int, s2)}, sbuf,
+                                                              svoff + (16 * j + 8 * ps) * nseg_out * 8 + 8 * ih, 0, 0);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -943,10 +993,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     ovf_commit<T>(p.ovf, ovf_lanes);
 }
 
-template <typename T, int EPI, int LN>
+template <typename T, int EPI, int LN, int ACT = 0>
 static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
-    AVX_ENSURE_LDS((gemm256p_kernel<T, EPI, LN>), LDS5);
-    hipLaunchKernelGGL((gemm256p_kernel<T, EPI, LN>), dim3(grid), dim3(512), LDS5, s, a5);
+    AVX_ENSURE_LDS((gemm256p_kernel<T, EPI, LN, ACT>), LDS5);
+    hipLaunchKernelGGL((gemm256p_kernel<T, EPI, LN, ACT>), dim3(grid), dim3(512), LDS5, s, a5);
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
@@ -1192,7 +1242,11 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.pool_part && !a.resid && !a.row_zero && !force_generic;
         const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out && a.gelu <= 2;      // the fast epilogue knows GELU and SiLU only
         const bool fast_resid = plain_out && (a.resid_half || a.lnr_y) && !a.gelu && !a.ln_rows;
-        if (fast_half) return a.ln_rows ? launch256<T, 1, 1>(a5, grid, s) : launch256<T, 1, 0>(a5, grid, s);
+        if (fast_half) {
+            if (a.gelu == 1) return a.ln_rows ? launch256<T, 1, 1, 1>(a5, grid, s) : launch256<T, 1, 0, 1>(a5, grid, s);
+            if (a.gelu == 2) return a.ln_rows ? launch256<T, 1, 1, 2>(a5, grid, s) : launch256<T, 1, 0, 2>(a5, grid, s);
+            return a.ln_rows ? launch256<T, 1, 1, 0>(a5, grid, s) : launch256<T, 1, 0, 0>(a5, grid, s);
+        }
         if (fast_resid) {
             if (a.lnr_y) return a.stats_out ? launch256<T, 2, 3>(a5, grid, s) : launch256<T, 2, 1>(a5, grid, s);
             return a.stats_out ? launch256<T, 2, 2>(a5, grid, s) : launch256<T, 2, 0>(a5, grid, s);

@@ -117,7 +117,7 @@ class EatEncoder:
         for i in sorted(set(int(x) for x in hook_layers)):
             if not 0 <= i < self.L:
                 raise ValueError(f"hook layer {i} out of range 0..{self.L - 1}")
-            hooks[i] = torch.empty((B, E) if hook_pooled else (B, Tt, E), dtype=torch.float32, device=dev)
+            hooks[i] = torch.empty((B, E) if K.pool_code(hook_pooled) else (B, Tt, E), dtype=torch.float32, device=dev)      # sized by the code the library gets
             ptrs[i] = int(hooks[i].data_ptr())
             mask |= 1 << i
         feats = torch.empty((B, Tt, E), dtype=torch.float32, device=dev) if want_features else None

@@ -41,23 +41,44 @@ def _stage(batch: Dict[str, Any], device: torch.device, stream: Optional["torch.
     return w, m, ev
 
 
+def _check_same_batches(batch: Dict[str, Any], tdist: Any, group: Any, device: torch.device) -> None:
+    """Sharded extraction assumes every rank iterates the same batches: compare the first batch's signature across ranks."""
+    wav = batch["raw_wav"]
+    lab = batch.get("label")
+    sig = [float(wav.shape[0]), float(wav.shape[-1]), float(wav.detach().double().abs().sum().item())]
+    if torch.is_tensor(lab):
+        sig.append(float(lab.detach().double().sum().item()))
+    backend = tdist.get_backend(group)
+    t = torch.tensor(sig, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    lo, hi = t.clone(), t.clone()
+    tdist.all_reduce(lo, op=tdist.ReduceOp.MIN, group=group)
+    tdist.all_reduce(hi, op=tdist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("extract_embeddings_in_memory(sharded=True): the ranks do not iterate the same batches (first batch differs: "
+                           f"min {lo.tolist()} max {hi.tolist()}).  Sharded extraction splits every batch over the ranks; with a "
+                           "DistributedSampler (a different batch per rank) call it with sharded=False.")
+
+
 def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]], target_layers: List[Any],
                                  device: Any, aggregation: str = "mean", disable_tqdm: bool = True,
                                  disable_layerdrop: Optional[bool] = None, prefetch: Optional[bool] = None,
-                                 sharded: Optional[bool] = None, group: Any = None
+                                 sharded: bool = False, group: Any = None
                                  ) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, List[tuple]]:
     """Run ``model.extract_embeddings`` over every batch of ``dataloader`` and stack the results on the CPU
     (reference: embedding_utils.py:26-144; ``disable_tqdm`` is accepted for signature compatibility, no progress bar here).
 
-    ``sharded`` (default: on when ``torch.distributed`` is initialised with more than one rank): every rank iterates the SAME
-    batches, embeds clips ``dist.shard_bounds(B, rank, world)`` of each and the embeddings are all-gathered in clip order
-    (``dist.PipelinedGather``: batch n's exchange under batch n + 1's forward), so every rank returns what a single device would
-    (the reference's loop is single-device, run_evaluate.py:1053)."""
+    ``sharded=True`` (opt-in; needs ``torch.distributed`` with more than one rank): every rank iterates the SAME batches, embeds clips
+    ``dist.shard_bounds(B, rank, world)`` of each and the embeddings are all-gathered in clip order (``dist.PipelinedGather``: batch
+    n's exchange under batch n + 1's forward), so every rank returns what a single device would (the
+    reference's loop is single-device, run_evaluate.py:1053).  It is NOT the default: a multi-rank caller with a
+    ``DistributedSampler`` -- the usual set-up -- hands every rank DIFFERENT batches, and sharding those would gather rows of unrelated
+    clips beside the local labels without any visible failure.  The first batch's signature (clip count, samples, a checksum of the
+    audio and of the labels) is compared across ranks and a mismatch raises ``RuntimeError``."""
     from . import dist as adist
     import torch.distributed as tdist
     world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
     rank = tdist.get_rank(group) if world > 1 else 0
-    sharded = world > 1 if sharded is None else (bool(sharded) and world > 1)
+    sharded = bool(sharded) and world > 1
     device = torch.device(device)
     if prefetch is None:
         prefetch = device.type == "cuda"
@@ -86,6 +107,8 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
             it = iter(dataloader)
             nxt = next(it, None)
             gathers: Dict[int, Any] = {}                        # position in the output list -> PipelinedGather
+            if sharded and nxt is not None:
+                _check_same_batches(nxt, tdist, group, device)
 
             def my_rows(b: Dict[str, Any]) -> Optional[Tuple[int, int]]:
                 return adist.shard_bounds(int(b["raw_wav"].shape[0]), rank, world) if sharded else None

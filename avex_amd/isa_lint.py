@@ -9,6 +9,13 @@ instruction is exact when the CU runs no matrix work.  ``op_sel:[1,0]``, ``[1,1]
 and ``v_mov_b64`` are unaffected.  hipcc's SLP vectoriser emits the bad form for complex (float2) butterflies: that was round 1's
 "fbank kernel is wrong beside a GEMM" bug.
 
+Second rule (round 4, ``profiles/r04d_store_hazard.txt``): a buffer / global store of MORE than 64 bits whose data registers a VALU
+instruction overwrites within the next two instructions.  hipcc inserts the two wait states the hardware needs -- except when the
+store's scalar-offset operand is a register (LLVM's hazard recogniser: "this hazard only exists if the instruction is not using a
+register in the soffset field").  On gfx950 it exists there too: ``buffer_store_dwordx4 v[48:51], v120, s[28:31], s65 offen nt``
+directly followed by ``v_pk_mul_f32 v[48:49], ...`` stored the new value of v49 for lanes 12-15 of every 16.  The kernels keep that
+operand 0 (``gemm.hip`` ``buf_st16``); the lint catches whatever form brings the pattern back.
+
 ``check_library()`` disassembles every gfx950 code object bundled in the shared library and fails on the form, so a compiler
 or source change cannot bring it back unnoticed (called by ``avex_amd.build`` after linking and by ``tests/test_isa_lint.py``).
 """
@@ -62,17 +69,80 @@ def disassemble(code_object: bytes) -> str:
         return r.stdout
 
 
+_WIDE_STORE = re.compile(r"^\s*(?:buffer|global|flat|scratch)_store_dwordx[34]\s+(.*)$")
+_VREG = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def _vregs(operand: str) -> set:
+    out = set()
+    for m in _VREG.finditer(operand):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def _store_data_regs(line: str) -> set:
+    """Data VGPRs of a wide store: the first operand of buffer_store (vdata, vaddr, srsrc, soffset), the second of global / flat / scratch (vaddr, vdata, saddr)."""
+    m = _WIDE_STORE.match(line)
+    if not m:
+        return set()
+    ops = [o.strip() for o in m.group(1).split(",")]
+    is_buffer = line.lstrip().startswith("buffer_")
+    return _vregs(ops[0] if is_buffer else (ops[1] if len(ops) > 1 else ""))
+
+
+def _valu_dest_regs(line: str) -> set:
+    t = line.strip()
+    if not t.startswith("v_") or t.startswith(("v_cmp", "v_cmpx", "v_nop", "v_readlane", "v_readfirstlane")):
+        return set()
+    first = t.split(None, 1)[1].split(",")[0] if " " in t else ""
+    return _vregs(first)
+
+
+def find_store_hazards(text: str) -> List[Tuple[str, str]]:
+    """Wide stores whose data registers are overwritten by a VALU instruction less than two wait states later."""
+    hits: List[Tuple[str, str]] = []
+    sym = "?"
+    pending: List[Tuple[set, int, str]] = []          # (data registers, wait states seen since, store text)
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            sym, pending = m.group(1), []
+            continue
+        body = line.split("//")[0].strip()
+        if not body or body.endswith(":"):
+            continue
+        if body.startswith(("s_endpgm", "s_branch", "s_setpc_b64", "s_swappc_b64")):      # the listing continues with another block
+            pending = []
+            continue
+        dest = _valu_dest_regs(body)
+        for regs, _, st in pending:
+            if dest & regs:
+                hits.append((sym, f"{st}  ->  {body}"))
+        nop = re.match(r"s_nop\s+(\d+)", body)
+        step = int(nop.group(1)) + 1 if nop else 1
+        pending = [(r, n + step, st) for r, n, st in pending if n + step < 2]
+        regs = _store_data_regs(body)
+        if regs:
+            pending.append((regs, 0, body))
+    return hits
+
+
 def find_bad_instructions(lib_path: str) -> List[Tuple[str, str]]:
-    """[(kernel symbol, instruction text)] for every occurrence of the forbidden form."""
+    """[(kernel symbol, instruction text)] for every occurrence of a forbidden form."""
     hits: List[Tuple[str, str]] = []
     for co in device_code_objects(lib_path):
         sym = "?"
-        for line in disassemble(co).splitlines():
+        text = disassemble(co)
+        for line in text.splitlines():
             m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
             if m:
                 sym = m.group(1)
             elif _BAD.search(line):
                 hits.append((sym, line.strip()))
+        hits += find_store_hazards(text)
     return hits
 
 
@@ -84,8 +154,8 @@ def check_library(lib_path: str) -> int:
     hits = find_bad_instructions(lib_path)
     if hits:
         lines = "\n".join(f"  {s}: {i}" for s, i in hits[:20])
-        raise RuntimeError(f"{lib_path}: {len(hits)} packed-fp32 instruction(s) with op_sel:[0,1] (wrong beside MFMA work on gfx950, "
-                           f"see avex_amd/isa_lint.py):\n{lines}")
+        raise RuntimeError(f"{lib_path}: {len(hits)} forbidden instruction form(s) -- packed fp32 with op_sel:[0,1] (wrong beside MFMA work on "
+                           f"gfx950) or a wide store whose data registers are overwritten too early (see avex_amd/isa_lint.py):\n{lines}")
     return len(objs)
 
 

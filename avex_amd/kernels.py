@@ -351,6 +351,8 @@ def lstm_layer(xg: torch.Tensor, w_hh_t: torch.Tensor, out: torch.Tensor, col: i
     H = G // 4
     if w_hh_t.shape != (H, 4 * H) or out.shape[:2] != (B, T) or out.shape[2] < col + H or not (xg.is_contiguous() and w_hh_t.is_contiguous() and out.is_contiguous()):
         raise ValueError("lstm_layer: shapes")
+    if not all(t.dtype == torch.float32 for t in (xg, w_hh_t, out)):      # (the column offset below is in 4-byte elements)
+        raise ValueError("lstm_layer: float32 tensors only")
     check(lib().avexhip_lstm_layer(_ptr(xg), _ptr(w_hh_t), B, T, H, int(bool(reverse)), int(out.data_ptr()) + 4 * col, out.shape[2], _stream()), "lstm_layer")
 
 
@@ -710,10 +712,11 @@ class BeatsGraph:
         self.hooks: Dict[int, torch.Tensor] = {}
         self._ptrs = (C.c_void_p * (enc.L + 1))()
         mask = 0
+        code = pool_code(hook_pooled)      # the buffers are sized by the CODE the library gets ("none" is a true string and code 0)
         for i in sorted(set(int(x) for x in hook_layers)):
             if not 0 <= i <= enc.L:
                 raise ValueError(f"hook layer {i} out of range 0..{enc.L}")
-            self.hooks[i] = torch.empty((B, enc.E) if hook_pooled else (B, Tt, enc.E), dtype=torch.float32, device=dev)
+            self.hooks[i] = torch.empty((B, enc.E) if code else (B, Tt, enc.E), dtype=torch.float32, device=dev)
             self._ptrs[i] = int(self.hooks[i].data_ptr())
             mask |= 1 << i
         self.features = torch.empty((B, Tt, enc.E), dtype=torch.float32, device=dev) if want_features else None
@@ -723,7 +726,7 @@ class BeatsGraph:
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._g = lib().avexhip_beats_graph_capture(enc._h, _ptr(self.wav), B, T, T, _ptr(self.frame_pad), mask, self._ptrs, pool_code(hook_pooled),
+            self._g = lib().avexhip_beats_graph_capture(enc._h, _ptr(self.wav), B, T, T, _ptr(self.frame_pad), mask, self._ptrs, code,
                                                         _ptr(self.features), _ptr(self.pooled), _ptr(self._ws), self._ws.numel(), _stream())
         cur.wait_stream(side)
         if not self._g:
@@ -731,7 +734,19 @@ class BeatsGraph:
         self.nodes = int(lib().avexhip_beats_graph_nodes(self._g))
 
     def replay(self) -> "BeatsGraph":
+        """Launch the recorded forward.  The encoder's ``on_overflow`` policy applies to replays as to eager forwards -- ``"warn"`` (one call
+        late, no synchronisation) and ``"raise"`` (synchronises) -- except ``"retry"``: a graph has no bf16 twin to fall back to, so a clipped
+        f16 value raises there as well."""
         check(lib().avexhip_beats_graph_launch(self._g, _stream()), "beats_graph_launch")
+        enc = self._enc
+        if enc.on_overflow != "ignore":
+            new = enc._new_overflow(sync=enc.on_overflow in ("raise", "retry"))
+            if new:
+                msg = (f"avex_amd: {new} lane(s) clipped a value to the f16 range (+-65504) inside a replayed BEATs forward: the result is not the "
+                       "reference's.  Use operand_dtype='bf16' with residual='f32' (fp32's exponent range); on_overflow='retry' is not available for graphs.")
+                if enc.on_overflow in ("raise", "retry"):
+                    raise AvexHipError(msg)
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
         return self
 
     def close(self) -> None:
@@ -808,10 +823,11 @@ class BeatsEncoder:
         hooks: Dict[int, torch.Tensor] = {}
         ptrs = (C.c_void_p * (self.L + 1))()
         mask = 0
+        code = pool_code(hook_pooled)      # sizes the tap buffers AND goes to the library: never the truthiness of the argument
         for i in sorted(set(int(x) for x in hook_layers)):
             if not 0 <= i <= self.L:
                 raise ValueError(f"hook layer {i} out of range 0..{self.L}")
-            shape = (B, self.E) if hook_pooled else (B, Tt, self.E)
+            shape = (B, self.E) if code else (B, Tt, self.E)
             hooks[i] = torch.empty(shape, dtype=torch.float32, device=dev)
             ptrs[i] = int(hooks[i].data_ptr())
             mask |= 1 << i
@@ -823,7 +839,7 @@ class BeatsEncoder:
             if pad.shape != (B, Tt):
                 raise ValueError(f"frame_pad must be [B={B}, T'={Tt}], got {tuple(pad.shape)}")
         check(lib().avexhip_beats_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(pad), mask, ptrs,
-                                          pool_code(hook_pooled), _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
+                                          code, _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
               "beats_forward")
         if self.on_overflow != "ignore":
             new = self._new_overflow(sync=self.on_overflow in ("raise", "retry"))

@@ -162,6 +162,100 @@ def parity_vs_golden(cfg, sd, args, enc, wav):
     return out
 
 
+def effnet_algorithmic_bytes(stages, H, W, samples, stem=32, head=1280):
+    """EfficientNet on one clip, layer by layer: every convolution reads its input once and writes its output once in the operand type
+    (2 bytes), at the REAL channel counts; the mel frontend reads the fp32 wav and writes the fp32 image; weights (4 M parameters, L2-
+    resident) are not counted.  No cross-layer fusion is assumed -- it is the traffic of the algorithm as the reference structures it
+    (efficientnet.py:163-215: torchvision's features stack), the figure SURVEY.md section 8d asks the C5 rate to be priced with."""
+    co = lambda n, k, s: (n + 2 * ((k - 1) // 2) - k) // s + 1      # noqa: E731
+    b = samples * 4 + H * W * 4 + H * W * 4                         # frontend in / out, stem in
+    H, W = co(H, 3, 2), co(W, 3, 2)
+    b += H * W * stem * 2
+    c = stem
+    for er, k, s, cin, cout, reps in stages:
+        for r in range(reps):
+            st, ci = (s if r == 0 else 1), (cin if r == 0 else cout)
+            ce = ci * er
+            if er != 1:
+                b += H * W * (ci + ce) * 2                          # expand 1x1
+            Ho, Wo = co(H, k, st), co(W, k, st)
+            b += (H * W + Ho * Wo) * ce * 2                         # depthwise (the squeeze pool rides on its way out)
+            b += Ho * Wo * (ce + cout) * 2                          # squeeze-scaled projection 1x1
+            if st == 1 and ci == cout:
+                b += Ho * Wo * cout * 2                             # residual
+            H, W, c = Ho, Wo, cout
+    return b + H * W * (c + 2 * head) * 2 + head * 4                # head 1x1 (in, out), global pool (in, out)
+
+
+def other_configs(steps: int = 5):
+    """BASELINE.json configs C3 (EAT, 512 x 5 s) and C5 (EfficientNet-B0, 1024 x 10 s) after the headline's timed region, same box, same
+    process: ms per step, clips/s, a roofline each, and the pooled embedding of two clips against tests/golden/family_small.npz -- outputs
+    of the NumPy oracles on the synthetic checkpoints (tests/golden/make_family_goldens.py).  PARITY UNPINNED for both families: the
+    arithmetic they restate is third-party code absent from the reference tree, so those vectors pin the HIP
+    path to the oracle, not to the reference.  Not the headline `value`."""
+    import numpy as np
+    import torch
+    from avex_amd import kernels as K
+    from avex_amd import synth
+    from avex_amd.eat_encoder import EatEncoder
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "family_small.npz"))
+    rel = lambda a, b: float(f"{np.linalg.norm(a - b) / np.linalg.norm(b):.3e}")      # noqa: E731
+    out = {}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    try:        # ---- C3: EAT-base (eat_hf.py:241-289), 512 clips x 5 s -> mean over the 513 tokens
+        B, n = 512, 80000
+        enc = EatEncoder(synth.EAT_BASE_CFG, synth.eat_state_dict(), operand_dtype="f16")
+        wav = torch.from_numpy(synth.noise_clips(B, n, seed=0)).cuda()
+        dt = timed(lambda: enc.forward(wav, want_features=False, pooling="mean")["pooled"])
+        fl = 2 * 512 * 256 * 768 + 12 * (2 * 513 * 768 * (2304 + 768 + 3072 + 3072) + 4 * 513 * 513 * 768)      # per clip: patch GEMM + 12 blocks
+        small = torch.from_numpy(synth.noise_clips(2, n, seed=int(gold["eat.seed"][0]))).cuda()
+        p = enc.forward(small, want_features=False, pooling="mean")["pooled"].cpu().numpy()
+        out["c3_eat"] = {"workload": "EAT-base (12L/768/3072/12H, 513 tokens), batch 512 x 5 s @ 16 kHz, wav resident in HBM -> mean-pooled 768-d",
+                         "ms_per_step": round(1e3 * dt, 3), "clips_per_s": round(B / dt, 1), "dtype": "f16",
+                         "roofline": {"bound": "mfma", "achieved": round(B * fl / dt / 1e12, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(B * fl / dt / 1e12 / PEAK_TFLOPS, 4), "gflop_per_clip": round(fl / 1e9, 2)},
+                         "parity": {"reference": "tests/golden/family_small.npz:eat.pooled_mean (oracle/eat_oracle.py, UNPINNED: EAT's remote code is absent from the reference tree)",
+                                    "how": "2 clips x 5 s", "pooled_rel_l2_f16": rel(p, gold["eat.pooled_mean"]), "tolerance": 1e-3}}
+        enc.close()
+        del wav, enc
+    except Exception as e:  # noqa: BLE001
+        out["c3_eat"] = {"error": repr(e)[:300]}
+    try:        # ---- C5: EfficientNet-B0 (efficientnet.py:163-215), 1024 clips x 10 s -> mel 128 x 1001 -> features -> global average pool
+        B, n = 1024, 160000
+        enc = EfficientNetB0Encoder(synth.effnet_b0_state_dict())
+        plan = K.MelspecPlan(n_fft=800, hop_length=160, n_mels=128, normalize=True)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        wav = 0.1 * torch.randn(B, n, device="cuda", generator=g)
+        dt = timed(lambda: enc.forward(plan(wav), want_features=False, want_pooled=True)["pooled"])
+        nbytes = effnet_algorithmic_bytes(synth.EFFNET_B0_STAGES, 128, 1 + n // 160, n)
+        small = torch.from_numpy(synth.noise_clips(2, n, seed=int(gold["effnet.seed"][0]))).cuda()
+        p = enc.forward(plan(small), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
+        out["c5_effnet"] = {"workload": "EfficientNet-B0 (torchvision features stack, BatchNorm folded), batch 1024 x 10 s @ 16 kHz, wav resident in HBM -> "
+                                        "mel 128 x 1001 -> pooled 1280-d; conv / depthwise HIP kernels, the 1x1 convolutions on the MFMA GEMMs",
+                            "ms_per_step": round(1e3 * dt, 3), "clips_per_s": round(B / dt, 1), "dtype": "f16",
+                            "roofline": {"bound": "hbm", "achieved": round(B * nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                         "frac": round(B * nbytes / dt / 1e9 / 8000.0, 4), "algorithmic_mb_per_clip": round(nbytes / 1e6, 2),
+                                         "how": "every layer's input read once + output written once at 2 bytes and the real channel counts, no fusion assumed (bench.py effnet_algorithmic_bytes)"},
+                            "parity": {"reference": "tests/golden/family_small.npz:effnet.pooled (oracle/effnet_oracle.py, UNPINNED: torchvision is absent from the reference tree)",
+                                       "how": "2 clips x 10 s", "pooled_rel_l2_f16": rel(p, gold["effnet.pooled"]), "tolerance": 2e-2}}
+        del wav, enc
+    except Exception as e:  # noqa: BLE001
+        out["c5_effnet"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def h2d_inclusive(enc, wav, steps: int):
     """Outside the timed region, N = 1: the same step when the caller hands over HOST buffers (fp32 wav, 640 KB per clip: SURVEY.md
     section 8d asks for this second number).  The batch sits in pinned host memory; batch n + 1 crosses PCIe on a copy stream while
@@ -242,6 +336,7 @@ def main():
                     help="inter-kernel residual stream: fp32, or the operand type (default; pooled parity unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the post-run board power / clock sample (rocm-smi)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs C3 (EAT) and C5 (EfficientNet-B0) after the timed region")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="tests only: run the launch / barrier / timing / all-gather / JSON control flow on the CPU with gloo and a stub "
                          "in place of the encoder (no number it prints is a measurement)")
@@ -477,6 +572,8 @@ def main():
             line["config"]["h2d_included"] = h2d_inclusive(enc, wav, max(args.steps, 5))
         if world == 1 and not dry and not args.no_power:
             line["power"] = board_power(step, sync, local_rank)
+        if world == 1 and not dry and not args.no_other_configs:
+            line["configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline and not dry:
             line["cpu_baseline"] = cpu_baseline(sd, cfg)
         print(json.dumps(line), flush=True)

@@ -160,8 +160,22 @@ def _pipe_worker(rank, world, port, out_dir):
     for list_output in (False, True):
         model = _StubModel(list_output)
         emb, labels, dims = extract_embeddings_in_memory(model, _batches(5, (6, 5, 1)), ["last_layer"], "cpu",
-                                                         aggregation="none" if list_output else "mean")
+                                                         aggregation="none" if list_output else "mean", sharded=True)
         res[list_output] = ({k: v.numpy() for k, v in emb.items()}, labels.numpy(), dims, model.calls)
+    # (c) sharding is opt-in: by default every rank embeds its own whole batches (what a DistributedSampler set-up needs) ...
+    model = _StubModel(False)
+    own = _batches(3, (4,))
+    for b in own:
+        b["raw_wav"] = b["raw_wav"] + rank      # a different batch per rank
+    emb, labels, dims = extract_embeddings_in_memory(model, own, ["last_layer"], "cpu")
+    ok_c = model.calls == [4, 4, 4] and torch.equal(next(iter(emb.values())), torch.cat([_embed(b["raw_wav"]) for b in own]))
+    # ... and asking for it with different batches per rank is refused instead of gathering unrelated rows
+    try:
+        extract_embeddings_in_memory(_StubModel(False), own, ["last_layer"], "cpu", sharded=True)
+        ok_c = False
+    except RuntimeError as e:
+        ok_c = ok_c and "same batches" in str(e)
+    np.save(os.path.join(out_dir, f"optin_ok_r{rank}.npy"), np.array([int(ok_c)]))
     np.save(os.path.join(out_dir, f"pipe_ok_r{rank}.npy"), np.array([int(ok_a)]))
     import pickle
     with open(os.path.join(out_dir, f"loop_r{rank}.pkl"), "wb") as f:
@@ -182,6 +196,7 @@ def test_pipelined_gather_and_sharded_extraction_loop(tmp_path):
         ref[list_output] = ({k: v.numpy() for k, v in emb.items()}, labels.numpy(), dims)
     for r in range(2):
         assert np.load(tmp_path / f"pipe_ok_r{r}.npy")[0] == 1
+        assert np.load(tmp_path / f"optin_ok_r{r}.npy")[0] == 1      # default = unsharded; sharded=True with different batches per rank is refused
         with open(tmp_path / f"loop_r{r}.pkl", "rb") as f:
             res = pickle.load(f)
         for list_output in (False, True):

@@ -91,6 +91,11 @@ def test_pooled_tap_aggregations(encoder):
                     assert rel_l2(r[i].cpu().numpy(), want.cpu().numpy()) < 1e-5
                 else:
                     assert torch.equal(r[i], want), (samples, agg, i)
+        # "none" is a non-empty string and code 0: the taps come back FULL, in buffers sized for full taps (sized by the string's
+        # truthiness they were [B, E] buffers the library wrote B * T' * E floats into)
+        r = encoder.forward(wav, hook_layers=[0, 12], hook_pooled="none", want_features=False)["hooks"]
+        for i in (0, 12):
+            assert r[i].shape == full[i].shape and torch.equal(r[i], full[i])
 
 
 def test_layernorm_in_split_k_epilogue(encoder, monkeypatch):

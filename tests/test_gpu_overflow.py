@@ -174,6 +174,16 @@ def test_overflow_policies(built_lib, clips):
     want = wide.forward(x, want_features=False, want_pooled=True)["pooled"]
     wide.close()
     assert torch.equal(got, want)
+    # a recorded forward obeys the policy too: the warm-up forward of the capture is the first to see the clipping; a replay raises
+    # ("retry" has no graph to fall back to and raises as well)
+    for policy in ("raise", "retry"):
+        enc = K.BeatsEncoder(CFG, sd, on_overflow=policy)
+        g = enc.capture(x.shape[0], x.shape[1], want_features=False, want_pooled=True)
+        enc.reset_overflow(); enc._overflow_seen = 0
+        g.wav.copy_(x)
+        with pytest.raises(AvexHipError, match="replayed"):
+            g.replay()
+        g.close(); enc.close()
     # a clean checkpoint never alarms, in any mode
     clean = synth.beats_state_dict(CFG, seed=0)
     enc = K.BeatsEncoder(CFG, clean, on_overflow="raise")

@@ -207,6 +207,42 @@ def test_flac_host_parser_accepts_and_refuses(built_lib):
         ingest.parse_wav(bytes(data))                                           # and the WAV parser does not take it for a WAV
 
 
+def test_flac_host_parser_refuses_order_beyond_block(built_lib):
+    """A crafted frame: block-size code 6 with a size byte of 0 (a ONE-sample block) and an LPC subframe of order 32.  The warm-up samples
+    of such a subframe would be written past the block's buffer; the parser must refuse it before writing anything (valid CRCs, so only
+    the order check can stop it).  Same for a FIXED subframe of order 4 in a two-sample block."""
+    import _flac_enc as E
+    from oracle.flac_oracle import crc8, crc16
+
+    def stream(size_byte, sub_type, warm):
+        bw = E.Bits()
+        bw.put(0x3FFE, 14); bw.put(0, 1); bw.put(0, 1)
+        bw.put(6, 4); bw.put(5, 4); bw.put(0, 4); bw.put(4, 3); bw.put(0, 1)      # bs code 6, 16 kHz, mono, 16 bit
+        bw.put(0, 8)                                                                # frame number 0
+        bw.put(size_byte, 8)                                                        # block size - 1
+        hdr = bw.bytes()
+        bw.put(crc8(hdr), 8)
+        bw.put(0, 1); bw.put(sub_type, 6); bw.put(0, 1)                             # subframe header
+        for _ in range(warm):
+            bw.put(0x1234, 16)
+        bw.put(11, 4); bw.put(3, 5)                                                 # precision 12, shift 3 (LPC only reads them; harmless for FIXED)
+        for _ in range(32):
+            bw.put(1, 12)
+        bw.put(0, 2); bw.put(0, 4); bw.put(0, 4)
+        bw.align()
+        body = bw.bytes()
+        frame = body + crc16(body).to_bytes(2, "big")
+        n = size_byte + 1
+        x = (16000 << 44) | (0 << 41) | (15 << 36) | n
+        info = (16).to_bytes(2, "big") * 2 + len(frame).to_bytes(3, "big") * 2 + x.to_bytes(8, "big") + bytes(16)
+        return b"fLaC" + bytes([0x80, 0, 0, 34]) + info + frame
+
+    with pytest.raises(ValueError, match="predictor order"):
+        ingest.FlacStream(stream(0, 63, 32))          # LPC order 32 in a 1-sample block
+    with pytest.raises(ValueError, match="predictor order"):
+        ingest.FlacStream(stream(1, 12, 4))           # FIXED order 4 in a 2-sample block
+
+
 @pytest.mark.gpu
 def test_flac_device_decoder_is_bit_exact(built_lib):
     import hashlib
