@@ -56,7 +56,7 @@ class AvesEncoder:
     and the workspace."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, np.ndarray], operand_dtype: str = "f16", prefix: str = "model.",
-                 max_chunk_clips: int = 0, residual: str = "half") -> None:
+                 max_chunk_clips: int = 0, residual: str = "half", batch_invariant: bool = False) -> None:
         _capi.require_gpu()
         self.cfg = dict(cfg)
         self.dtype = operand_dtype
@@ -75,7 +75,7 @@ class AvesEncoder:
             c.conv_kernel[i], c.conv_stride[i] = k, st
         c.operand_dtype = _capi.dtype_code(operand_dtype)
         c.max_chunk_clips = int(max_chunk_clips)
-        c.residual_dtype = K.RESIDUAL_CODES[str(residual).lower()]
+        c.residual_dtype = K.residual_code(residual, batch_invariant)
         sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
         arr, n, keep = K.tensor_table(sub)
         self._h = _capi.lib().avexhip_aves_create(C.byref(c), arr, n)

@@ -13,6 +13,8 @@ PARITY UNPINNED against torchaudio (see oracle/aves_oracle.py).
 """
 from __future__ import annotations
 
+import os
+
 import logging
 from typing import Any, Dict, List, Optional, Union
 
@@ -126,8 +128,10 @@ class Model(ModelBase):
 
     def __init__(self, *, num_classes: Optional[int] = None, pretrained: bool = False, device: str = "cuda",
                  audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None, operand_dtype: str = "f16",
-                 init_config: Optional[Dict[str, Any]] = None) -> None:
+                 init_config: Optional[Dict[str, Any]] = None, batch_invariant: Optional[bool] = None) -> None:
         super().__init__(device=device, audio_config=audio_config)
+        # a clip's outputs bit-identical whatever batch it arrives in (kernels.residual_code; environment: AVEX_AMD_BATCH_INVARIANT=1)
+        self.batch_invariant = bool(batch_invariant) if batch_invariant is not None else os.environ.get("AVEX_AMD_BATCH_INVARIANT", "0") not in ("", "0")
         if pretrained:
             raise FileNotFoundError("pretrained=True needs birdaves-biox-base.torchaudio.pt (aves_model.py:87-90), which is not "
                                     "reachable offline; load a local state dict with load_state_dict() / checkpoint_path=")
@@ -164,7 +168,7 @@ class Model(ModelBase):
                 raise AvexHipError(f"AVES parameters live on {p.device}; the avex_amd path runs on a GPU only (no CPU fallback)")
             with torch.cuda.device(p.device):
                 state = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
-                self._encoder = AvesEncoder(self.config.to_dict(), state, operand_dtype=self.operand_dtype)
+                self._encoder = AvesEncoder(self.config.to_dict(), state, operand_dtype=self.operand_dtype, batch_invariant=self.batch_invariant)
             self._weights_dirty = False
         return self._encoder
 

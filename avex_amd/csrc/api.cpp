@@ -208,6 +208,7 @@ struct avexhip_beats : avxh::HandleBase {
     avexhip_beats_config cfg;
     int E = 0, F = 0, H = 0, L = 0, D = 0, P = 0, NM = 0, chunk = 256;
     bool fast = false;   // residual stream / pre-LN sums in the operand type
+    bool batch_invariant = false;  // residual_dtype bit 1: see CoreCfg::batch_invariant
     bool ln_fold = false;  // fast mode: LayerNorms between the GEMMs folded into their epilogues
     int ln_fold_min_rows = 0;   // ... for chunks of at least this many rows (avxh::fold_policy)
     int nstreams = 1;    // chunks of one forward run concurrently on this many streams (caller's + side streams)
@@ -242,7 +243,7 @@ struct avexhip_beats : avxh::HandleBase {
     CoreCfg core() const {
         CoreCfg c;
         c.E = E; c.F = F; c.H = H; c.L = L; c.alpha = alpha; c.eps = 1e-5f; c.hook_site = 0; c.fast = fast; c.fold = ln_fold;
-        c.fold_min_rows = ln_fold_min_rows; c.act = act; c.glu = glu; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
+        c.fold_min_rows = ln_fold_min_rows; c.batch_invariant = batch_invariant; c.act = act; c.glu = glu; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
         return c;
     }
     ~avexhip_beats() override {
@@ -647,12 +648,13 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     h->E = c.encoder_embed_dim; h->F = c.encoder_ffn_embed_dim; h->H = c.encoder_attention_heads;
     h->L = c.encoder_layers; h->D = c.embed_dim; h->P = c.input_patch_size; h->NM = c.num_mel_bins;
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
-    h->fast = c.residual_dtype != 0;
+    h->fast = avxh::cfg_fast(c.residual_dtype);
+    h->batch_invariant = avxh::cfg_batch_invariant(c.residual_dtype);
     {
         // The encoder's LayerNorms are folded into the GEMM epilogues around them (GemmArgs) unless AVEX_AMD_LN_FOLD=0: 24 LayerNorm
         // launches and 9 GB of traffic per 256-clip step disappear, +2.7 % (9 367 -> 9 623 clips/s alternating inside one process,
         // profiles/r03a_ln_fold.txt) and one rounding of the residual stream less per sublayer.  Built for post-LN blocks with a GELU FFN.
-        avxh::fold_policy(h->fast, c.encoder_embed_dim, c.encoder_ffn_embed_dim, &h->ln_fold, &h->ln_fold_min_rows);
+        avxh::fold_policy(h->fast, c.encoder_embed_dim, c.encoder_ffn_embed_dim, &h->ln_fold, &h->ln_fold_min_rows, h->batch_invariant);
         if (c.layer_norm_first || c.activation_fn != AVEXHIP_FFN_GELU) h->ln_fold = false;
     }
     h->pre_ln = c.layer_norm_first != 0;

@@ -130,6 +130,33 @@ static __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 u = (f32x2)(0.5f) - q;
     return __builtin_elementwise_fma(ax, u, x * (f32x2)(0.5f));
 }
+// The same GELU over N pairs at once, written step by step ACROSS the pairs: N independent chains side by side in program order (the
+// scheduler keeps a dependent chain of packed FMAs together when it is handed one pair at a time, and each link then waits for the last).
+template <int N>
+static __device__ __forceinline__ void gelu_erf2xN(f32x2 (&x)[N]) {
+    f32x2 ax[N], a[N], p[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        ax[q][0] = __builtin_fabsf(x[q][0]); ax[q][1] = __builtin_fabsf(x[q][1]);
+        a[q][0] = __builtin_fminf(ax[q][0], AVX_GELU_A); a[q][1] = __builtin_fminf(ax[q][1], AVX_GELU_A);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = __builtin_elementwise_fma((f32x2)(AVX_GELU_C6), a[q], (f32x2)(AVX_GELU_C5));
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = __builtin_elementwise_fma(p[q], a[q], (f32x2)(AVX_GELU_C4));
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = __builtin_elementwise_fma(p[q], a[q], (f32x2)(AVX_GELU_C3));
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = __builtin_elementwise_fma(p[q], a[q], (f32x2)(AVX_GELU_C2));
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = __builtin_elementwise_fma(p[q], a[q], (f32x2)(AVX_GELU_C1));
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = __builtin_elementwise_fma(p[q], a[q], (f32x2)(AVX_GELU_C0));
+#pragma unroll
+    for (int q = 0; q < N; ++q) { p[q][0] = __builtin_amdgcn_exp2f(p[q][0]); p[q][1] = __builtin_amdgcn_exp2f(p[q][1]); }
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] = __builtin_elementwise_fma(ax[q], (f32x2)(0.5f) - p[q], x[q] * (f32x2)(0.5f));
+}
 // SiLU x * sigmoid(x) = x / (1 + 2^(-x log2 e)) (EfficientNet's activation), two elements at a time
 static __device__ __forceinline__ f32x2 silu2(f32x2 x) {
     const f32x2 t = x * (f32x2)(-1.4426950408889634f);

@@ -176,8 +176,9 @@ extern "C" avexhip_eat* avexhip_eat_create(const avexhip_eat_config* cfg, const 
     h->dtype = c.operand_dtype;
     h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.depth;
     h->core.alpha = 1.0f; h->core.eps = c.norm_eps > 0.f ? c.norm_eps : 1e-6f; h->core.hook_site = 1;
-    h->core.fast = c.residual_dtype != 0;
-    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
+    h->core.fast = avxh::cfg_fast(c.residual_dtype);
+    h->core.batch_invariant = avxh::cfg_batch_invariant(c.residual_dtype);
+    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows, h->core.batch_invariant);
     h->P = c.patch_size;
     h->n_patches = (c.target_length / 16) * (c.n_mels / 16);
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
@@ -324,9 +325,10 @@ extern "C" avexhip_stack* avexhip_stack_create(const avexhip_stack_config* cfg, 
     h->dtype = c.operand_dtype;
     h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.num_layers; h->core.head_dim = hd;
     h->core.alpha = 1.0f; h->core.eps = c.norm_eps > 0.f ? c.norm_eps : 1e-5f; h->core.hook_site = 0;
-    h->core.fast = c.residual_dtype != 0;
+    h->core.fast = avxh::cfg_fast(c.residual_dtype);
+    h->core.batch_invariant = avxh::cfg_batch_invariant(c.residual_dtype);
     h->core.act = c.activation;
-    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
+    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows, h->core.batch_invariant);
     if (c.activation != 1 || c.ffn_dim == 0) h->core.fold = false;      // the folded epilogues know GELU only
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     if (h->init_alarm() != AVEXHIP_OK) { delete h; return nullptr; }
@@ -530,8 +532,9 @@ extern "C" avexhip_aves* avexhip_aves_create(const avexhip_aves_config* cfg, con
     }
     h->core.E = c.embed_dim; h->core.F = c.ffn_dim; h->core.H = c.num_heads; h->core.L = c.num_layers;
     h->core.alpha = 1.0f; h->core.eps = 1e-5f; h->core.hook_site = 0;
-    h->core.fast = c.residual_dtype != 0;
-    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows);
+    h->core.fast = avxh::cfg_fast(c.residual_dtype);
+    h->core.batch_invariant = avxh::cfg_batch_invariant(c.residual_dtype);
+    avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows, h->core.batch_invariant);
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 64;       // layer 0 of the extractor holds 32 MB per 10 s clip
     if (h->init_alarm() != AVEXHIP_OK || aves_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
     return h;

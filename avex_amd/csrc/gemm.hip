@@ -461,6 +461,18 @@ static __device__ __forceinline__ float seg8_sum(float v) {
     return v;
 }
 
+// Sum and sum of squares of a lane's 8 values x[0..3], y[0..3] (a row segment's share of the LayerNorm statistics), as PACKED operations down
+// the register pairs -- (x.01 + x.23) + (y.01 + y.23), the two halves added last -- 9 instructions.  (Written as a chain of scalar adds the
+// compiler packed it anyway, with two register moves per packed add to line the pairs up: ~500 v_mov per tile and wave in the residual
+// epilogue.)  Both epilogues that write statistics use this one function, so they agree bit for bit.
+static __device__ __forceinline__ void stats8(const f32x4& x, const f32x4& y, float& s1, float& s2) {
+    const f32x2 xl = {x[0], x[1]}, xh = {x[2], x[3]}, yl = {y[0], y[1]}, yh = {y[2], y[3]};
+    const f32x2 t = (xl + xh) + (yl + yh);
+    const f32x2 q = __builtin_elementwise_fma(yh, yh, __builtin_elementwise_fma(yl, yl, __builtin_elementwise_fma(xh, xh, xl * xl)));
+    s1 = hsum2(t);
+    s2 = hsum2(q);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The 256-tile kernel: the half-tile pipeline above as ONE CONTINUOUS K STREAM over a persistent workgroup's tiles (one
 // workgroup per CU).  The last iterations of a tile issue the DMA for the next tile's first K-tiles as if they were K-tiles
@@ -486,6 +498,26 @@ static_assert(L5_ROWS + 4096 <= 32768, "EPI 1 scratch above the stages");
 #endif
 #ifndef GEMM_XCD_WALK
 #define GEMM_XCD_WALK 0
+#endif
+#ifndef GEMM_COL_WALK
+#define GEMM_COL_WALK 0     // 1: AVEX_AMD_GEMM_TILE_ORDER=-n selects the column-group walk (A/B builds; the scalar code of a third walk in
+                            // set_tile is kept out of the default kernel: it sits inside the K loop's second-to-last iteration)
+#endif
+#ifndef GEMM_GELU_CHAINS
+#define GEMM_GELU_CHAINS 0  // EPI 1: 1 = the activation of a 16-row chunk as 8 chains side by side (gelu_erf2xN); fewer stall cycles, same
+                            // instructions: fc1 -0.3 %, QKV +1.1 % (profiles/r04h_epilogue_ab2.txt) -- under the power cap stall cycles are not the currency
+#endif
+#ifndef GEMM_EPI2_EARLY
+#define GEMM_EPI2_EARLY 0
+#endif
+#ifndef GEMM_W_POLICY
+#define GEMM_W_POLICY 0
+#endif
+#ifndef GEMM_A_POLICY
+#define GEMM_A_POLICY 0
+#endif
+#ifndef GEMM_EPI1_SWAP
+#define GEMM_EPI1_SWAP 0   // EPI 1: 0 = transpose through a private LDS slab (default), 1 = in registers with v_permlane16_swap (A/B builds; measured SLOWER, see below)
 #endif
 
 template <typename T, int EPI, int LN, int ACT>
@@ -526,9 +558,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     // At K = 3072 a group would be 12.6 MB: row-major there.
     const bool grouped = p.tile_order >= 2 || (p.tile_order == 0 && p.K < 2048);
     const int group_m = p.tile_order >= 2 ? p.tile_order : 8;
+    // tile_order < 0: COLUMN-group walk, -tile_order column tiles per group.  Tile ids run (column group, row panel, column inside the
+    // group) and every XCD owns a contiguous eighth of them (xw below): an XCD keeps one group of weight panels (e.g. 6 x 393 KB) for
+    // hundreds of tiles while the A row panels stream past ONCE per group -- the row-group walk above re-fetches a group's A panels for
+    // every round of column tiles once 32 concurrent tiles have pushed 4.7 MB through a 4 MiB L2 (roofline.traffic_by_shape).
+    const bool colwalk = GEMM_COL_WALK && p.tile_order < 0;
+    const int group_n = colwalk ? (-p.tile_order < tiles_n ? -p.tile_order : tiles_n) : 1;
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
         int tm, tn;
-        if (grouped) tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
+        if (colwalk) {
+            const int per_group = tiles_m * group_n;
+            const int gid = tile / per_group;
+            const int first_n = gid * group_n;
+            const int gsz = (tiles_n - first_n) < group_n ? (tiles_n - first_n) : group_n;
+            const int r = tile - gid * per_group;
+            tm = r / gsz;
+            tn = first_n + (r - tm * gsz);
+        } else if (grouped) tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
         else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
         m0 = tm * T2; n0 = tn * T2;
 #pragma unroll
@@ -543,15 +589,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 xsrc[h][q] = A + (int64_t)arow * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3);
             }
     };
+    // GEMM_W_POLICY / GEMM_A_POLICY (A/B builds): cache-policy bits of the two operand streams' LDS-DMA (0 default, 2 = nt: stream, evict first).
+    // Measured (profiles/r04g_epilogue_ab.txt, r04h_epilogue_ab2.txt): W nt 6 - 24 % slower on every shape; A nt 13 - 15 % slower on QKV / fc1
+    // and 8 % FASTER on out_proj stand-alone -- but chosen per product inside the step (N <= 768 only) it still LOSES 0.8 %: what it
+    // pushes out of the caches are the next kernels' inputs.  (As a run-time branch around each DMA pair it also cost the loop 1.5 %.)
     auto dma_w = [&](int h, int kt, int stg) __attribute__((always_inline)) {
         char* base = smem + stg * STAGE2;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, GEMM_W_POLICY);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, GEMM_W_POLICY);
     };
     auto dma_x = [&](int h, int kt, int stg) __attribute__((always_inline)) {
         char* base = smem + stg * STAGE2;
-        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, GEMM_A_POLICY);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, GEMM_A_POLICY);
     };
     constexpr bool fast_half = EPI == 1, fast_resid = EPI == 2;
     constexpr bool LNA = EPI == 1 && (LN & 1), LNR = EPI == 2 && (LN & 1), STATS = EPI == 2 && (LN & 2);
@@ -593,9 +643,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     // touch at least 11.3 operand panels of 393 KB (K = 768) per round, 4.4 MB against 4 MB of L2, so under LRU nothing survives from
     // one round to the next whichever XCD runs it; the fetch counter sits at rounds x that footprint (the floor of this tiling), and
     // what it counts is L2 <-> fabric traffic, of which the 256 MB Infinity Cache absorbs the A re-reads (A is 195 MB).
-    const int t_lo = GEMM_XCD_WALK ? (int)(((int64_t)ntiles * xcd) >> 3) : 0;
-    const int t_hi = GEMM_XCD_WALK ? (int)(((int64_t)ntiles * (xcd + 1)) >> 3) : ntiles;
-    int tile = GEMM_XCD_WALK ? t_lo + slot : (0 * 8 + xcd) * per_xcd + slot;
+    const bool xw = GEMM_XCD_WALK || colwalk;
+    const int t_lo = xw ? (int)(((int64_t)ntiles * xcd) >> 3) : 0;
+    const int t_hi = xw ? (int)(((int64_t)ntiles * (xcd + 1)) >> 3) : ntiles;
+    int tile = xw ? t_lo + slot : (0 * 8 + xcd) * per_xcd + slot;
     if (tile >= t_hi) return;
     set_tile(tile);
     dma_aux(n0, m0, 0);
@@ -605,8 +656,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     AVX_BAR();
     if (wm == 1) { AVX_BAR(); }      // stagger: waves 4-7 run one barrier behind, for the whole tile walk
     int g0 = 0;                      // global K-tile index of the tile's first K-tile: its stage parity
-    constexpr bool early_w1 = EPI == 1 && !GEMM_NOSTORE;
-    bool prev_full = false;
+    // EPI 1 (and EPI 2 in GEMM_EPI2_EARLY builds): the epilogue's trailing stores are COUNTED PAST by the next tile's first wait instead of
+    // waited for (see the B phase of K-tile 0 below).  Their number is exact since the stores became raw-buffer stores that always issue
+    // (rows past M are dropped by the bounds check, not skipped by an exec mask): 16 output stores per wave, EPI 2 with statistics 16 more,
+    // interleaved -- whichever form, at least the last 16 vector-memory operations before the new tile's DMAs are epilogue operations
+    // that need not have retired.  For EPI 2 it measured level (out_proj) to 1 % slower (fc2): profiles/r04h_epilogue_ab2.txt; not the default.
+    constexpr bool early_w1 = (EPI == 1 || (GEMM_EPI2_EARLY && EPI == 2)) && !GEMM_NOSTORE;
 
     // One continuous K stream over this workgroup's tiles: the DMA for the next tile's first K-tiles is issued by the
     // LAST iterations of the current tile exactly as if they were K-tiles nk, nk + 1 of the same product (the source
@@ -620,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool stamp = stamp_on && tile < 8192;
         const int em0 = m0, en0 = n0;
-        const int next_tile = GEMM_XCD_WALK ? t_lo + (it + 1) * per_xcd + slot : ((it + 1) * 8 + xcd) * per_xcd + slot;
+        const int next_tile = xw ? t_lo + (it + 1) * per_xcd + slot : ((it + 1) * 8 + xcd) * per_xcd + slot;
         const bool has_next = next_tile < t_hi;
         AVX_STAMP(if (stamp) { g_gemm_stamps[4 * tile + 0] = g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); });
         for (int kt = 0; kt < nk; ++kt) {
@@ -644,9 +699,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_READ_W(1, st);
             if (kt + 2 < nk) {
                 dma_w(0, kt + 2, st); dma_x(0, kt + 2, st); dma_x(1, kt + 2, st);
-                // first K-tile after an epilogue: its 16 global stores sit between K-tile 1's DMAs (older) and these six; count past them
-                // instead of waiting for them to retire (only when the previous tile stored all of its rows, so that the count is exact)
-                if (early_w1 && kt == 0 && it > 0 && prev_full) { AVX_VMCNT(22); }
+                // first K-tile after an epilogue: the epilogue's last 16 vector-memory operations (its trailing stores) sit between K-tile 1's
+                // DMAs (older) and these six; count past them instead of waiting for them to retire
+                if (early_w1 && kt == 0 && it > 0) { AVX_VMCNT(22); }
                 else { AVX_VMCNT(6); }
             } else if (has_next) {
                 dma_w(0, kt + 2 - nk, st); dma_x(0, kt + 2 - nk, st); dma_x(1, kt + 2 - nk, st);
@@ -691,6 +746,64 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rst[j] = ((const float2*)(ldsrows + (it & 1) * 512))[wn * 64 + 16 * j + lc];      // (rstd, -mu rstd) of tile row 64 wn + 16 j + lc
             }
+#if GEMM_EPI1_SWAP
+            // (A/B form, NOT the default: profiles/r04g_epilogue_ab.txt -- QKV 6.5 % slower than the slab form below, fc1 1.2 % faster; the
+            //  residual epilogue built the same way was 14 % / 4 % slower on out_proj / fc2.  What it loses is the store shape: 16 rows x 64
+            //  contiguous bytes per instruction instead of 8 rows x 128, i.e. half lines.)
+            // Register transpose instead of an LDS round trip.  After the arithmetic a lane holds, for each of the four 16-column MFMA tiles
+            // i of a 16-row chunk, 4 consecutive columns (16 i + 4 lg ..) of row lc as two registers of halves.  One v_permlane16_swap per
+            // register of a tile PAIR (2 p, 2 p + 1) exchanges the odd rows of 16 lanes of the first tile with the even rows of the second:
+            // a lane then owns 8 CONSECUTIVE columns of row lc -- lanes lg = 0, 2 the two halves of tile 2 p, lanes lg = 1, 3 those of tile
+            // 2 p + 1 -- i.e. one 16-byte store, 64 contiguous bytes per row and instruction (the fabric's request size).  Per chunk:
+            // 4 swaps in place of 4 ds_write_b64 + 2 ds_read_b128 + two lgkmcnt(0) waits (scripts/micro/permlane16.hip checks the rows).
+            const int ldh = (int)p.ldh;
+            const int vrows = p.M - (em0 + wn * 64);
+            const __amdgpu_buffer_rsrc_t obuf = buf_rsrc((const T*)p.out_half + (int64_t)(em0 + wn * 64) * p.ldh + en0 + wm * 128,
+                                                         vrows > 0 ? (unsigned)(vrows < 64 ? vrows : 64) * (unsigned)ldh * 2u : 0u);
+            const int ovoff = (lc * ldh + 16 * (lg & 1) + 8 * (lg >> 1)) * 2;
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                f32x4 bv[4], sv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = *(const f32x4*)(lb + 64 * ih + 16 * i + 4 * lg);
+                if (LNA) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sv[i] = *(const f32x4*)(lsv + 64 * ih + 16 * i + 4 * lg);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2 v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // LayerNorm of the A rows folded in: rstd * acc + ((-mu rstd) * s[n] + bias'[n])
+                            if (LNA) v[2 * i + (e >> 1)][e & 1] = __builtin_fmaf(rst[j].x, acc[4 * ih + i][j][e], __builtin_fmaf(rst[j].y, sv[i][e], bv[i][e]));
+                            else v[2 * i + (e >> 1)][e & 1] = acc[4 * ih + i][j][e] + bv[i][e];
+                        }
+                    }
+                    if constexpr (ACT == 1) gelu_erf2xN<8>(v);
+                    else if constexpr (ACT == 2) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = silu2(v[q]);
+                    }
+                    unsigned hw[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        ovf_see<T>(ovf_mx, v[q][0], v[q][1]);
+                        typename Half<T>::v4 h2 = {Half<T>::from(v[q][0]), Half<T>::from(v[q][1]), Half<T>::from(0.f), Half<T>::from(0.f)};
+                        hw[q] = __builtin_bit_cast(uint2, h2).x;
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(hw[4 * pr], hw[4 * pr + 2], false, false);          // columns 0, 1 of the lane's four
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(hw[4 * pr + 1], hw[4 * pr + 3], false, false);      // columns 2, 3
+                        const i32x4_buf o = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                        if (!GEMM_NOSTORE) buf_st16<GEMM_NT ? 2 : 0>(o, obuf, ovoff + (16 * j * ldh + 64 * ih + 32 * pr) * 2);
+                    }
+                }
+            }
+#else
             constexpr int HP_LD = 72;     // halves per slab row (64 n + 8 pad = 144 B)
             T* slab = (T*)(smem + 2 * STAGE2 + wid * (16 * HP_LD * 2));
             // this wave's 64 rows x 128 columns of the output as a raw buffer that ends with the last valid row (see buf_rsrc)
@@ -710,6 +823,32 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#if GEMM_GELU_CHAINS
+                    // the chunk's 16 values per lane as 8 pairs, so that the activation runs as 8 chains side by side (gelu_erf2xN)
+                    f32x2 v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // LayerNorm of the A rows folded in: rstd * acc + ((-mu rstd) * s[n] + bias'[n])
+                            if (LNA) v[2 * i + (e >> 1)][e & 1] = __builtin_fmaf(rst[j].x, acc[4 * ih + i][j][e], __builtin_fmaf(rst[j].y, sv[i][e], bv[i][e]));
+                            else v[2 * i + (e >> 1)][e & 1] = acc[4 * ih + i][j][e] + bv[i][e];
+                        }
+                    }
+                    if constexpr (ACT == 1) gelu_erf2xN<8>(v);
+                    else if constexpr (ACT == 2) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = silu2(v[q]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ovf_see<T>(ovf_mx, v[2 * i][0], v[2 * i][1]);
+                        ovf_see<T>(ovf_mx, v[2 * i + 1][0], v[2 * i + 1][1]);
+                        v4 h;
+                        h[0] = Half<T>::from(v[2 * i][0]); h[1] = Half<T>::from(v[2 * i][1]); h[2] = Half<T>::from(v[2 * i + 1][0]); h[3] = Half<T>::from(v[2 * i + 1][1]);
+                        *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;
+                    }
+#else
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         f32x4 v;
@@ -728,6 +867,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
                         *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;
                     }
+#endif
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) {
@@ -738,6 +878,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next chunk overwrites it
                 }
             }
+#endif
         } else if constexpr (fast_resid) {
             // out = half( resid * alpha + acc + bias ), the sum formed in fp32 AFTER the transpose (fp32 slab), so the residual is read and the
             // result written as row-contiguous 16-byte vectors and nothing is rounded twice.  LNR: resid = LayerNorm(lnr_y) applied on the
@@ -833,9 +974,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     if (STATS) {
                         // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
                         // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
-                        const f32x4 q0 = o0 * o0, q1 = o1 * o1;
-                        float s1 = (o0[0] + o0[1]) + (o0[2] + o0[3]) + ((o1[0] + o1[1]) + (o1[2] + o1[3]));
-                        float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+                        float s1, s2;
+                        stats8(o0, o1, s1, s2);
                         s1 = seg8_sum(s1); s2 = seg8_sum(s2);
                         __builtin_amdgcn_raw_buffer_store_b64((i32x2_buf){__builtin_bit_cast(int, s1), __builtin_bit_cast(int, s2)}, sbuf,
                                                               svoff + (16 * j + 8 * ps) * nseg_out * 8 + 8 * ih, 0, 0);
@@ -942,9 +1082,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                                 st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                             }
                             if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
-                                const f32x4 q0 = v0 * v0, q1 = v1 * v1;     // same order as EPI 2
-                                float s1 = (v0[0] + v0[1]) + (v0[2] + v0[3]) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-                                float s2 = (q0[0] + q0[1]) + (q0[2] + q0[3]) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+                                float s1, s2;
+                                stats8(v0, v1, s1, s2);      // the function EPI 2 uses: same bits
                                 s1 = seg8_sum(s1); s2 = seg8_sum(s2);
                                 if (ec == 0)
                                     *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((en0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
@@ -980,7 +1119,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         ovf_lanes |= ovf_mask<T>(ovf_mx);
         AVX_STAMP(if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime(););
         if (!has_next) break;
-        prev_full = em0 + T2 <= p.M;
         {   // the next tile's 8 source pointers (16 registers) are computed a second time here instead of being carried through the
             // epilogue, which needs every register it can get (the barrier on the tile id keeps the two computations apart)
             int t2 = next_tile;
@@ -1231,8 +1369,8 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
         const int tiles = ((a.M + T2 - 1) / T2) * (a.N / T2);
         avx::GemmArgs a5 = a;
-        static const int order = getenv("AVEX_AMD_GEMM_TILE_ORDER") ? atoi(getenv("AVEX_AMD_GEMM_TILE_ORDER")) : 0;
-        a5.tile_order = order;
+        const char* eo = getenv("AVEX_AMD_GEMM_TILE_ORDER");      // read per launch: A/B runs switch it inside one process
+        a5.tile_order = eo ? atoi(eo) : 0;
         a5.nt = gemm_nt_mode(a);
         int grid = tiles < n_cu ? ((tiles + 7) / 8) * 8 : (n_cu / 8) * 8;
         if (grid < 8) grid = 8;

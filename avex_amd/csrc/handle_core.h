@@ -303,6 +303,8 @@ struct CoreCfg {
     int act = 1;                  // GemmArgs::gelu code of the FFN activation (0 none, 1 erf GELU, 2 SiLU, 3 ReLU, 4 tanh GELU, 5 tanh)
     bool glu = false;             // fc1 is the reference's GLU_Linear(E, F, "swish"): one Linear to 2F, then value * swish(gate) (backbone.py:296-297)
     bool pre_ln = false;          // pre-LN blocks (backbone.py:328-348): x += attn(LN1 x); x += ffn(LN2 x); `final_ln` after the stack (:146-147)
+    bool batch_invariant = false; // residual_dtype bit 1 (AVEXHIP_RESIDUAL_BATCH_INVARIANT): a clip's outputs must not depend on the batch it arrives in --
+                                  // fold at every size, no split-K, no LayerNorm inside a split-K epilogue, one final LayerNorm + pool path
     const float* final_ln_w = nullptr; const float* final_ln_b = nullptr;
 };
 
@@ -312,13 +314,19 @@ struct CoreCfg {
 // 2.22 -> 1.66, eight 2.28 -> 2.00; from sixteen clips on (7 936 rows) the fold is level or ahead (profiles/r03r_midsize.txt).
 // "1": fold whatever the size -- a clip's embedding is then bit-identical whether it came alone or in a batch of 256 (with "auto" the two
 // differ in their last bits, both inside the parity bar).  "0": never fold.
-inline void fold_policy(bool fast, int E, int F, bool* fold, int* min_rows) {
+// residual_dtype of the handle configs: bit 0 = residual stream in the operand type, bit 1 = batch-invariant results
+inline bool cfg_fast(int residual_dtype) { return (residual_dtype & 1) != 0; }
+inline bool cfg_batch_invariant(int residual_dtype) {
+    const char* e = getenv("AVEX_AMD_BATCH_INVARIANT");      // the environment can only turn it ON (for callers that cannot reach the config)
+    return (residual_dtype & 2) != 0 || (e && atoi(e) != 0);
+}
+inline void fold_policy(bool fast, int E, int F, bool* fold, int* min_rows, bool batch_invariant = false) {
     const char* e = getenv("AVEX_AMD_LN_FOLD");
     const bool is_auto = !e || e[0] == 'a' || e[0] == 'A';
     *fold = fast && E % 256 == 0 && F % 256 == 0 && !(e && !is_auto && atoi(e) == 0);
     int rows = 4096;
     if (e && is_auto) { const char* c = strchr(e, ':'); if (c && atoi(c + 1) > 0) rows = atoi(c + 1); }      // "auto:4096": another threshold (experiments)
-    *min_rows = is_auto ? rows : 0;
+    *min_rows = is_auto && !batch_invariant ? rows : 0;
 }
 
 // upload layer i (and, with the fold, its LayerNorm-folded copies; layer i - 1 must have been built)
@@ -457,7 +465,9 @@ inline Tap tap_begin(const CoreCfg& c, const CoreWs& w, const CoreIo& io, int la
     // ... where that kernel is the one the product takes anyway (a folded LayerNorm, or enough tiles): a pooled tap must not change which
     // kernel computes the layer, or its max / first-token values would differ in their last bits from the same reduction of the full tap
     const bool streams = g.ln_rows || g.lnr_y || g.stats_out || avx::gemm_streams(g.M, g.N);
-    t.fused = io.hook_pooled && io.Tt >= 64 && c.E % 256 == 0 && g.K >= 128 && streams && !no_fuse;
+    // batch-invariant handles do not fuse the MEAN: its partial sums are grouped by 64-row blocks of the whole batch, so a clip's mean would
+    // depend on where the clip starts (maxima and first rows are exact and stay fused)
+    t.fused = io.hook_pooled && io.Tt >= 64 && c.E % 256 == 0 && g.K >= 128 && streams && !no_fuse && !(c.batch_invariant && io.hook_pooled == 1);
     if (t.fused) {
         g.pool_T = io.Tt; g.pool_mode = io.hook_pooled - 1;
         g.pool_part = io.hook_pooled == 3 ? t.out : w.pool;      // the first rows go straight to the caller's [B, E]
@@ -468,6 +478,12 @@ inline int tap_finish(const Tap& t, const CoreCfg& c, const CoreWs& w, const Cor
     if (!t.hooked || !io.hook_pooled) return AVEXHIP_OK;
     if (t.fused) return io.hook_pooled == 3 ? AVEXHIP_OK : avx::pool_reduce(w.pool, io.Bc, io.Tt, c.E, t.out, c.E, cs, io.hook_pooled - 1);
     return avx::agg_pool(w.raw, io.Bc, io.Tt, c.E, io.hook_pooled, t.out, cs);
+}
+
+// batch-invariant handles: every layer product in the 256-tile streaming kernel whatever its row count (the 128-tile kernel's residual
+// epilogue multiplies and adds where the streaming kernel's fuses, and its split-K adds in another order)
+inline void pin_kernel(const CoreCfg& c, avx::GemmArgs& g) {
+    if (c.batch_invariant && g.variant == 0 && g.N % 256 == 0 && g.K >= 128 && g.M >= 2) g.variant = 5;
 }
 
 inline int self_attention(HandleBase* h, const CoreCfg& c, const Layer& ly, const CoreWs& w, const CoreIo& io, hipStream_t cs) {
@@ -482,6 +498,7 @@ inline int ffn_hidden(HandleBase* h, const CoreCfg& c, const CoreWs& w, avx::Gem
     int rc;
     if (c.glu) { g.N = 2 * c.F; g.gelu = 0; g.out_half = w.hh2; g.ldh = 2 * c.F; }
     prof.begin("gemm.fc1", flops);
+    pin_kernel(c, g);
     rc = avx::gemm(g, h->dtype, cs);
     prof.end();
     if (rc != AVEXHIP_OK || !c.glu) return rc;
@@ -513,7 +530,7 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         g.A = w.ah; g.lda = E; g.W = ly.w_qkv; g.ldw = E; g.M = M; g.N = 3 * E; g.K = E; g.bias = ly.b_qkv;
         g.out_half = w.qkv; g.ldh = 3 * E;
         prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
-        RC(avx::gemm(g, dt, cs));
+        pin_kernel(c, g); RC(avx::gemm(g, dt, cs));
         prof.end();
         prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
         RC(self_attention(h, c, ly, w, io, cs));
@@ -525,7 +542,7 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         Tap tap_o;
         if (c.hook_site == 1) tap_o = tap_begin(c, w, io, i, g);
         prof.begin("gemm.out_proj", 2.0 * Md * E * E);
-        RC(avx::gemm(g, dt, cs));
+        pin_kernel(c, g); RC(avx::gemm(g, dt, cs));
         prof.end();
         RC(tap_finish(tap_o, c, w, io, cs));
         prof.begin("layernorm", 0.0);
@@ -537,18 +554,18 @@ inline int run_layers_pre_ln(HandleBase* h, const CoreCfg& c, const std::vector<
         RC(ffn_hidden(h, c, w, g, M, prof, cs));
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
-        if (M <= 8192) { g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes; }
+        if (M <= 8192 && !c.batch_invariant) { g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes; }
         if (fast) { g.resid_half = s1_h; g.ldrh = E; g.out_half = s0_h; g.ldh = E; }
         else { g.resid = s1_32; g.ldr = E; g.out_f32 = s0_32; g.ldo = E; }
         Tap tap_f;
         if (c.hook_site == 0) tap_f = tap_begin(c, w, io, i, g);
         prof.begin("gemm.fc2", 2.0 * Md * E * F);
-        RC(avx::gemm(g, dt, cs));
+        pin_kernel(c, g); RC(avx::gemm(g, dt, cs));
         prof.end();
         RC(tap_finish(tap_f, c, w, io, cs));
     }
     if (L > 0 && (io.features_out || io.pooled_out)) {      // the encoder's LayerNorm after the stack (backbone.py:146-147)
-        const bool fused_pool = io.pooled_out && !io.features_out && fast && E % 8 == 0 && E <= 768 && Bc >= 32;
+        const bool fused_pool = io.pooled_out && !io.features_out && fast && E % 8 == 0 && E <= 768 && (Bc >= 32 || c.batch_invariant);
         if (fused_pool) {
             prof.begin("layernorm+mean_pool", 0.0);
             RC(avx::layernorm_pool(s0_h, E, c.final_ln_w, c.final_ln_b, c.eps, Bc, Tt, E, io.pooled_out + io.c0 * E, dt, cs));
@@ -597,7 +614,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         g.out_half = w.qkv; g.ldh = 3 * E;
         if (raw_in) { g.W = ly.w_qkv_f; g.bias = ly.b_qkv_f; g.ln_rows = w.r2; g.ln_s = ly.s_qkv; }
         prof.begin("gemm.qkv", 2.0 * Md * 3 * E * E);
-        RC(avx::gemm(g, dt, cs));
+        pin_kernel(c, g); RC(avx::gemm(g, dt, cs));
         prof.end();
         prof.begin("attention", 4.0 * Md * Tt * E + (ly.grep_w ? 2.0 * Md * 8 * (E / H) * H : 0.0));
         RC(self_attention(h, c, ly, w, io, cs));
@@ -618,7 +635,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         // few rows, no fold: LayerNorm 1 rides in the split-K epilogue of the product (one kernel less per layer; x32 / xh are read as the
         // residual and rewritten row by row by the same wave)
         bool ln1_fused = false;
-        if (!fold && F > 0 && M <= 8192) {
+        if (!fold && F > 0 && M <= 8192 && !c.batch_invariant) {
             g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes;
             if (avx::gemm_post_ln_ok(g)) {
                 g.post_ln_w = ly.ln1_w; g.post_ln_b = ly.ln1_b; g.post_ln_eps = c.eps; g.post_ln_round = fast ? 1 : 0;
@@ -627,7 +644,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             } else { g.splitk_ws = nullptr; g.splitk_bytes = 0; }
         }
         prof.begin("gemm.out_proj", 2.0 * Md * E * E);
-        RC(avx::gemm(g, dt, cs));
+        pin_kernel(c, g); RC(avx::gemm(g, dt, cs));
         prof.end();
         RC(tap_finish(tap_o, c, w, io, cs));
         if (F == 0) {      // attention-only block: LN1 closes it
@@ -663,7 +680,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         const bool last = i == L - 1;
         memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
         g.A = w.hh; g.lda = F; g.W = ly.w_fc2; g.ldw = F; g.M = M; g.N = E; g.K = F; g.bias = ly.b_fc2; g.alpha = c.alpha;
-        if (M <= 8192) { g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes; }
+        if (M <= 8192 && !c.batch_invariant) { g.splitk_ws = w.splitk; g.splitk_bytes = w.splitk_bytes; }      // (split-K adds in another order than one pass over K)
         if (fast) { g.resid_half = w.xh; g.ldrh = E; g.out_half = preh; g.ldh = E; }
         else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
         if (fold) {   // residual = LN1(y1) on the fly; y2 (raw) goes to xh, which nothing reads any more in this layer
@@ -678,7 +695,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         if (last) xo = io.features_out ? io.features_out + io.c0 * Tt * E : ((io.pooled_out || !fast) ? x32 : nullptr);
         else if (!fast) xo = x32;
         // pooled embedding only (the headline path): final LayerNorm and the mean over tokens in one pass, no fp32 feature tensor
-        const bool fused_pool = last && io.pooled_out && !io.features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && Bc >= 32;
+        const bool fused_pool = last && io.pooled_out && !io.features_out && preh && !pre32 && E % 8 == 0 && E <= 768 && (Bc >= 32 || c.batch_invariant);
         // few rows, no fold: LayerNorm 2 in the split-K epilogue (as LayerNorm 1 above)
         bool ln2_fused = false;
         if (!fold && !fused_pool && (xo || !last) && avx::gemm_post_ln_ok(g)) {
@@ -687,7 +704,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             ln2_fused = true;
         }
         prof.begin("gemm.fc2", 2.0 * Md * E * F);
-        RC(avx::gemm(g, dt, cs));
+        pin_kernel(c, g); RC(avx::gemm(g, dt, cs));
         prof.end();
         RC(tap_finish(tap_f, c, w, io, cs));
         if (fold && !last) {

@@ -26,11 +26,14 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        import datetime
+        timeout = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "180")))      # a rank that never arrives fails the job instead of hanging it
         if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank), timeout=timeout)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=timeout)
     return rank, world, local_rank
 
 
@@ -74,8 +77,13 @@ class PipelinedGather:
     next overwrites it.
     """
 
-    def __init__(self, group=None, force: bool = False) -> None:
+    def __init__(self, group=None, force: bool = False, measure: bool = False) -> None:
         self.group = group
+        # measure: time what the consumer actually WAITED for each gather (``exposed_ms``): on a GPU two events on the compute stream
+        # around the stream dependency (0 when the collective had finished under the next batch's kernels), on the CPU the blocking wait
+        self.measure = bool(measure)
+        self._waits: List[Tuple[Any, Any]] = []
+        self._cpu_wait_s = 0.0
         # force: go through the collective with a single rank too (scripts/rccl_one_rank.py: the only way to execute the RCCL leg on a
         # one-GPU box)
         self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
@@ -98,7 +106,19 @@ class PipelinedGather:
         self._pending = None
         if work is None:                       # single process: the "buffer" is the input itself
             return buf
-        work.wait()
+        if self.measure and buf.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            self._waits.append((e0, e1))
+        elif self.measure:
+            import time
+            t0 = time.perf_counter()
+            work.wait()
+            self._cpu_wait_s += time.perf_counter() - t0
+        else:
+            work.wait()
         sizes = [shard_bounds(n_total, r, self.world) for r in range(self.world)]
         width = max(hi - lo for lo, hi in sizes)
         if all(hi - lo == width for lo, hi in sizes):
@@ -131,6 +151,16 @@ class PipelinedGather:
 
     def flush(self) -> Optional[torch.Tensor]:
         return self._finish()
+
+    def exposed_ms(self, reset: bool = True) -> float:
+        """Milliseconds the consumer waited for gathers since the last reset (``measure=True``; synchronises the device)."""
+        ms = 1e3 * self._cpu_wait_s
+        if self._waits:
+            torch.cuda.synchronize()
+            ms += sum(a.elapsed_time(b) for a, b in self._waits)
+        if reset:
+            self._waits, self._cpu_wait_s = [], 0.0
+        return ms
 
 
 def extract_embeddings_sharded(embed_fn: Callable[[torch.Tensor], torch.Tensor], wav: torch.Tensor,

@@ -35,7 +35,7 @@ class EatEncoder:
     and the workspace."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype: str = "f16", prefix: str = "backbone.model.",
-                 norm_mean: float = -4.268, norm_std: float = 4.569, max_chunk_clips: int = 0, residual: str = "half") -> None:
+                 norm_mean: float = -4.268, norm_std: float = 4.569, max_chunk_clips: int = 0, residual: str = "half", batch_invariant: bool = False) -> None:
         _capi.require_gpu()
         self.cfg = dict(cfg)
         self.dtype = operand_dtype
@@ -52,7 +52,7 @@ class EatEncoder:
         c.norm_eps, c.norm_mean, c.norm_std = self.eps, float(norm_mean), float(norm_std)
         c.operand_dtype = _capi.dtype_code(operand_dtype)
         c.max_chunk_clips = int(max_chunk_clips)
-        c.residual_dtype = K.RESIDUAL_CODES[str(residual).lower()]
+        c.residual_dtype = K.residual_code(residual, batch_invariant)
         sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
         arr, n, keep = K.tensor_table(sub)
         self._h = _capi.lib().avexhip_eat_create(C.byref(c), arr, n)

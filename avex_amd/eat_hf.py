@@ -17,6 +17,8 @@ fairseq checkpoint.  Inference only; no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import logging
 from collections import OrderedDict
 from typing import Any, Dict, List, Optional, Union
@@ -102,7 +104,8 @@ class EATHFModel(ModelBase):
     def __init__(self, *, model_name: str = "worstchan/EAT-base_epoch30_pretrain", num_classes: Optional[int] = None, device: str = "cuda",
                  audio_config: Optional[Dict[str, Any]] = None, target_length: int = 1024, pooling: str = "cls",
                  fairseq_weights_path: Optional[str] = None, norm_mean: float = -4.268, norm_std: float = 4.569,
-                 return_features_only: bool = False, operand_dtype: str = "f16", init_config: Optional[Dict[str, Any]] = None) -> None:
+                 return_features_only: bool = False, operand_dtype: str = "f16", init_config: Optional[Dict[str, Any]] = None,
+                 batch_invariant: Optional[bool] = None) -> None:
         super().__init__(device=device, audio_config=audio_config)
         if num_classes is None:
             num_classes = 0
@@ -114,6 +117,8 @@ class EATHFModel(ModelBase):
         self.audio_config = audio_config
         self.model_name = model_name
         self.operand_dtype = operand_dtype
+        # a clip's outputs bit-identical whatever batch it arrives in (kernels.residual_code; environment: AVEX_AMD_BATCH_INVARIANT=1)
+        self.batch_invariant = bool(batch_invariant) if batch_invariant is not None else os.environ.get("AVEX_AMD_BATCH_INVARIANT", "0") not in ("", "0")
         self.norm_mean, self.norm_std = norm_mean, norm_std
         self.config = dict(EAT_BASE_CFG, target_length=target_length)
         if init_config:
@@ -170,7 +175,8 @@ class EATHFModel(ModelBase):
                 raise AvexHipError(f"EAT parameters live on {p.device}; the avex_amd path runs on a GPU only (no CPU fallback)")
             with torch.cuda.device(p.device):
                 state = {"backbone." + k: v for k, v in self.backbone.state_dict().items()}
-                self._encoder = EatEncoder(self.config, state, operand_dtype=self.operand_dtype, norm_mean=self.norm_mean, norm_std=self.norm_std)
+                self._encoder = EatEncoder(self.config, state, operand_dtype=self.operand_dtype, norm_mean=self.norm_mean, norm_std=self.norm_std,
+                                           batch_invariant=self.batch_invariant)
             self._weights_dirty = False
         return self._encoder
 

@@ -62,7 +62,7 @@ def _check_same_batches(batch: Dict[str, Any], tdist: Any, group: Any, device: t
 def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]], target_layers: List[Any],
                                  device: Any, aggregation: str = "mean", disable_tqdm: bool = True,
                                  disable_layerdrop: Optional[bool] = None, prefetch: Optional[bool] = None,
-                                 sharded: bool = False, group: Any = None
+                                 sharded: bool = False, group: Any = None, batch_invariant: Optional[bool] = None
                                  ) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, List[tuple]]:
     """Run ``model.extract_embeddings`` over every batch of ``dataloader`` and stack the results on the CPU
     (reference: embedding_utils.py:26-144; ``disable_tqdm`` is accepted for signature compatibility, no progress bar here).
@@ -73,9 +73,16 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
     reference's loop is single-device, run_evaluate.py:1053).  It is NOT the default: a multi-rank caller with a
     ``DistributedSampler`` -- the usual set-up -- hands every rank DIFFERENT batches, and sharding those would gather rows of unrelated
     clips beside the local labels without any visible failure.  The first batch's signature (clip count, samples, a checksum of the
-    audio and of the labels) is compared across ranks and a mismatch raises ``RuntimeError``."""
+    audio and of the labels) is compared across ranks and a mismatch raises ``RuntimeError``.
+
+    ``batch_invariant`` (``True`` / ``False``; default: leave the model as it is): make the model's HIP handle give every clip the same
+    bits whatever batch it arrives in -- the loop's last, partial batch then rounds exactly like the full ones (``kernels.residual_code``;
+    the reference's fp32 path is batch-independent, beats_model.py:279-429).  The handle is rebuilt if the setting changes."""
     from . import dist as adist
     import torch.distributed as tdist
+    if batch_invariant is not None and hasattr(model, "batch_invariant") and bool(model.batch_invariant) != bool(batch_invariant):
+        model.batch_invariant = bool(batch_invariant)
+        model._weights_dirty = True      # the next forward builds its handle again, with the other policy
     world = tdist.get_world_size(group) if tdist.is_available() and tdist.is_initialized() else 1
     rank = tdist.get_rank(group) if world > 1 else 0
     sharded = bool(sharded) and world > 1

@@ -614,10 +614,22 @@ _CFG_FIELDS = ("input_patch_size", "embed_dim", "encoder_layers", "encoder_embed
 
 
 RESIDUAL_CODES = {"f32": 0, "fp32": 0, "float32": 0, "half": 1, "f16": 1, "bf16": 1, "operand": 1}
+RESIDUAL_BATCH_INVARIANT = 2      # AVEXHIP_RESIDUAL_BATCH_INVARIANT: OR-ed into residual_dtype (include/avexhip.h)
+
+
+def residual_code(residual, batch_invariant: bool = False) -> int:
+    """``residual_dtype`` of the handle configs: "f32" / "half" (+ the batch-invariance bit: a clip's outputs are then bit-identical
+    whatever batch it arrives in -- LayerNorm fold at every size, no split-K, one final LayerNorm + pool path; the reference's fp32 path
+    is batch-independent, beats_model.py:279-429)."""
+    try:
+        code = RESIDUAL_CODES[str(residual).lower()]
+    except KeyError as e:
+        raise ValueError(f"residual must be 'f32' or 'half', got {residual!r}") from e
+    return code | (RESIDUAL_BATCH_INVARIANT if batch_invariant else 0)
 
 
 def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0,
-                      residual="half") -> BeatsConfig:
+                      residual="half", batch_invariant: bool = False) -> BeatsConfig:
     act = str(cfg.get("activation_fn", "gelu"))
     if act not in _capi.FFN_CODES:
         raise RuntimeError(f"--activation-fn {act} not supported")      # the reference's own error (modules.py:237)
@@ -641,10 +653,7 @@ def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_
     c.fbank_std = float(cfg.get("fbank_std", 6.55582))
     c.operand_dtype = dtype_code(operand_dtype)
     c.max_chunk_clips = int(max_chunk_clips)
-    try:
-        c.residual_dtype = RESIDUAL_CODES[str(residual).lower()]
-    except KeyError as e:
-        raise ValueError(f"residual must be 'f32' or 'half', got {residual!r}") from e
+    c.residual_dtype = residual_code(residual, batch_invariant)
     return c
 
 
@@ -767,7 +776,7 @@ class BeatsEncoder:
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype="f16",
-                 max_chunk_clips: int = 0, residual="half", on_overflow: Optional[str] = None) -> None:
+                 max_chunk_clips: int = 0, residual="half", on_overflow: Optional[str] = None, batch_invariant: bool = False) -> None:
         """``on_overflow``: what to do when an f16 conversion inside the forward clipped a value to +-65504 (the handle's sticky range
         alarm, ``avexhip_beats_overflow_count``; the reference computes in fp32 and has no such limit, backbone.py:350-375):
         ``"warn"`` (default; checked without synchronising, so the warning may come one call late), ``"raise"``, ``"retry"`` (the
@@ -782,7 +791,8 @@ class BeatsEncoder:
         self._overflow_seen = 0
         self._fallback: Optional["BeatsEncoder"] = None
         self._fallback_args = (dict(cfg), state, max_chunk_clips) if self.on_overflow == "retry" and dtype_code(operand_dtype) == _capi.F16 else None
-        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual)
+        self.batch_invariant = bool(batch_invariant)      # a clip's outputs do not depend on the batch it arrives in (bit for bit); see residual_code
+        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual, self.batch_invariant)
         self.E = int(cfg["encoder_embed_dim"])
         self.L = int(cfg["encoder_layers"])
         arr, n, keep = tensor_table(state)
@@ -851,7 +861,7 @@ class BeatsEncoder:
                 if self.on_overflow == "retry" and self._fallback_args is not None:
                     if self._fallback is None:
                         fcfg, fstate, fchunk = self._fallback_args
-                        self._fallback = BeatsEncoder(fcfg, fstate, operand_dtype="bf16", max_chunk_clips=fchunk, residual="f32", on_overflow="ignore")
+                        self._fallback = BeatsEncoder(fcfg, fstate, operand_dtype="bf16", max_chunk_clips=fchunk, residual="f32", on_overflow="ignore", batch_invariant=self.batch_invariant)
                     logger.warning(msg + "  Re-running the batch with bf16 operands and an fp32 residual stream.")
                     return self._fallback.forward(wav, hook_layers=hook_layers, hook_pooled=hook_pooled, want_features=want_features,
                                                   want_pooled=want_pooled, frame_pad=frame_pad)

@@ -27,32 +27,50 @@ FLOP_PER_CLIP = 98.7e9      # SURVEY.md §8d (FFN 56.17, QKV/out 28.09, SDPA 9.0
 PEAK_TFLOPS = 2500.0        # dense bf16/f16 MFMA peak, MI355X_MICROARCH.md
 
 
-def cpu_baseline(sd, cfg, seconds_budget=20.0):
-    """Time the oracle (checker, never shipped) on a bounded sample of the same workload."""
-    import numpy as np
+def cpu_baseline_worker(seconds_budget: float) -> None:
+    """One worker of the CPU baseline (a fresh process started by cpu_baseline; never touches the GPU): the oracle on one clip at a
+    time for `seconds_budget` seconds, BLAS threads as the environment says; prints {"clips", "seconds"}."""
     from avex_amd import synth
     from oracle import beats_oracle as O
-    threads = min(os.cpu_count() or 1, 32)     # OpenBLAS scales poorly past ~32 threads on these GEMM sizes
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=threads)
-    except Exception:  # noqa: BLE001
-        import contextlib
-        ctx = contextlib.nullcontext()
-        threads = os.cpu_count() or 1
-    n = 4
-    x = synth.noise_clips(n, SAMPLES, seed=0)
-    with ctx:
-        O.beats_forward(x[:1], sd, cfg)                      # warm-up (BLAS threads, page-in)
-        t0 = time.time()
-        done = 0
-        while True:
-            f, _ = O.beats_forward(x, sd, cfg)
-            O.pooled(f)
-            done += n
-            el = time.time() - t0
-            if el > seconds_budget or done >= 64:
-                break
+    cfg = synth.BEATS_BASE_CFG
+    sd = synth.beats_state_dict(cfg, seed=0)
+    x = synth.noise_clips(2, SAMPLES, seed=0)
+    O.beats_forward(x[:1], sd, cfg)                      # warm-up (BLAS threads, page-in)
+    t0 = time.time()
+    done = 0
+    while True:
+        f, _ = O.beats_forward(x[done % 2: done % 2 + 1], sd, cfg)
+        O.pooled(f)
+        done += 1
+        el = time.time() - t0
+        if el > seconds_budget or done >= 256:
+            break
+    print(json.dumps({"clips": done, "seconds": el}), flush=True)
+
+
+def cpu_baseline(sd, cfg, seconds_budget=20.0):
+    """Time the oracle (checker, never shipped) on a bounded sample of the same workload, the way a CPU job would run it: clips are
+    independent, so W worker processes of 4 BLAS threads each embed clips side by side (one OpenBLAS pool over all cores spends most of
+    its time synchronising on 496-row products: 1.4 clips/s on 32 threads in round 3, below the reference's own 2.6 on 8).  The workers
+    are fresh processes (this one has initialised the GPU and must not fork)."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    per = 4 if cores >= 8 else max(1, cores // 2)
+    workers = max(1, min(cores // per, 16))
+    env = dict(os.environ, OPENBLAS_NUM_THREADS=str(per), OMP_NUM_THREADS=str(per), MKL_NUM_THREADS=str(per))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(seconds_budget)]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
+    rate, clips, secs = 0.0, 0, 0.0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=seconds_budget * 4 + 120)
+            j = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+            rate += j["clips"] / j["seconds"]
+            clips += j["clips"]
+            secs = max(secs, j["seconds"])
+        except Exception:  # noqa: BLE001
+            p.kill()
     fixture = None
     try:        # the real reference (PyTorch fp32) timed once in the development container when the goldens were made: a fixture, not this host
         j = json.load(open(os.path.join(ROOT, "tests", "golden", "base_api.json")))
@@ -60,8 +78,9 @@ def cpu_baseline(sd, cfg, seconds_budget=20.0):
                    "host": j.get("cpu_reference_host"), "sample": "4 clips x 10 s, avex BEATs forward, recorded by tests/golden/make_goldens.py"}
     except Exception:  # noqa: BLE001
         pass
-    return {"value": round(done / el, 3), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{done} clips x 10 s through oracle/beats_oracle.py (NumPy fp32, OpenBLAS limited to {threads} threads), {el:.1f} s",
+    return {"value": round(rate, 3), "unit": "clips/s", "cores": workers * per, "kind": "port",
+            "sample": f"{clips} clips x 10 s through oracle/beats_oracle.py (NumPy fp32) in {workers} worker processes x {per} OpenBLAS threads, "
+                      f"{secs:.1f} s each ({time.time() - t0:.0f} s wall with start-up); host has {cores} logical cores",
             "reference_fixture": fixture}
 
 
@@ -317,11 +336,28 @@ def launch_ranks(n: int) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault("NCCL_DEBUG", "WARN")                    # RCCL warnings on stderr; on failure the tail is printed below
+    import collections
+    import threading
+    tail = collections.deque(maxlen=80)
+
+    def pump():      # stderr passes through live AND its tail is kept for the failure report
+        for ln in proc.stderr:
+            sys.stderr.write(ln)
+            tail.append(ln)
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
     for ln in proc.stdout:           # rank 0's single JSON line (and nothing else on stdout) passes through unchanged
         sys.stdout.write(ln)
         sys.stdout.flush()
-    return proc.wait()
+    rc = proc.wait()
+    th.join(timeout=5)
+    if rc != 0:
+        sys.stderr.write(f"[bench launcher] {n} ranks exited with code {rc}; last lines of their stderr (NCCL_DEBUG={env.get('NCCL_DEBUG')}, "
+                         f"HSA_ENABLE_IPC_MODE_LEGACY={env.get('HSA_ENABLE_IPC_MODE_LEGACY')}, master 127.0.0.1:{port}):\n" + "".join(tail))
+    return rc
 
 
 def main():
@@ -340,8 +376,12 @@ def main():
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="tests only: run the launch / barrier / timing / all-gather / JSON control flow on the CPU with gloo and a stub "
                          "in place of the encoder (no number it prints is a measurement)")
+    ap.add_argument("--cpu-baseline-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_baseline_worker > 0:
+        cpu_baseline_worker(args.cpu_baseline_worker)      # a worker of the cpu_baseline leg: NumPy only, no torch, no GPU
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # plain `python bench.py --gpus N`: this parent never touches the GPU
 
@@ -367,11 +407,23 @@ def main():
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")                   # RCCL's warnings go to stderr: the launcher keeps the tail of every rank's
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts
+        timeout = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "180")))
+        try:
+            if dry:
+                dist.init_process_group(backend="gloo", timeout=timeout)
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=timeout)
+            dist.barrier()                                            # the first collective: communicator set-up (xGMI rings) happens here
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}/{world} local {local_rank}] rendezvous / first collective FAILED after <= {timeout.seconds} s: {e!r}; "
+                  f"MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} backend={'gloo' if dry else 'nccl'} "
+                  f"visible devices={torch.cuda.device_count() if not dry else 'cpu'}", file=sys.stderr, flush=True)
+            sys.exit(3)
 
     from avex_amd import build, synth
     cfg = synth.BEATS_BASE_CFG
@@ -399,7 +451,7 @@ def main():
     # stream under the kernels of step n + 1 and is waited for one step later; the last one is flushed inside the timed region, so
     # K steps are K forwards + K completed gathers ("overlap gather(n) with compute(n+1)")
     from avex_amd.dist import PipelinedGather
-    pipe = PipelinedGather() if world > 1 else None
+    pipe = PipelinedGather(measure=True) if world > 1 else None
 
     def step():
         r = enc.forward(wav, want_features=False, want_pooled=True)
@@ -412,6 +464,7 @@ def main():
         out = step()
     if pipe is not None:
         out = pipe.flush()
+        pipe.exposed_ms()            # (reset: the warm-up's waits are not the timed region's)
         dist.barrier()
     sync()
     t0 = time.perf_counter()
@@ -420,14 +473,27 @@ def main():
     if pipe is not None:
         out = pipe.flush()
     sync()
+    own_elapsed = time.perf_counter() - t0      # this rank's K steps + K completed gathers, before it waits for the others
     if world > 1:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank view, so that a slow first 8-GPU run says WHERE it is slow: each rank's own time for the K steps and the time its
+        # compute stream spent waiting for gathers that had not finished under the next step's kernels
+        mine = torch.tensor([own_elapsed, pipe.exposed_ms() / 1e3], dtype=torch.float64, device=dev)
+        allr = torch.empty((world * 2,), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().reshape(world, 2)
+        ms = (allr[:, 0] * 1e3 / args.steps).tolist()
+        ex = (allr[:, 1] * 1e3 / args.steps).tolist()
+        per_rank = {"ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3), "slowest_rank": int(max(range(world), key=lambda r: ms[r])),
+                    "ms_per_step": [round(v, 3) for v in ms],
+                    "exposed_gather_ms_per_step_max": round(max(ex), 4), "exposed_gather_ms_per_step_mean": round(sum(ex) / world, 4)}
     assert torch.isfinite(out).all()
 
     # ---- after the timed region: the gathered matrix is in clip order on every rank ----
@@ -528,11 +594,26 @@ def main():
                                         for k, v in tj["gemm256p_kernel_by_shape"].items() if k in alg}
             except Exception:  # noqa: BLE001
                 traffic = None
+        # rocprof-reported MFMA utilisation of the same kernel (north_star): SQ counters, one --pmc pass set per GEMM shape
+        # (scripts/pmc_gemm_sq.sh -> profiles/rNN_gemm_sq.json): "frac of the 2.4 GHz peak" = clock held / 2400 x matrix-pipe busy share x issue efficiency
+        sq = {}
+        sfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_gemm_sq.json")))
+        if sfiles:
+            try:
+                sj = json.load(open(sfiles[-1]))
+                tw = sj["layer_gemms_time_weighted"]
+                sq = {"mfma_busy_frac": tw["mfma_busy_frac"], "effective_clock_mhz": tw["effective_clock_mhz"],
+                      "mfma_busy_by_shape": {k: {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_mhz": v["effective_clock_mhz"]}
+                                             for k, v in sj.items() if k in ("qkv", "out", "fc1", "fc2")},
+                      "sq_source": "profiles/" + os.path.basename(sfiles[-1]) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE ...; busy = matrix-pipe busy cycles / "
+                                   "(shader cycles x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / kernel time)"}
+            except Exception:  # noqa: BLE001
+                sq = {}
         roof = {"bound": "mfma", "kernel": kernel_name, "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_by_shape": traffic_by_shape,
                 "algorithmic_tflop_per_launch": round(gemm_fl / n_gemm_launch / 1e12, 4),
                 "launches_per_step": n_gemm_launch, "avg_launch_ms": round(gemm_ms / n_gemm_launch, 4),
-                "gemm_share_of_step": round(gemm_ms / total_ms, 3),
+                "gemm_share_of_step": round(gemm_ms / total_ms, 3), **sq,
                 "note": "peak is the 2.4 GHz dense MFMA figure; this kernel (and the step as a whole) runs at the board's 1400 W power cap, "
                         "shader clock 1.5-1.9 GHz on random operands (profiles/r01c_gemm_power.txt, profiles/r01e_step_power.txt); a register-only MFMA loop "
                         "on random halves sustains 1.8 PFLOP/s under that cap, 1.4 with this kernel's LDS traffic (profiles/r01h_mfma_power.txt); "
@@ -555,7 +636,10 @@ def main():
                        "parallelism": f"dp{world}", "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else None), "gathered_rows_in_clip_order": gather_check,
                        "all_gather": (None if world == 1 else {"form": "non-blocking, overlapped with the next step's kernels, last one flushed inside the timed region",
-                                                               "blocking_ms": round(all_gather_ms, 4), "bytes_per_rank": B * 768 * 4}),
+                                                               "blocking_ms": round(all_gather_ms, 4), "bytes_per_rank": B * 768 * 4,
+                                                               "exposed_ms": per_rank["exposed_gather_ms_per_step_max"],
+                                                               "exposed_ms_how": "per step, the slowest rank: time its compute stream waited for a gather that had not finished under the next step's kernels (two events around the stream dependency)"}),
+                       "per_rank": per_rank,
                        "inputs": "avex_amd.synth.noise_clips(seed=0), keyed by global clip index",
                        "chunk_clips": args.chunk, "streams": max(1, min(4, int(os.environ.get("AVEX_AMD_STREAMS", "1") or 1))), "residual_stream": args.residual,
                        "layernorm_fold": bool(args.residual == "half" and os.environ.get("AVEX_AMD_LN_FOLD", "1") != "0"),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 6
+#define AVEXHIP_ABI_VERSION 7
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -369,16 +369,24 @@ typedef struct {
     float   fbank_std;               /* 6.55582 */
     int32_t operand_dtype;           /* AVEXHIP_F16 (default; parity 3e-4) or AVEXHIP_BF16 (2e-3) */
     int32_t max_chunk_clips;         /* clips processed per internal pass (0 = default 256) */
-    int32_t residual_dtype;          /* 0: residual stream + pre-LN sums kept fp32 between kernels (frame-level
+    int32_t residual_dtype;          /* bit 0 -- 0: residual stream + pre-LN sums kept fp32 between kernels (frame-level
                                         error 4e-4); 1: kept in the operand type (1.5e-3 frame level, pooled
                                         unchanged at 2.8e-4, ~25 % less HBM traffic).  Hook taps and the
-                                        features output are fp32 either way. */
+                                        features output are fp32 either way.
+                                        bit 1 (ABI 7) -- AVEXHIP_RESIDUAL_BATCH_INVARIANT, in every handle config that has
+                                        this field: a clip's outputs are bit-identical whatever batch it arrives in (the
+                                        LayerNorm fold at every batch size, no split-K, one final LayerNorm + pool path);
+                                        without it small batches take quicker kernels whose roundings differ in the last
+                                        bits (both inside the parity bar).  The reference's fp32 path is batch-independent
+                                        (beats_model.py:279-429). */
     /* ABI 6: the rest of BEATsConfig's architecture switches (beats.py:181-196); zero = the official checkpoints' values */
     int32_t layer_norm_first;        /* 0: post-LN blocks (backbone.py:350-375); 1: pre-LN blocks + LayerNorm after the stack
                                         (backbone.py:328-348, 146-147); excludes deep_norm (beats.py:275) */
     int32_t activation_fn;           /* AVEXHIP_FFN_* below (modules.py:203-237) */
     int32_t conv_bias;               /* 1: the patch embedding has a bias ("patch_embedding.bias", beats.py:263-269) */
 } avexhip_beats_config;
+
+#define AVEXHIP_RESIDUAL_BATCH_INVARIANT 2   /* OR into residual_dtype */
 
 /* activation_fn of the config: get_activation_fn's names (modules.py:203-237).  GLU = fc1 replaced by GLU_Linear(E, F, "swish")
  * (backbone.py:296-297): weights "fc1.linear.weight" [2F, E] / "fc1.linear.bias" [2F], hidden = y[:, :F] * swish(y[:, F:]). */

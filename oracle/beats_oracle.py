@@ -316,25 +316,35 @@ def attention(x: np.ndarray, p: Mapping[str, np.ndarray], pre: str, H: int, bias
     q = linear(x, p[pre + "q_proj.weight"], p[pre + "q_proj.bias"]).reshape(B, T, H, hd).transpose(0, 2, 1, 3)
     k = linear(x, p[pre + "k_proj.weight"], p[pre + "k_proj.bias"]).reshape(B, T, H, hd).transpose(0, 2, 1, 3)
     v = linear(x, p[pre + "v_proj.weight"], p[pre + "v_proj.bias"]).reshape(B, T, H, hd).transpose(0, 2, 1, 3)
-    scores = (q @ k.transpose(0, 1, 3, 2)) * np.float32(hd ** -0.5)          # SDPA scale (backbone.py:567)
-    if bias_hTT is not None:
-        if gru_rel_pos:
-            g8 = linear(q, p[pre + "grep_linear.weight"], p[pre + "grep_linear.bias"])   # [B,H,T,8]
-            g2 = g8.reshape(B, H, T, 2, 4).sum(-1, dtype=np.float32)
-            sg = (np.float32(1.0) / (np.float32(1.0) + np.exp(-g2))).astype(np.float32)
-            gate_a, gate_b = sg[..., 0:1], sg[..., 1:2]
-            grep_a = p[pre + "grep_a"].reshape(1, H, 1, 1)
-            gate = gate_a * (gate_b * grep_a - np.float32(1.0)) + np.float32(2.0)        # backbone.py:550
-            scores = scores + gate * bias_hTT[None]
-        else:
-            scores = scores + bias_hTT[None]
-    if key_padding_mask is not None:
-        scores = np.where(key_padding_mask[:, None, None, :], -np.inf, scores)
-    scores = scores.astype(np.float32, copy=False)
-    scores -= scores.max(axis=-1, keepdims=True)
-    e = np.exp(scores, out=scores)
-    e /= e.sum(axis=-1, keepdims=True, dtype=np.float32)
-    o = (e @ v).transpose(0, 2, 1, 3).reshape(B, T, E)
+    gate = None
+    if bias_hTT is not None and gru_rel_pos:
+        g8 = linear(q, p[pre + "grep_linear.weight"], p[pre + "grep_linear.bias"])   # [B,H,T,8]
+        g2 = g8.reshape(B, H, T, 2, 4).sum(-1, dtype=np.float32)
+        sg = (np.float32(1.0) / (np.float32(1.0) + np.exp(-g2))).astype(np.float32)
+        gate_a, gate_b = sg[..., 0:1], sg[..., 1:2]
+        grep_a = p[pre + "grep_a"].reshape(1, H, 1, 1)
+        gate = gate_a * (gate_b * grep_a - np.float32(1.0)) + np.float32(2.0)        # backbone.py:550
+    o = np.empty((B, H, T, hd), np.float32)
+    kt = k.transpose(0, 1, 3, 2)
+    tmp = np.empty((H, T, T), np.float32) if gate is not None else None
+    # clip by clip, every step in place: the same operations per element in the same order as the whole-batch expressions
+    # (scores * scale, + gate * bias, mask, - max, exp, / sum), without [B, H, T, T] temporaries -- the CPU baseline of bench.py times this
+    for b in range(B):
+        sc = np.matmul(q[b], kt[b])                                               # [H,T,T]
+        sc *= np.float32(hd ** -0.5)                                              # SDPA scale (backbone.py:567)
+        if bias_hTT is not None:
+            if gate is not None:
+                np.multiply(gate[b], bias_hTT, out=tmp)
+                sc += tmp
+            else:
+                sc += bias_hTT
+        if key_padding_mask is not None:
+            sc[:, :, key_padding_mask[b]] = -np.inf
+        sc -= sc.max(axis=-1, keepdims=True)
+        np.exp(sc, out=sc)
+        sc /= sc.sum(axis=-1, keepdims=True, dtype=np.float32)
+        np.matmul(sc, v[b], out=o[b])
+    o = o.transpose(0, 2, 1, 3).reshape(B, T, E)
     return linear(o, p[pre + "out_proj.weight"], p[pre + "out_proj.bias"])
 
 

@@ -16,8 +16,9 @@ out["fbank.noise16k.max_abs"] = max_abs(y, fb["noise16k"])
 y = plan(torch.from_numpy(synth.noise_clips(2, 160000, seed=0)).cuda()).cpu().numpy()
 out["fbank.noise160k.max_abs"] = max_abs(y[:, ::37], fb["noise160k_rows37"])
 sd = synth.beats_state_dict(synth.BEATS_BASE_CFG, seed=0)
-for dt in ("f16", "bf16"):
-    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, sd, operand_dtype=dt)
+for dt, residual in (("f16", "half"), ("bf16", "half"), ("f16", "f32")):
+    enc = K.BeatsEncoder(synth.BEATS_BASE_CFG, sd, operand_dtype=dt, residual=residual)
+    dt = dt if residual == "half" else dt + "_residual_f32"      # (the model classes run this mode for calls that return frames)
     for tag, B, T in (("b1", 1, 160000), ("b4", 4, 160000), ("odd", 2, 123457), ("short", 3, 16000)):
         r = enc.forward(torch.from_numpy(synth.noise_clips(B, T, seed=0)).cuda(), hook_layers=range(13), want_pooled=True)
         p = r["pooled"].cpu().numpy()

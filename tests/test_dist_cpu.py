@@ -223,3 +223,22 @@ def test_bench_control_flow_at_eight_ranks(tmp_path):
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp8" and d["config"]["world_size"] == 8
     assert d["config"]["gathered_rows_in_clip_order"] is True
     assert d["config"]["all_gather"]["blocking_ms"] > 0 and d["config"]["all_gather"]["bytes_per_rank"] == 2 * 768 * 4
+    # what a first real 8-GPU run needs in order to say WHERE it is slow: every rank's own step time, the slowest rank, and the time
+    # the compute stream waited for gathers that had not finished under the next step
+    pr = d["config"]["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] and 0 <= pr["slowest_rank"] < 8
+    assert pr["ms_per_step_max"] <= d["ms_per_step"] * 1.001 + 1e-6          # the line's time is the max over ranks (plus the closing barrier)
+    assert pr["exposed_gather_ms_per_step_max"] >= pr["exposed_gather_ms_per_step_mean"] >= 0
+    assert d["config"]["all_gather"]["exposed_ms"] == pr["exposed_gather_ms_per_step_max"]
+
+
+def test_bench_rendezvous_failure_is_loud_and_names_the_rank(tmp_path):
+    """A rank whose peers never arrive must not hang the job: init_process_group has a timeout (AVEX_AMD_DIST_TIMEOUT_S), the rank says
+    which rank it is and what it was waiting for, and exits with code 3."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29431", AVEX_AMD_DIST_TIMEOUT_S="5")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--cpu-dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "rank 1/2" in r.stderr and "FAILED" in r.stderr and "MASTER_PORT=29431" in r.stderr

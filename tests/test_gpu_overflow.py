@@ -195,9 +195,21 @@ def test_overflow_policies(built_lib, clips):
 def test_model_class_exposes_the_alarm(built_lib, clips):
     import avex_amd
     spec = avex_amd.get_model_spec("esp_aves2_sl_beats_all").model_copy(deep=True)
-    m = avex_amd.build_model_from_spec(spec, "cuda", return_features_only=True, on_overflow="ignore")
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in _heavy_checkpoint("residual").items()}, strict=False)
+    sd = {k: torch.from_numpy(v) for k, v in _heavy_checkpoint("residual").items()}
+    m = avex_amd.build_model_from_spec(spec, "cuda", return_features_only=True, on_overflow="ignore", residual="half")
+    m.load_state_dict(sd, strict=False)
     m.eval()
     assert m.overflow_events() == 0
     m(torch.from_numpy(clips).cuda())
     assert m.overflow_events() > 0
+    # the default residual="auto": a call that hands FRAMES back runs the fp32 residual stream, where these out-of-range sums never pass
+    # through f16 (nothing to count); a pooled-only call (mean-aggregated taps) runs the operand-type stream and the alarm speaks
+    m = avex_amd.build_model_from_spec(spec, "cuda", return_features_only=True, on_overflow="ignore")
+    m.load_state_dict(sd, strict=False)
+    m.eval()
+    m(torch.from_numpy(clips).cuda())
+    assert m.overflow_events() == 0
+    m.register_hooks_for_layers(["last_layer"])
+    m.extract_embeddings(torch.from_numpy(clips).cuda(), aggregation="mean")
+    assert m.overflow_events() > 0
+    m.deregister_all_hooks()
