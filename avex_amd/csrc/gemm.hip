@@ -499,6 +499,9 @@ static_assert(L5_ROWS + 4096 <= 32768, "EPI 1 scratch above the stages");
 #ifndef GEMM_XCD_WALK
 #define GEMM_XCD_WALK 0
 #endif
+#ifndef GEMM_NOEPI
+#define GEMM_NOEPI 0
+#endif
 #ifndef GEMM_COL_WALK
 #define GEMM_COL_WALK 0     // 1: AVEX_AMD_GEMM_TILE_ORDER=-n selects the column-group walk (A/B builds; the scalar code of a third walk in
                             // set_tile is kept out of the default kernel: it sits inside the K loop's second-to-last iteration)
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     // (rows past M are dropped by the bounds check, not skipped by an exec mask): 16 output stores per wave, EPI 2 with statistics 16 more,
     // interleaved -- whichever form, at least the last 16 vector-memory operations before the new tile's DMAs are epilogue operations
     // that need not have retired.  For EPI 2 it measured level (out_proj) to 1 % slower (fc2): profiles/r04h_epilogue_ab2.txt; not the default.
-    constexpr bool early_w1 = (EPI == 1 || (GEMM_EPI2_EARLY && EPI == 2)) && !GEMM_NOSTORE;
+    constexpr bool early_w1 = (EPI == 1 || (GEMM_EPI2_EARLY && EPI == 2)) && !GEMM_NOSTORE && !GEMM_NOEPI;
 
     // One continuous K stream over this workgroup's tiles: the DMA for the next tile's first K-tiles is issued by the
     // LAST iterations of the current tile exactly as if they were K-tiles nk, nk + 1 of the same product (the source
@@ -735,7 +738,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         const int er = le >> 3, ec = le & 7, lc = le & 15, lg = le >> 4;
         float ovf_mx = 0.f;
 
-        if constexpr (fast_half) {
+        if constexpr (GEMM_NOEPI && (EPI == 1 || EPI == 2)) {
+            // diagnostic build: NO epilogue at all (the accumulators are only kept alive) -- the upper bound of what any scheme that hides
+            // the epilogue under the next tile's MFMAs could reach, with the epilogue's energy taken away as well (profiles/r04n_noepi.txt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if constexpr (fast_half) {
             // bias / GELU (/ the folded LayerNorm of the A rows) in the accumulator layout; the slab holds the converted halves
             // (ds_write_b64 of 4 halves, ds_read_b128 of 8); no uniform branches inside, so the scheduler interleaves the
             // independent GELU chains of a 64-column slice
