@@ -1,0 +1,366 @@
+// The double-accumulator form of the K = 768 GEMM, as a microbenchmark WITH its LDS reads, LDS-DMA, epilogue arithmetic and stores in the
+// loop (round 4).  Not a product kernel: addresses, barriers, counted waits, instruction mix and bytes are
+// those a real kernel would have, the output values are not checked.
+//
+// Shape.  A 256 x 256 output tile is done as TWO PASSES of 128 (n) x 256 (m): 8 waves as 2 (n) x 4 (m), 64 x 64 outputs per wave = 64
+// accumulator registers, and TWO such sets.  Pass q accumulates into set q & 1 over the 12 K-tiles of K = 768 while the epilogue of pass
+// q - 1 (bias + exact-erf GELU + f16 + transpose through a private LDS slab + 16-byte non-temporal stores, 8 rows x 128 B per instruction)
+// is spread over the LOAD segments of its K-tiles: chunk c (16 rows x 64 columns per wave) does its arithmetic and slab writes in K-tile
+// 2 c + 1 and its slab reads and stores in K-tile 2 c + 2.  The matrix pipe never waits for an epilogue.
+// Per K-tile and wave: 16 ds_read_b128 (8 W + 8 X fragments), 6 LDS-DMA instructions (W half-tile 16 KB + X tile 32 KB = 48 KB per
+// workgroup; three 48 KB stages, K-tile g + 2 requested while g is read), 32 MFMAs (16x16x32 f16).  Waves 4-7 run one barrier behind waves
+// 0-3.  X is streamed twice per 256 x 256 of output (96 instead of 64 KB of L2 -> LDS per 64-deep step), fragments are read 4 instead of 3
+// times per 8 MFMAs.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scripts/micro/gemm_dbuf.hip -o scripts/micro/bin/gemm_dbuf
+//   scripts/micro/bin/gemm_dbuf            (M = 126976, N = 3072, K = 768: fc1 of the 256-clip step)
+// Compare with the product kernel on the same shape and epilogue:  python scripts/gemm_forms.py --plain --shapes fc1
+#include "../../avex_amd/csrc/common.h"
+#include <stdlib.h>
+#include <vector>
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int BK = 64, NK = 12, K = NK * BK;
+constexpr int STAGE = 49152;                   // W half-tile 128 rows (16 KiB) + X tile 256 rows (32 KiB)
+constexpr int SLABS = 3 * STAGE;               // 8 waves x 2 KiB
+constexpr int LDS_BYTES = SLABS + 8 * 2048;    // 163 840 = all of it
+
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// KNOCK (diagnostics of the in-loop form): 1 = no stores in the loop (counted waits back to 6), 2 = no arithmetic / slab writes in the loop,
+// 3 = neither (the bare two-pass K loop with its final epilogue only)
+template <bool EPI_IN_LOOP, int KNOCK = 0, bool IN_M = false>
+__global__ __launch_bounds__(512) void dbuf_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ out,
+                                                   const float* __restrict__ bias, int M, int N, unsigned long long* __restrict__ clk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tiles_n = N / 256, tiles_m = M / 256, ntiles = tiles_m * tiles_n;
+    const int sw = (lane >> 1) & 7;
+    const int foff0 = (lane & 15) * 128 + ((((lane >> 4)) ^ sw) << 4), foff1 = foff0 ^ 64;
+    const int wfrag = (64 * wm) * 128, xfrag = 16384 + (64 * wn) * 128;
+    const int er = lane >> 3, ec = lane & 7, lc = lane & 15, lg = lane >> 4;
+
+    // pass p of this workgroup: 256 x 256 tile (p >> 1) of the product kernel's walk -- blocks that share blockIdx % 8 share an XCD and take 32
+    // consecutive tile ids per round; ids run down groups of 8 row panels, then one column to the right (gemm.hip tile_coords) -- n-half p & 1
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    int nt_mine = 0;
+    for (int it = 0; (it * 8 + xcd) * per_xcd + slot < ntiles; ++it) ++nt_mine;
+    const int npass = 2 * nt_mine;
+    auto coords = [&](int p, int& m0, int& n0) __attribute__((always_inline)) {
+        const int t = ((p >> 1) * 8 + xcd) * per_xcd + slot;
+        const int per_group = 8 * tiles_n;
+        const int gid = t / per_group;
+        const int first_m = gid * 8;
+        const int gsz = (tiles_m - first_m) < 8 ? (tiles_m - first_m) : 8;
+        const int r = t - gid * per_group;
+        const int tn = r / gsz, tm = first_m + (r - tn * gsz);
+        m0 = tm * 256; n0 = tn * 256 + 128 * (p & 1);
+    };
+    // this wave's 2 W pieces and 4 X pieces (8 rows x 128 B each) of every K-tile: lane offsets that do not depend on the pass, and one
+    // uniform base pointer per operand and pass (scalar registers)
+    int woff[2], xoff[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 8 * (wid + 8 * q) + (lane >> 3);
+        woff[q] = (r * K + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 8 * (wid + 8 * q) + (lane >> 3);
+        xoff[q] = (r * K + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2;
+    }
+    auto bases = [&](int p, const char*& wb, const char*& xb) __attribute__((always_inline)) {
+        int m0, n0;
+        coords(p, m0, n0);
+        wb = (const char*)(W + (int64_t)n0 * K);
+        xb = (const char*)(A + (int64_t)m0 * K);
+    };
+    auto dma = [&](const char* wb, const char* xb, int kt, int stg) __attribute__((always_inline)) {      // 6 x 1 KiB
+        char* base = smem + stg * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) __builtin_amdgcn_global_load_lds((gptr_t*)(wb + (unsigned)(woff[q] + kt * BK * 2)), (lptr_t*)(base + (wid + 8 * q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds((gptr_t*)(xb + (unsigned)(xoff[q] + kt * BK * 2)), (lptr_t*)(base + 16384 + (wid + 8 * q) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[2][4][4];
+    v8 wf[4][2], xf[4][2];
+    _Float16* slab = (_Float16*)(smem + SLABS + wid * 2048);      // 16 rows x 64 halves
+    float sink = 0.f;
+    const f32x4 bv = {bias[lg], bias[lg + 4], bias[lg + 8], bias[lg + 12]};      // loaded before any DMA is in flight
+
+    const char *wb_cur, *xb_cur, *wb_nxt = nullptr, *xb_nxt = nullptr;
+    bases(0, wb_cur, xb_cur);
+    dma(wb_cur, xb_cur, 0, 0);
+    dma(wb_cur, xb_cur, 1, 1);
+    VMCNT(6);
+    BAR();
+    if (wm == 1) BAR();                 // stagger: waves 4-7 one barrier behind
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+
+    // epilogue chunk j of accumulator set `set` of the pass that ended at output (em0, en0): arithmetic + slab writes (part 0), slab reads + stores (part 1)
+    auto chunk_math = [&](int set, int j, int en0) __attribute__((always_inline)) {
+        f32x2 v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[2 * i + (e >> 1)][e & 1] = acc[set][i][j][e] + bv[e];      // (a real kernel reads the tile's bias row from LDS, filled by DMA a tile ahead)
+        }
+        gelu_erf2xN<8>(v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v4 h;
+            h[0] = Half<_Float16>::from(v[2 * i][0]); h[1] = Half<_Float16>::from(v[2 * i][1]);
+            h[2] = Half<_Float16>::from(v[2 * i + 1][0]); h[3] = Half<_Float16>::from(v[2 * i + 1][1]);
+            *(v4*)(slab + lc * 64 + 16 * i + 4 * lg) = h;
+        }
+    };
+    // the same arithmetic in pieces of one 16 x 16 MFMA tile (4 values per lane) -- NG of them side by side -- so that every load segment
+    // of a pass carries about the same share of the previous pass's epilogue (16 pieces over 12 K-tiles)
+    auto group_math = [&](int set, int c, int i0, int ng) __attribute__((always_inline)) {
+        f32x2 v[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[2 * q + (e >> 1)][e & 1] = acc[set][i0 + (q < ng ? q : 0)][c][e] + bv[e];
+        if (ng == 2) gelu_erf2xN<4>(v);
+        else { f32x2 w2[2] = {v[0], v[1]}; gelu_erf2xN<2>(w2); v[0] = w2[0]; v[1] = w2[1]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q >= ng) break;
+            v4 h;
+            h[0] = Half<_Float16>::from(v[2 * q][0]); h[1] = Half<_Float16>::from(v[2 * q][1]);
+            h[2] = Half<_Float16>::from(v[2 * q + 1][0]); h[3] = Half<_Float16>::from(v[2 * q + 1][1]);
+            *(v4*)(slab + lc * 64 + 16 * (i0 + q) + 4 * lg) = h;
+        }
+    };
+    auto chunk_read = [&](v8 (&h)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) h[ps] = *(const v8*)(slab + (8 * ps + er) * 64 + 8 * ec);
+    };
+    auto chunk_store = [&](const v8 (&h)[2], int j, int em0, int en0) __attribute__((always_inline)) {
+        const uint64_t a = (uint64_t)(out + (int64_t)(em0 + 64 * wn) * N + en0 + 64 * wm);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a)),
+                                                                             0, 64 * N * 2, 0x00020000);
+        typedef int i32x4_st __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_st, h[ps]), rs, ((16 * j + 8 * ps + er) * N + 8 * ec) * 2, 0, 2);
+    };
+
+    int pm0 = 0, pn0 = 0;               // output coordinates of the pass whose LAST chunk is still in the slab (stored in K-tile 0 of the pass after next)
+    for (int p = 0; p < npass; p += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                // pass p + half accumulates into set `half`, the other set drains
+            const int pp = p + half;
+            const int set = half, other = half ^ 1;
+            const bool drain = EPI_IN_LOOP && pp > 0;
+            int em0 = 0, en0 = 0;
+            if (pp > 0) coords(pp - 1, em0, en0);
+            const bool has_next = pp + 1 < npass;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[set][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int st = 0, st2 = 2;                                   // stage of K-tile kt and of kt + 2 (12 K-tiles per pass: the ring position repeats every pass)
+#pragma unroll 1
+            for (int kt = 0; kt < NK; ++kt) {
+                v8 hs[2];
+                // chunk c of the draining pass is complete in the slab after K-tile 3 c + 2: read back and stored in K-tile 3 c + 3
+                // (the last one in K-tile 0 of the NEXT pass)
+                const bool rd = EPI_IN_LOOP && !(KNOCK & 1) && ((drain && (kt == 3 || kt == 6 || kt == 9)) || (kt == 0 && pp >= 2));
+                if (rd) chunk_read(hs);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* r = smem + st * STAGE + xfrag + (16 * j) * 128;
+                    xf[j][0] = *(const v8*)(r + foff0); xf[j][1] = *(const v8*)(r + foff1);
+                }
+                if (rd) LGKM(8);                       // the two slab reads are the oldest of 10: the slab may be rewritten below
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* r = smem + st * STAGE + wfrag + (16 * i) * 128;
+                    wf[i][0] = *(const v8*)(r + foff0); wf[i][1] = *(const v8*)(r + foff1);
+                }
+                if (kt == NK - 3 && has_next) bases(pp + 1, wb_nxt, xb_nxt);
+                if (kt + 2 < NK) dma(wb_cur, xb_cur, kt + 2, st2);
+                else if (has_next) dma(wb_nxt, xb_nxt, kt + 2 - NK, st2);
+                if (rd) {                              // AFTER this K-tile's DMAs: the counted waits then never wait for a store younger than two K-tiles
+                    if (kt == 0) chunk_store(hs, 3, pm0, pn0);
+                    else chunk_store(hs, kt / 3 - 1, em0, en0);
+                }
+                // K-tile kt + 1 (requested one K-tile ago) must have landed before the next load segment reads it; what may stay in flight:
+                // this K-tile's 6 DMAs, its 2 stores, and the 2 stores of the K-tile before (issued after that K-tile's DMAs)
+                {
+                    const bool s0 = rd, s1 = EPI_IN_LOOP && !(KNOCK & 1) && ((drain && (kt == 4 || kt == 7 || kt == 10)) || (kt == 1 && pp >= 2));
+                    if (s0 || s1) VMCNT(8);
+                    else VMCNT(6);
+                }
+                if (!IN_M && drain && !(KNOCK & 2)) {
+                    switch (kt) {
+                        case 0: group_math(other, 0, 0, 1); break;
+                        case 1: group_math(other, 0, 1, 1); break;
+                        case 2: group_math(other, 0, 2, 2); break;
+                        case 3: group_math(other, 1, 0, 1); break;
+                        case 4: group_math(other, 1, 1, 1); break;
+                        case 5: group_math(other, 1, 2, 2); break;
+                        case 6: group_math(other, 2, 0, 1); break;
+                        case 7: group_math(other, 2, 1, 1); break;
+                        case 8: group_math(other, 2, 2, 2); break;
+                        case 9: group_math(other, 3, 0, 1); break;
+                        case 10: group_math(other, 3, 1, 1); break;
+                        default: group_math(other, 3, 2, 2); break;
+                    }
+                }
+                LGKM(0);
+                BAR();
+                __builtin_amdgcn_s_setprio(1);
+                // IN_M: the piece of the previous pass's epilogue that belongs to this K-tile sits at the head of the MFMA segment instead of in
+                // the load segment.  (Interleaved WITH the MFMAs it would ride in their issue shadows -- an MFMA holds the vector issue port
+                // for 8 of its 16 cycles -- but that needs the piece and the 32 MFMAs in ONE basic block per K-tile position, and with twelve
+                // such blocks hipcc stops accumulating in place (v_mfma D != C, copies between blocks), spills 23 registers and puts a
+                // vmcnt(0) for the reload inside the segment: profiles/r04p_gemm_dbuf.txt.  That form is hand-scheduled assembly, not HIP.)
+                if (IN_M && drain && !(KNOCK & 2)) {
+                    switch (kt) {
+                        case 0: group_math(other, 0, 0, 1); break;
+                        case 1: group_math(other, 0, 1, 1); break;
+                        case 2: group_math(other, 0, 2, 2); break;
+                        case 3: group_math(other, 1, 0, 1); break;
+                        case 4: group_math(other, 1, 1, 1); break;
+                        case 5: group_math(other, 1, 2, 2); break;
+                        case 6: group_math(other, 2, 0, 1); break;
+                        case 7: group_math(other, 2, 1, 1); break;
+                        case 8: group_math(other, 2, 2, 2); break;
+                        case 9: group_math(other, 3, 0, 1); break;
+                        case 10: group_math(other, 3, 1, 1); break;
+                        default: group_math(other, 3, 2, 2); break;
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = (i & 1) ? 3 - jj : jj;
+                            acc[set][i][j] = mfma16(wf[i][ks], xf[j][ks], acc[set][i][j]);
+                        }
+                __builtin_amdgcn_s_setprio(0);
+                BAR();
+                st = st == 2 ? 0 : st + 1;
+                st2 = st2 == 2 ? 0 : st2 + 1;
+            }
+            if (has_next) { wb_cur = wb_nxt; xb_cur = xb_nxt; }
+            pm0 = em0; pn0 = en0;
+            if (!EPI_IN_LOOP) {
+                // the serial form of the same pass structure: the whole epilogue of this pass here, matrix pipe idle
+                int m0, n0;
+                coords(pp, m0, n0);
+                if (wm == 0) BAR();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    chunk_math(set, j, n0);
+                    LGKM(0);
+                    v8 hs[2];
+                    chunk_read(hs);
+                    LGKM(0);
+                    chunk_store(hs, j, m0, n0);
+                }
+                if (wm == 1) BAR();
+            }
+        }
+    }
+    if (EPI_IN_LOOP) {                  // chunk 3 of the pass before last is still in the slab; then the last pass's accumulators (set 1: npass is even)
+        v8 hs[2];
+        if (npass >= 2 && !(KNOCK & 1)) {
+            chunk_read(hs);
+            LGKM(0);
+            chunk_store(hs, 3, pm0, pn0);
+        }
+        int m0, n0;
+        coords(npass - 1, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            chunk_math(1, j, n0);
+            LGKM(0);
+            chunk_read(hs);
+            LGKM(0);
+            chunk_store(hs, j, m0, n0);
+        }
+    }
+    if (tid == 0) {
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    if (sink != 0.f) out[0] = (_Float16)sink;
+}
+
+template <bool E, int KN = 0, bool INM = false>
+static double run(const _Float16* A, const _Float16* W, _Float16* out, const float* bias, int M, int N, unsigned long long* clk, int iters, double* ghz) {
+    CK(hipFuncSetAttribute((const void*)dbuf_kernel<E, KN, INM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((dbuf_kernel<E, KN, INM>), dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk);      // clocks settle under load
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((dbuf_kernel<E, KN, INM>), dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(512);
+    CK(hipMemcpy(h.data(), clk, sizeof(unsigned long long) * 512, hipMemcpyDeviceToHost));
+    double s = 0;
+    for (int b = 0; b < 256; ++b) s += (double)h[2 * b] / ((double)h[2 * b + 1] * 10.0);      // cycles per ns (s_memrealtime: 100 MHz)
+    *ghz = s / 256;
+    return ms * 1e3 / iters;
+}
+
+int main(int argc, char** argv) {
+    const int M = 126976, N = 3072;
+    const int iters = argc > 1 ? atoi(argv[1]) : 200;
+    _Float16 *A, *W, *out;
+    float* bias;
+    unsigned long long* clk;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&out, (size_t)M * N * 2));
+    CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&clk, 512 * 8));
+    {   // pseudo-random halves (the power the MFMAs draw depends on the data)
+        std::vector<_Float16> h((size_t)M * K);
+        unsigned s = 12345u;
+        for (size_t i = 0; i < h.size(); ++i) { s = s * 1664525u + 1013904223u; h[i] = (_Float16)(((int)(s >> 9) % 2001 - 1000) * 1e-3f); }
+        CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < (size_t)N * K; ++i) { s = s * 1664525u + 1013904223u; h[i] = (_Float16)(((int)(s >> 9) % 2001 - 1000) * 5e-5f); }
+        CK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+        std::vector<float> b(N);
+        for (int i = 0; i < N; ++i) b[i] = 0.01f * (float)(i % 17);
+        CK(hipMemcpy(bias, b.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    const double flop = 2.0 * M * N * K;
+    for (int rep = 0; rep < 3; ++rep) {
+        double g1, g0;
+        const double us1 = run<true>(A, W, out, bias, M, N, clk, iters, &g1);
+        double g2;
+        const double us2 = run<true, 0, true>(A, W, out, bias, M, N, clk, iters, &g2);
+        const double us0 = run<false>(A, W, out, bias, M, N, clk, iters, &g0);
+        printf("two passes of 128 x 256, two accumulator sets: epilogue IN the K loop %7.1f us (%6.1f TFLOP/s, %.3f GHz)   epilogue after each pass %7.1f us (%6.1f TFLOP/s, %.3f GHz)\n",
+               us1, flop / us1 / 1e6, g1, us0, flop / us0 / 1e6, g0);
+        printf("   ... the pieces at the head of the MFMA segments instead of in the load segments %7.1f us (%6.1f TFLOP/s, %.3f GHz)\n", us2, flop / us2 / 1e6, g2);
+        if (rep == 0) {
+            double ga, gb, gc;
+            const double ua = run<true, 1>(A, W, out, bias, M, N, clk, iters, &ga);
+            const double ub = run<true, 2>(A, W, out, bias, M, N, clk, iters, &gb);
+            const double uc = run<true, 3>(A, W, out, bias, M, N, clk, iters, &gc);
+            printf("   knock-outs of the in-loop form: no stores in the loop %7.1f us (%.3f GHz) | no arithmetic / slab writes %7.1f us (%.3f GHz) | neither (bare two-pass K loop) %7.1f us (%6.1f TFLOP/s, %.3f GHz)\n",
+                   ua, ga, ub, gb, uc, flop / uc / 1e6, gc);
+        }
+    }
+    return 0;
+}
