@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void dbuf_kernel(const _Float16* __restrict__ 
             v4 h;
             h[0] = Half<_Float16>::from(v[2 * i][0]); h[1] = Half<_Float16>::from(v[2 * i][1]);
             h[2] = Half<_Float16>::from(v[2 * i + 1][0]); h[3] = Half<_Float16>::from(v[2 * i + 1][1]);
-            *(v4*)(slab + lc * 64 + 16 * i + 4 * lg) = h;
+            *(v4*)((char*)slab + lc * 128 + (((2 * i + (lg >> 1)) ^ ((lc >> 1) & 7)) << 4) + 8 * (lg & 1)) = h;      // 16-byte slot s of row r at slot s ^ ((r >> 1) & 7): conflict-free writes and reads without padding
         }
     };
     // the same arithmetic in pieces of one 16 x 16 MFMA tile (4 values per lane) -- NG of them side by side -- so that every load segment
@@ -140,12 +140,12 @@ __global__ __launch_bounds__(512) void dbuf_kernel(const _Float16* __restrict__ 
             v4 h;
             h[0] = Half<_Float16>::from(v[2 * q][0]); h[1] = Half<_Float16>::from(v[2 * q][1]);
             h[2] = Half<_Float16>::from(v[2 * q + 1][0]); h[3] = Half<_Float16>::from(v[2 * q + 1][1]);
-            *(v4*)(slab + lc * 64 + 16 * (i0 + q) + 4 * lg) = h;
+            *(v4*)((char*)slab + lc * 128 + (((2 * (i0 + q) + (lg >> 1)) ^ ((lc >> 1) & 7)) << 4) + 8 * (lg & 1)) = h;
         }
     };
     auto chunk_read = [&](v8 (&h)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) h[ps] = *(const v8*)(slab + (8 * ps + er) * 64 + 8 * ec);
+        for (int ps = 0; ps < 2; ++ps) h[ps] = *(const v8*)((const char*)slab + (8 * ps + er) * 128 + ((ec ^ (((8 * ps + er) >> 1) & 7)) << 4));
     };
     auto chunk_store = [&](const v8 (&h)[2], int j, int em0, int en0) __attribute__((always_inline)) {
         const uint64_t a = (uint64_t)(out + (int64_t)(em0 + 64 * wn) * N + en0 + 64 * wm);
