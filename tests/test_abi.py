@@ -133,4 +133,5 @@ def test_oracle_is_test_infrastructure_only():
         for node in ast.walk(fn):
             if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
                 owners[fn.name] = node.lineno
-    assert set(owners) == {"cpu_baseline"}, owners
+    # the cpu_baseline leg is two functions: the parent that times, and the worker body its child processes run
+    assert set(owners) <= {"cpu_baseline", "cpu_baseline_worker"} and owners, owners

@@ -412,3 +412,22 @@ def test_efficientnet_class_contract_cpu():
         m(torch.zeros(1, 3, 16, 16))
     spec = avex_amd.get_model_spec("esp_aves2_effnetb0_all")
     assert spec.name == "efficientnet" and spec.audio_config.n_fft == 800 and spec.audio_config.representation == "mel_spectrogram"
+
+
+def test_bench_effnet_algorithmic_bytes():
+    import os
+    """bench.py's C5 roofline prices the EfficientNet leg on ALGORITHMIC bytes: every layer's input read once and its output written once at
+    2 bytes and the real channel counts, the frontend's fp32 wav in / image out (DESIGN.md section 4, "Other BASELINE configs"): pin the
+    figure for B0 on a 128 x 1001 mel image, and its pieces for a one-block toy stack."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from avex_amd.synth import EFFNET_B0_STAGES
+    b = bench.effnet_algorithmic_bytes(EFFNET_B0_STAGES, 128, 1001, 160000)
+    assert b == 71942656
+    # toy: 8 x 8 image, stem 4 channels (-> 4 x 4), one expand-free 3x3 stride-1 block 4 -> 4 channels with a residual, head 8 channels
+    toy = bench.effnet_algorithmic_bytes([(1, 3, 1, 4, 4, 1)], 8, 8, 100, stem=4, head=8)
+    want = 100 * 4 + 64 * 4 + 64 * 4 + 16 * 4 * 2 + (16 + 16) * 4 * 2 + 16 * (4 + 4) * 2 + 16 * 4 * 2 + 16 * (4 + 2 * 8) * 2 + 8 * 4
+    assert toy == want
