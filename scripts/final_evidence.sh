@@ -1,16 +1,18 @@
 #!/bin/bash
-# round-3 evidence on the final tree (run on the GPU box through gpurun)
+# evidence on the final tree of a round (run on the GPU box through gpurun):  bash scripts/final_evidence.sh <tag>
+TAG=${1:-r04z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-bash scripts/collect_profiles.sh r03u > gpurun_out/r03u_collect.log 2>&1
-python tests/tools/parity_families.py > gpurun_out/r03u_parity.log 2>&1
-{ python scripts/other_configs.py; python scripts/eat_bench.py; python scripts/effnet_bench.py 256; python scripts/effnet_bench.py 1024; python scripts/aves_bench.py 128; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r03u_other_configs.txt
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03u_effnet_prof -- python3 $R/scripts/effnet_bench.py 256 > /dev/null 2>&1
-cp $(find $R/gpurun_out/r03u_effnet_prof -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r03u_effnet_kernel_stats.csv
-cd $R
-python tests/tools/fuzz_kernels.py 200 31 > gpurun_out/r03u_fuzz_kernels.txt 2>&1
-python tests/tools/fuzz_e2e.py 100 17 > gpurun_out/r03u_fuzz_e2e.txt 2>&1
-python scripts/soak.py 60 > gpurun_out/r03u_soak.txt 2>&1
-tail -qn 2 gpurun_out/r03u_fuzz_kernels.txt gpurun_out/r03u_fuzz_e2e.txt gpurun_out/r03u_soak.txt
-cat gpurun_out/r03u_other_configs.txt
+mkdir -p gpurun_out
+python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/${TAG}_gputests.txt
+bash scripts/collect_profiles.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
+python tests/tools/parity_families.py > gpurun_out/${TAG}_parity.log 2>&1
+python scripts/parity_report.py > gpurun_out/${TAG}_parity_report.log 2>&1
+{ python scripts/other_configs.py; python scripts/eat_bench.py; python scripts/effnet_bench.py 256; python scripts/effnet_bench.py 1024; python scripts/aves_bench.py 128; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_other_configs.txt
+python tests/tools/fuzz_kernels.py 200 41 > gpurun_out/${TAG}_fuzz_kernels.txt 2>&1
+python tests/tools/fuzz_e2e.py 100 23 > gpurun_out/${TAG}_fuzz_e2e.txt 2>&1
+python scripts/soak.py 60 > gpurun_out/${TAG}_soak.txt 2>&1
+cat gpurun_out/${TAG}_gputests.txt
+tail -qn 2 gpurun_out/${TAG}_fuzz_kernels.txt gpurun_out/${TAG}_fuzz_e2e.txt gpurun_out/${TAG}_soak.txt
+cat gpurun_out/${TAG}_other_configs.txt
+cat gpurun_out/${TAG}_bench.json
