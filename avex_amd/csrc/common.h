@@ -330,6 +330,11 @@ struct GemmArgs {
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // fp32 NHWC rows [B * HW, ld] -> NCHW [B, C, HW], optionally undoing a folded BatchNorm: (x - shift[c]) / scale[c] (effnet.hip)
 int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s);
+// MBConv front in one kernel: 1x1 expansion (kin = 32 | 64; 0 = none) + BN + SiLU + depthwise k x k + BN + SiLU + squeeze sums (effnet.hip)
+int64_t mbconv_front_tiles(int H, int W, int k, int stride, int kin);
+int mbconv_front(const void* in, int B, int H, int W, int ld_in, int kin, const void* w_exp, int ldw, const float* b_exp, int k, int stride,
+                 const float* w_dw, const float* b_dw, int cp_exp, void* out, float* pool, float* part, size_t part_bytes, unsigned int* ovf,
+                 int dtype, hipStream_t s);
 // GemmArgs::pool_part [ceil(M / 64)][2][N] -> out[b][n] = mean over clip b's T rows (b < B, M = B * T), blocks added in order
 //                                                 (mode 1: the maximum over the clip's rows instead)
 int pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, hipStream_t s, int mode = 0);

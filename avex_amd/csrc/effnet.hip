@@ -249,6 +249,209 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused front of an MBConv block: 1x1 expansion (+ folded BatchNorm + SiLU) and the depthwise convolution after it in ONE kernel, so the
+// expanded tensor -- the largest tensor of the network by far at the first stages (96 channels at 64 x 501: 6 MB per clip, written once and
+// read once) -- never exists in HBM.  A workgroup owns a TH x TW tile of OUTPUT pixels of one clip:
+//   0. the tile's input pixels, halo included ((TH-1) ST + KS rows x (TW-1) ST + KS columns, KIN input channels each), go to LDS once;
+//   per chunk of CC = 32 expanded channels:
+//   1. expansion on the MFMA: W [32 x KIN] as the A operand, 16 pixels as B, so a lane ends with four consecutive channels of one pixel
+//      (one 8-byte LDS write); bias + SiLU + rounding to the operand type exactly as the GEMM epilogue did; pixels outside the image are
+//      written as ZERO (the depthwise convolution pads its INPUT, the expanded tensor, with zeros);
+//   2. the depthwise taps from LDS in (ky, kx) order (the order dwconv_kernel adds them: same bits), bias + SiLU, 16-byte stores, and the
+//      squeeze sums as one row of partials per workgroup (pool_sum_kernel adds the rows in order).
+// The halo is expanded by every tile that needs it (1.2 - 1.5 x the SiLUs of the unfused expansion); what is saved is 2 x the expanded
+// tensor of HBM traffic.  KIN = 0: no expansion (the first block of EfficientNet, and a depthwise convolution on its own): step 1 is a
+// copy of the chunk's channels from global memory.
+// ---------------------------------------------------------------------------------------------
+#ifndef MB_WAVES
+#define MB_WAVES 3      // waves per SIMD the fused kernel is compiled for (168 registers): without the bound hipcc hoists every LDS read of an item to its top (220 - 512 registers, spills at 5 x 5)
+#endif
+struct MbArgs {
+    const void* in; int H, W, ld_in;
+    const void* w_exp; int ldw; const float* b_exp;
+    const float* w_dw; const float* b_dw;
+    void* out; int Ho, Wo, cp_exp;
+    float* part;                 // [B][gridDim.x][cp_exp] or NULL
+    int tiles_x;
+    unsigned int* ovf;
+};
+
+template <int KS, int ST, int KIN, int TH, int TW, int CC>
+struct MbGeo {
+    static constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, NPIX = IH * IW, NPG = (NPIX + 15) / 16, NPX = NPG * 16;
+    static constexpr int ISTR = KIN > 0 ? KIN * 2 + 16 : 0;      // bytes per input pixel in LDS (16 bytes of padding: the 16 pixels of an MFMA fragment read meet 16 distinct bank groups)
+    static constexpr int ESTR = CC * 2 + 16;                     // bytes per expanded pixel
+    static constexpr int LDS = NPX * (ISTR + ESTR) + KS * KS * CC * 4 + 4 * CC * 4;
+};
+
+template <typename T, int KS, int ST, int KIN, int TH, int TW, int PIX, int CC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB_WAVES, MB_WAVES))) void mbconv_kernel(const MbArgs p) {
+    typedef typename Half<T>::v8 v8;
+    typedef typename Half<T>::v4 v4;
+    typedef MbGeo<KS, ST, KIN, TH, TW, CC> G;
+    constexpr bool EXPAND = KIN > 0;
+    constexpr int PAD = (KS - 1) / 2, IW = G::IW, NPIX = G::NPIX, NPG = G::NPG, NPX = G::NPX, ISTR = G::ISTR, ESTR = G::ESTR;
+    constexpr int NCOL = (PIX - 1) * ST + KS, SXN = TW / PIX, NCG = CC / 8, NITEM = TH * SXN * NCG;
+    constexpr int KST = EXPAND ? KIN / 32 : 1, MT = CC / 16;
+    static_assert(TW % PIX == 0 && NITEM % 256 == 0 && (NCG == 4 || NCG == 8), "mbconv tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_in = smem;
+    char* s_exp = smem + NPX * ISTR;
+    float* s_w = (float*)(s_exp + NPX * ESTR);
+    float* s_red = s_w + KS * KS * CC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
+    const T* in = (const T*)p.in + (int64_t)b * p.H * p.W * p.ld_in;
+    T* out = (T*)p.out + (int64_t)b * p.Ho * p.Wo * p.cp_exp;
+    const int cp = p.cp_exp;
+    float ovf_mx = 0.f;
+
+    if constexpr (EXPAND) {
+        constexpr int NCH = KIN / 8;
+        for (int i = tid; i < NPX * NCH; i += 256) {
+            const int pix = i / NCH, ch = i - pix * NCH;
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *(const uint4*)(in + ((int64_t)gy * p.W + gx) * p.ld_in + ch * 8);
+            *(uint4*)(s_in + pix * ISTR + ch * 16) = v;
+        }
+    }
+    const int lr = lane & 15, lq = lane >> 4;
+    v8 wf[MT][KST];
+    f32x4 be[MT];
+    auto load_w = [&](int c) __attribute__((always_inline)) {
+        if constexpr (EXPAND) {
+            const T* W = (const T*)p.w_exp;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) wf[mt][ks] = *(const v8*)(W + (int64_t)(c + 16 * mt + lr) * p.ldw + ks * 32 + lq * 8);
+                be[mt] = *(const f32x4*)(p.b_exp + c + 16 * mt + 4 * lq);
+            }
+        }
+    };
+    load_w(0);
+    const int cg = tid & (NCG - 1);
+    for (int c = 0; c < cp; c += CC) {
+        // depthwise weights of the chunk (the previous chunk's taps are done: barrier at the end of the loop body)
+        for (int i = tid; i < KS * KS * CC; i += 256) s_w[i] = p.w_dw[(int64_t)(i / CC) * cp + c + (i % CC)];
+        if constexpr (EXPAND) {
+            if (c == 0) __syncthreads();                 // the input tile
+            for (int pg = wave; pg < NPG; pg += 4) {
+                const int pix = pg * 16 + lr;
+                const int iy = pix / IW, ix = pix - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const bool inside = pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                v8 xf[KST];
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) xf[ks] = *(const v8*)(s_in + pix * ISTR + ks * 64 + lq * 16);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KST; ++ks) acc = mfma16(wf[mt][ks], xf[ks], acc);
+                    f32x4 v = acc + be[mt];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu1(v[e]);
+                    ovf_see4<T>(ovf_mx, v);
+                    v4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = inside ? Half<T>::from(v[e]) : (T)0.0f;
+                    *(v4*)(s_exp + pix * ESTR + (16 * mt + 4 * lq) * 2) = h;
+                }
+            }
+            if (c + CC < cp) load_w(c + CC);             // the next chunk's weight fragments arrive under the taps below
+        } else {
+            for (int i = tid; i < NPX * NCG; i += 256) {
+                const int pix = i / NCG, ch = i - pix * NCG;
+                const int iy = pix / IW, ix = pix - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                uint4 v = {0u, 0u, 0u, 0u};
+                if (pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *(const uint4*)(in + ((int64_t)gy * p.W + gx) * p.ld_in + c + ch * 8);
+                *(uint4*)(s_exp + pix * ESTR + ch * 16) = v;
+            }
+        }
+        __syncthreads();
+        float psum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+        const f32x4 bd0 = *(const f32x4*)(p.b_dw + c + cg * 8), bd1 = *(const f32x4*)(p.b_dw + c + cg * 8 + 4);
+#pragma unroll
+        for (int it = tid; it < NITEM; it += 256) {
+            const int t = it / NCG;
+            const int oyl = t / SXN, sx = t - oyl * SXN;
+            float acc[PIX][8];
+#pragma unroll
+            for (int q = 0; q < PIX; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+            // one input row per trip of a ROLLED loop: unrolled, hipcc issues every LDS read of the item before its first tap (220 - 512
+            // registers, spills at 5 x 5; scheduling barriers do not pin the taps, which are pure arithmetic)
+            const char* rowp = s_exp + ((oyl * ST) * IW + sx * PIX * ST) * ESTR + cg * 16;
+            const float* wrow = s_w + cg * 8;
+#pragma unroll 1
+            for (int r = 0; r < KS; ++r) {
+                v8 col[NCOL];
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) col[q] = *(const v8*)(rowp + q * ESTR);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f32x4 w0 = *(const f32x4*)(wrow + kx * CC), w1 = *(const f32x4*)(wrow + kx * CC + 4);
+#pragma unroll
+                    for (int q = 0; q < PIX; ++q) {
+                        const v8 x = col[q * ST + kx];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[q][e] = __builtin_fmaf((float)x[e], w0[e], acc[q][e]);
+                            acc[q][4 + e] = __builtin_fmaf((float)x[4 + e], w1[e], acc[q][4 + e]);
+                        }
+                    }
+                }
+                rowp += IW * ESTR;
+                wrow += KS * CC;
+            }
+            const int oy = oy0 + oyl;
+#pragma unroll
+            for (int q = 0; q < PIX; ++q) {
+                const int ox = ox0 + sx * PIX + q;
+                if (oy < p.Ho && ox < p.Wo) {
+                    v8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float y = silu1(acc[q][e] + (e < 4 ? bd0[e] : bd1[e - 4]));
+                        h[e] = Half<T>::from(y);
+                        psum[e] += (float)h[e];
+                    }
+                    *(v8*)(out + ((int64_t)oy * p.Wo + ox) * cp + c + cg * 8) = h;
+                }
+            }
+        }
+        if (p.part) {
+            // lanes with the same channel group: bits 2.. (NCG = 4) or 3.. (NCG = 8) of the lane number
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = psum[e];
+#pragma unroll
+                for (int m = NCG; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+                psum[e] = s;
+            }
+            if (lane < NCG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_red[wave * CC + lane * 8 + e] = psum[e];
+            }
+        }
+        __syncthreads();
+        if (p.part && tid < CC) p.part[((int64_t)b * gridDim.x + blockIdx.x) * cp + c + tid] = (s_red[tid] + s_red[CC + tid]) + (s_red[2 * CC + tid] + s_red[3 * CC + tid]);
+    }
+    ovf_commit<T>(p.ovf, ovf_mx);
+}
+
 }  // namespace
 
 extern "C" int avexhip_effnet_stem(const float* img_dev, int B, int H, int W, const float* w_dev, const float* bias_dev, int Cp,
@@ -350,6 +553,81 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 }  // namespace
+
+namespace {
+// tile of the fused kernel for (stride, KIN): output rows x columns per workgroup and pixels along x per thread
+template <int ST, int KIN> struct MbTile;
+template <int KIN> struct MbTile<2, KIN> { static constexpr int TH = 4, TW = 16, PIX = 1; };
+template <> struct MbTile<1, 0>  { static constexpr int TH = 8, TW = 32, PIX = 4; };
+template <> struct MbTile<1, 32> { static constexpr int TH = 8, TW = 32, PIX = 4; };
+template <> struct MbTile<1, 64> { static constexpr int TH = 8, TW = 16, PIX = 2; };      // 144-byte input pixels: the narrower tile keeps two workgroups per CU
+
+template <typename T, int KS, int ST, int KIN>
+int mb_launch(const MbArgs& a0, int B, int64_t* n_tiles, hipStream_t s) {
+    typedef MbTile<ST, KIN> Tl;
+    typedef MbGeo<KS, ST, KIN, Tl::TH, Tl::TW, 32> G;
+    MbArgs a = a0;
+    a.tiles_x = (a.Wo + Tl::TW - 1) / Tl::TW;
+    const int64_t tiles = (int64_t)a.tiles_x * ((a.Ho + Tl::TH - 1) / Tl::TH);
+    if (n_tiles) { *n_tiles = tiles; return AVEXHIP_OK; }
+    AVX_ENSURE_LDS((mbconv_kernel<T, KS, ST, KIN, Tl::TH, Tl::TW, Tl::PIX, 32>), G::LDS);
+    hipLaunchKernelGGL((mbconv_kernel<T, KS, ST, KIN, Tl::TH, Tl::TW, Tl::PIX, 32>), dim3((unsigned)tiles, B), dim3(256), G::LDS, s, a);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+template <typename T>
+int mb_dispatch(const MbArgs& a, int B, int k, int st, int kin, int64_t* n_tiles, hipStream_t s) {
+#define AVX_MB(KS, ST, KIN) if (k == KS && st == ST && kin == KIN) return mb_launch<T, KS, ST, KIN>(a, B, n_tiles, s)
+    AVX_MB(3, 1, 0); AVX_MB(3, 2, 0); AVX_MB(5, 1, 0); AVX_MB(5, 2, 0);
+    AVX_MB(3, 1, 32); AVX_MB(3, 2, 32); AVX_MB(5, 1, 32); AVX_MB(5, 2, 32);
+    AVX_MB(3, 1, 64); AVX_MB(3, 2, 64); AVX_MB(5, 1, 64); AVX_MB(5, 2, 64);
+#undef AVX_MB
+    avexhip_set_error("mbconv_front: kernel %d stride %d K %d not built (k 3 | 5, stride 1 | 2, K 0 | 32 | 64)", k, st, kin);
+    return AVEXHIP_ERR_INVALID;
+}
+}  // namespace
+
+namespace avx {
+// workgroups per clip of the fused kernel = rows of squeeze partials it leaves per clip
+int64_t mbconv_front_tiles(int H, int W, int k, int stride, int kin) {
+    MbArgs a;
+    memset(&a, 0, sizeof(a));
+    const int pad = (k - 1) / 2;
+    a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;
+    int64_t n = 0;
+    if (mb_dispatch<_Float16>(a, 1, k, stride, kin, &n, nullptr) != AVEXHIP_OK) return 0;
+    return n;
+}
+// expansion (kin = 32 | 64 input channels read from rows of ld_in; kin = 0: none, the input already has cp_exp channels) + depthwise k x k
+// + SiLU + squeeze partials; in [B, H, W, ld_in], out [B, Ho, Wo, cp_exp] (cp_exp % 32 == 0), pool [B, cp_exp] or NULL with
+// part >= B * mbconv_front_tiles() * cp_exp floats
+int mbconv_front(const void* in, int B, int H, int W, int ld_in, int kin, const void* w_exp, int ldw, const float* b_exp, int k, int stride,
+                 const float* w_dw, const float* b_dw, int cp_exp, void* out, float* pool, float* part, size_t part_bytes, unsigned int* ovf,
+                 int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && w_dw && b_dw && out && B > 0 && H > 0 && W > 0 && cp_exp > 0 && cp_exp % 32 == 0 && B <= 65535, "mbconv_front: bad arguments");
+    AVX_REQUIRE(kin == 0 || (w_exp && b_exp && ld_in >= kin && ldw >= kin), "mbconv_front: expansion weights missing or rows shorter than K = %d", kin);
+    AVX_REQUIRE(kin != 0 || ld_in >= cp_exp, "mbconv_front: input rows of %d channels, %d wanted", ld_in, cp_exp);
+    MbArgs a;
+    memset(&a, 0, sizeof(a));
+    const int pad = (k - 1) / 2;
+    a.in = in; a.H = H; a.W = W; a.ld_in = ld_in; a.w_exp = w_exp; a.ldw = ldw; a.b_exp = b_exp; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.out = out; a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1; a.cp_exp = cp_exp; a.ovf = ovf;
+    const int64_t tiles = mbconv_front_tiles(H, W, k, stride, kin);
+    AVX_REQUIRE(tiles > 0, "mbconv_front: kernel %d stride %d K %d not built", k, stride, kin);
+    if (pool) {
+        AVX_REQUIRE(part && part_bytes >= sizeof(float) * (size_t)B * tiles * cp_exp, "mbconv_front: %zu bytes of squeeze scratch wanted, %zu given",
+                    sizeof(float) * (size_t)B * tiles * cp_exp, part_bytes);
+        a.part = part;
+    }
+    const int rc = dtype == AVEXHIP_BF16 ? mb_dispatch<__bf16>(a, B, k, stride, kin, nullptr, s) : mb_dispatch<_Float16>(a, B, k, stride, kin, nullptr, s);
+    if (rc != AVEXHIP_OK) return rc;
+    if (pool) {
+        hipLaunchKernelGGL(pool_sum_kernel, dim3((cp_exp + 255) / 256, B), dim3(256), 0, s, part, (int)tiles, cp_exp, pool);
+        AVX_LAUNCH_CHECK();
+    }
+    return AVEXHIP_OK;
+}
+}  // namespace avx
 
 namespace avx {
 int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s) {

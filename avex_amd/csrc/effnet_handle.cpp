@@ -53,6 +53,19 @@ struct Block {
     float* proj_scale = nullptr; float* proj_shift = nullptr;       // the folded BatchNorm of the projection, to undo it in a tap
 };
 
+// The front of a block (expansion + depthwise) in one kernel (avx::mbconv_front) where the block's input is narrow enough to expand on the
+// fly: K = 32 or 64 input channels (EfficientNet-B0: the five blocks at 64 x 501 ... 16 x 126, whose expanded tensors are the largest of
+// the network) and for the block without an expansion.  Returns -1 (unfused), 0 (no expansion), 32 or 64.  AVEX_AMD_MBCONV=0: never.
+inline int fused_kin(const Block& b) {
+    const char* e = getenv("AVEX_AMD_MBCONV");      // read per call: tests flip it inside one process
+    const bool off = e && atoi(e) == 0;
+    if (off || b.cp_exp % 32 != 0) return -1;
+    if (!b.has_expand) return b.cp_in >= b.cp_exp && b.cp_exp <= 64 ? 0 : -1;
+    if (b.cin <= 32 && b.cp_in >= 32) return 32;
+    if (b.cin <= 64 && b.cp_in >= 64) return 64;
+    return -1;
+}
+
 }  // namespace
 
 struct avexhip_effnet : avxh::HandleBase {
@@ -209,7 +222,9 @@ EffWs eff_carve(const avexhip_effnet* h, char* base, int Bc, int H, int W) {
     size_t max_part = 0;                                   // the depthwise kernel's rows of partial squeeze sums
     for (const Block& b : h->blocks) {
         if ((size_t)hh * ww * b.cp_exp * 2 > max_act) max_act = (size_t)hh * ww * b.cp_exp * 2;
-        const size_t part = avexhip_effnet_dwconv_part_bytes(Bc, hh, ww, b.cp_exp, b.k, b.stride);
+        const int kin = fused_kin(b);
+        const size_t part = kin >= 0 ? sizeof(float) * (size_t)Bc * (size_t)avx::mbconv_front_tiles(hh, ww, b.k, b.stride, kin) * b.cp_exp
+                                     : avexhip_effnet_dwconv_part_bytes(Bc, hh, ww, b.cp_exp, b.k, b.stride);
         if (part > max_part) max_part = part;
         hh = conv_out(hh, b.k, b.stride); ww = conv_out(ww, b.k, b.stride);
         if ((size_t)hh * ww * b.cp_exp * 2 > max_act) max_act = (size_t)hh * ww * b.cp_exp * 2;
@@ -321,7 +336,8 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             const int M_in = Bc * hh * ww;
             int x = in_buf;
             avx::GemmArgs g;
-            if (b.has_expand) {
+            const int kin = fused_kin(b);
+            if (b.has_expand && kin < 0) {
                 const int o = (in_buf + 1) & 3;
                 memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
                 g.A = w.act[in_buf]; g.lda = b.cp_in; g.W = b.w_exp; g.ldw = b.cp_in; g.M = M_in; g.N = pad128(b.cexp); g.K = b.cp_in; g.bias = b.b_exp; g.gelu = 2;
@@ -336,9 +352,16 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             }
             const int dw = (in_buf + 2) & 3;
             const int h2 = conv_out(hh, b.k, b.stride), w2 = conv_out(ww, b.k, b.stride);
-            prof.begin("dwconv", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k);
-            RC(avexhip_effnet_dwconv(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.pool, w.part, w.part_bytes, dt, s));
-            prof.end();
+            if (kin >= 0) {
+                prof.begin("mbconv.front", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k + (b.has_expand ? 2.0 * M_in * (double)b.cexp * b.cin : 0.0));
+                RC(avx::mbconv_front(w.act[in_buf], Bc, hh, ww, b.cp_in, kin, b.w_exp, b.cp_in, b.b_exp, b.k, b.stride, b.w_dw, b.b_dw, b.cp_exp, w.act[dw],
+                                     w.pool, w.part, w.part_bytes, h->d_ovf, dt, s));
+                prof.end();
+            } else {
+                prof.begin("dwconv", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k);
+                RC(avexhip_effnet_dwconv(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.pool, w.part, w.part_bytes, dt, s));
+                prof.end();
+            }
             const int M2 = Bc * h2 * w2;
             const int out = (in_buf + 3) & 3;
             const bool hooked = b.tap && ((hook_mask >> (tap + 1)) & 1u);

@@ -913,3 +913,31 @@ def test_effnet_b0_matches_oracle(built_lib):
     again = enc.forward(_dev(mel), hook_layers=[names[-1]], want_features=True, want_pooled=True)      # no float atomics anywhere: bit for bit
     assert torch.equal(again["features"], r["features"]) and torch.equal(again["pooled"], r["pooled"])
     assert torch.equal(again["hooks"][names[-1]], r["hooks"][names[-1]])
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("stages", ["b0", "b1"])
+def test_effnet_fused_block_front_matches_the_unfused_kernels(built_lib, monkeypatch, dtype, stages):
+    """avx::mbconv_front (expansion + depthwise convolution + squeeze sums in one kernel, effnet.hip) against the expansion GEMM and
+    dwconv_kernel it replaces (AVEX_AMD_MBCONV=0), on an image whose sizes are not multiples of any tile (ragged tiles on both axes, halos
+    that leave the image on all four sides).  Both forms round at the same places and add their taps in the same order; what differs is
+    the order in which the squeeze partial sums are added (one row per workgroup, different workgroups), i.e. fp32 rounding of the
+    squeeze-excitation scale, which flips an occasional operand rounding downstream."""
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    st = synth.EFFNET_B0_STAGES if stages == "b0" else synth.EFFNET_B1_STAGES
+    sd = synth.effnet_b0_state_dict(stages=st) if stages == "b1" else synth.effnet_b0_state_dict()
+    kw = {"stages": st} if stages == "b1" else {}
+    mel = _dev(np.abs(synth.normal("emelf", (3, 70, 133), 0.5)).astype(np.float32))
+    enc = EfficientNetB0Encoder(sd, operand_dtype=dtype, **kw)
+    names = enc.tap_names()
+    fused = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
+    monkeypatch.setenv("AVEX_AMD_MBCONV", "0")
+    plain = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
+    monkeypatch.delenv("AVEX_AMD_MBCONV")
+    tol = 2e-4 if dtype == "f16" else 1.5e-3
+    assert torch.equal(fused["hooks"][names[0]], plain["hooks"][names[0]])          # the stem is not touched
+    for n in names[1:]:
+        assert rel_l2(fused["hooks"][n].cpu().numpy(), plain["hooks"][n].cpu().numpy()) < tol, n
+    assert rel_l2(fused["pooled"].cpu().numpy(), plain["pooled"].cpu().numpy()) < tol
+    again = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
+    assert torch.equal(again["features"], fused["features"]) and torch.equal(again["pooled"], fused["pooled"])
