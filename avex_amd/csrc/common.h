@@ -330,7 +330,7 @@ struct GemmArgs {
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // fp32 NHWC rows [B * HW, ld] -> NCHW [B, C, HW], optionally undoing a folded BatchNorm: (x - shift[c]) / scale[c] (effnet.hip)
 int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s);
-// MBConv front in one kernel: 1x1 expansion (kin = 32 | 64; 0 = none) + BN + SiLU + depthwise k x k + BN + SiLU + squeeze sums (effnet.hip)
+// MBConv front in one kernel: 1x1 expansion (kin = 32 | 64 input channels) + BN + SiLU + depthwise k x k + BN + SiLU + squeeze sums (effnet.hip)
 int64_t mbconv_front_tiles(int H, int W, int k, int stride, int kin);
 int mbconv_front(const void* in, int B, int H, int W, int ld_in, int kin, const void* w_exp, int ldw, const float* b_exp, int k, int stride,
                  const float* w_dw, const float* b_dw, int cp_exp, void* out, float* pool, float* part, size_t part_bytes, unsigned int* ovf,

@@ -262,12 +262,12 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, 
 //   2. the depthwise taps from LDS in (ky, kx) order (the order dwconv_kernel adds them: same bits), bias + SiLU, 16-byte stores, and the
 //      squeeze sums as one row of partials per workgroup (pool_sum_kernel adds the rows in order).
 // The halo is expanded by every tile that needs it (1.2 - 1.5 x the SiLUs of the unfused expansion); what is saved is 2 x the expanded
-// tensor of HBM traffic.  KIN = 0: no expansion (the first block of EfficientNet, and a depthwise convolution on its own): step 1 is a
-// copy of the chunk's channels from global memory.
+// tensor of HBM traffic.  The kernel is bound by its vector instructions (two transcendentals per SiLU), not by memory.
+// Global loads and the vmcnt counter: every parameter a chunk needs (expansion weight fragments, depthwise weights, biases) is requested
+// at the top of the PREVIOUS chunk and consumed before that chunk's output stores are issued -- a wait placed after the stores would have
+// to be vmcnt(0) (the stores are conditional, the compiler cannot count them) and would drain them: 1 - 2 us per chunk of ~1 us of work.
 // ---------------------------------------------------------------------------------------------
-#ifndef MB_WAVES
-#define MB_WAVES 3      // waves per SIMD the fused kernel is compiled for (168 registers): without the bound hipcc hoists every LDS read of an item to its top (220 - 512 registers, spills at 5 x 5)
-#endif
+typedef int a_i32x2m __attribute__((ext_vector_type(2)));
 struct MbArgs {
     const void* in; int H, W, ld_in;
     const void* w_exp; int ldw; const float* b_exp;
@@ -281,26 +281,27 @@ struct MbArgs {
 template <int KS, int ST, int KIN, int TH, int TW, int CC>
 struct MbGeo {
     static constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, NPIX = IH * IW, NPG = (NPIX + 15) / 16, NPX = NPG * 16;
-    static constexpr int ISTR = KIN > 0 ? KIN * 2 + 16 : 0;      // bytes per input pixel in LDS (16 bytes of padding: the 16 pixels of an MFMA fragment read meet 16 distinct bank groups)
-    static constexpr int ESTR = CC * 2 + 16;                     // bytes per expanded pixel
-    static constexpr int LDS = NPX * (ISTR + ESTR) + KS * KS * CC * 4 + 4 * CC * 4;
+    static constexpr int ISTR = KIN * 2 + 16;      // bytes per input pixel in LDS (16 bytes of padding: the 16 pixels of an MFMA fragment read meet 16 distinct bank groups)
+    static constexpr int ESTR = CC * 2 + 16;       // bytes per expanded pixel
+    static constexpr int NWD = KS * KS * CC;       // depthwise weights per chunk (floats), double-buffered
+    static constexpr int LDS = NPX * (ISTR + ESTR) + 2 * NWD * 4 + 16 * CC * 4;
+    static constexpr int WPE = (3 * LDS <= 160 * 1024 && KIN == 32) ? 3 : 2;      // waves per SIMD the kernel is compiled for (168 or 256 registers): the workgroups per CU the LDS allows; K = 64 needs the 256 (two sets of weight fragments in flight)
 };
 
 template <typename T, int KS, int ST, int KIN, int TH, int TW, int PIX, int CC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB_WAVES, MB_WAVES))) void mbconv_kernel(const MbArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, ST, KIN, TH, TW, CC>::WPE, MbGeo<KS, ST, KIN, TH, TW, CC>::WPE))) void mbconv_kernel(const MbArgs p) {
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     typedef MbGeo<KS, ST, KIN, TH, TW, CC> G;
-    constexpr bool EXPAND = KIN > 0;
-    constexpr int PAD = (KS - 1) / 2, IW = G::IW, NPIX = G::NPIX, NPG = G::NPG, NPX = G::NPX, ISTR = G::ISTR, ESTR = G::ESTR;
+    constexpr int PAD = (KS - 1) / 2, IW = G::IW, NPIX = G::NPIX, NPG = G::NPG, NPX = G::NPX, ISTR = G::ISTR, ESTR = G::ESTR, NWD = G::NWD;
     constexpr int NCOL = (PIX - 1) * ST + KS, SXN = TW / PIX, NCG = CC / 8, NITEM = TH * SXN * NCG;
-    constexpr int KST = EXPAND ? KIN / 32 : 1, MT = CC / 16;
-    static_assert(TW % PIX == 0 && NITEM % 256 == 0 && (NCG == 4 || NCG == 8), "mbconv tile");
+    constexpr int KST = KIN / 32, MT = CC / 16, NWR = (NWD + 255) / 256;
+    static_assert(TW % PIX == 0 && NITEM % 256 == 0 && NCG == 4 && KIN % 32 == 0 && KIN > 0, "mbconv tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_in = smem;
     char* s_exp = smem + NPX * ISTR;
-    float* s_w = (float*)(s_exp + NPX * ESTR);
-    float* s_red = s_w + KS * KS * CC;
+    float* s_w = (float*)(s_exp + NPX * ESTR);       // [2][NWD]
+    float* s_red = s_w + 2 * NWD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -309,9 +310,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB_WAVES, M
     const T* in = (const T*)p.in + (int64_t)b * p.H * p.W * p.ld_in;
     T* out = (T*)p.out + (int64_t)b * p.Ho * p.Wo * p.cp_exp;
     const int cp = p.cp_exp;
+    const int lr = lane & 15, lq = lane >> 4, cg = tid & (NCG - 1);
     float ovf_mx = 0.f;
 
-    if constexpr (EXPAND) {
+    // parameters of a chunk: expansion weight fragments + bias (this lane's MFMA operands), depthwise bias of the lane's channel group, and
+    // the thread's share of the chunk's depthwise weights on their way to LDS
+    struct Par { v8 wf[MT][KST]; f32x4 be[MT]; f32x4 bd0, bd1; float wd[NWR]; };
+    auto request = [&](Par& q, int c) __attribute__((always_inline)) {
+        const T* W = (const T*)p.w_exp;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) q.wf[mt][ks] = *(const v8*)(W + (int64_t)(c + 16 * mt + lr) * p.ldw + ks * 32 + lq * 8);
+            q.be[mt] = *(const f32x4*)(p.b_exp + c + 16 * mt + 4 * lq);
+        }
+        q.bd0 = *(const f32x4*)(p.b_dw + c + cg * 8);
+        q.bd1 = *(const f32x4*)(p.b_dw + c + cg * 8 + 4);
+#pragma unroll
+        for (int r = 0; r < NWR; ++r) {
+            const int i = tid + 256 * r;
+            q.wd[r] = i < NWD ? p.w_dw[(int64_t)(i / CC) * cp + c + (i % CC)] : 0.f;
+        }
+    };
+    auto stage_wd = [&](const Par& q, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < NWR; ++r) {
+            const int i = tid + 256 * r;
+            if (i < NWD) s_w[slot * NWD + i] = q.wd[r];
+        }
+    };
+    Par cur;
+    request(cur, 0);
+    {
         constexpr int NCH = KIN / 8;
         for (int i = tid; i < NPX * NCH; i += 256) {
             const int pix = i / NCH, ch = i - pix * NCH;
@@ -322,66 +352,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB_WAVES, M
             *(uint4*)(s_in + pix * ISTR + ch * 16) = v;
         }
     }
-    const int lr = lane & 15, lq = lane >> 4;
-    v8 wf[MT][KST];
-    f32x4 be[MT];
-    auto load_w = [&](int c) __attribute__((always_inline)) {
-        if constexpr (EXPAND) {
-            const T* W = (const T*)p.w_exp;
+    stage_wd(cur, 0);
+    // which of this lane's pixels (pixel group wave + 4 j, pixel lr of it) lie inside the image: the same for every chunk
+    constexpr int NJ = (NPG + 3) / 4;
+    static_assert(NJ <= 32, "mbconv: pixel groups per wave");
+    unsigned inside_bits = 0u;
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+        const int pix = (wave + 4 * j) * 16 + lr;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        if (pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) inside_bits |= 1u << j;
+    }
+    __syncthreads();                                     // the input tile and chunk 0's depthwise weights
+
+    int slot = 0;
+    for (int c = 0; c < cp; c += CC, slot ^= 1) {
+        const bool more = c + CC < cp;
+        Par nxt;
+        if (more) request(nxt, c + CC);                  // in flight under the expansion below
+        auto expand_group = [&](int j) __attribute__((always_inline)) {
+            const int pix = (wave + 4 * j) * 16 + lr;
+            const bool inside = (inside_bits >> j) & 1u;
+            v8 xf[KST];
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) xf[ks] = *(const v8*)(s_in + pix * ISTR + ks * 64 + lq * 16);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KST; ++ks) wf[mt][ks] = *(const v8*)(W + (int64_t)(c + 16 * mt + lr) * p.ldw + ks * 32 + lq * 8);
-                be[mt] = *(const f32x4*)(p.b_exp + c + 16 * mt + 4 * lq);
+                for (int ks = 0; ks < KST; ++ks) acc = mfma16(cur.wf[mt][ks], xf[ks], acc);
+                const f32x4 v = silu4(acc + cur.be[mt]);
+                ovf_see4<T>(ovf_mx, v);
+                v4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = Half<T>::from(v[e]);
+                a_i32x2m hb = __builtin_bit_cast(a_i32x2m, h);
+                hb[0] = inside ? hb[0] : 0; hb[1] = inside ? hb[1] : 0;
+                *(a_i32x2m*)(s_exp + pix * ESTR + (16 * mt + 4 * lq) * 2) = hb;
             }
-        }
-    };
-    load_w(0);
-    const int cg = tid & (NCG - 1);
-    for (int c = 0; c < cp; c += CC) {
-        // depthwise weights of the chunk (the previous chunk's taps are done: barrier at the end of the loop body)
-        for (int i = tid; i < KS * KS * CC; i += 256) s_w[i] = p.w_dw[(int64_t)(i / CC) * cp + c + (i % CC)];
-        if constexpr (EXPAND) {
-            if (c == 0) __syncthreads();                 // the input tile
-            for (int pg = wave; pg < NPG; pg += 4) {
-                const int pix = pg * 16 + lr;
-                const int iy = pix / IW, ix = pix - iy * IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                const bool inside = pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                v8 xf[KST];
-#pragma unroll
-                for (int ks = 0; ks < KST; ++ks) xf[ks] = *(const v8*)(s_in + pix * ISTR + ks * 64 + lq * 16);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < KST; ++ks) acc = mfma16(wf[mt][ks], xf[ks], acc);
-                    f32x4 v = acc + be[mt];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu1(v[e]);
-                    ovf_see4<T>(ovf_mx, v);
-                    v4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = inside ? Half<T>::from(v[e]) : (T)0.0f;
-                    *(v4*)(s_exp + pix * ESTR + (16 * mt + 4 * lq) * 2) = h;
-                }
-            }
-            if (c + CC < cp) load_w(c + CC);             // the next chunk's weight fragments arrive under the taps below
-        } else {
-            for (int i = tid; i < NPX * NCG; i += 256) {
-                const int pix = i / NCG, ch = i - pix * NCG;
-                const int iy = pix / IW, ix = pix - iy * IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                uint4 v = {0u, 0u, 0u, 0u};
-                if (pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *(const uint4*)(in + ((int64_t)gy * p.W + gx) * p.ld_in + c + ch * 8);
-                *(uint4*)(s_exp + pix * ESTR + ch * 16) = v;
-            }
+        };
+        // every wave has NPG / 4 groups (two at a time: independent chains for the transcendentals), the first NPG % 4 waves one more
+#pragma unroll 2
+        for (int j = 0; j < NPG / 4; ++j) expand_group(j);
+        if (NPG % 4 != 0 && wave < NPG % 4) expand_group(NPG / 4);
+        const f32x4 bd0 = cur.bd0, bd1 = cur.bd1;
+        if (more) {                                      // every load of this chunk is consumed HERE, before the taps' stores
+            stage_wd(nxt, slot ^ 1);
+            cur = nxt;
         }
         __syncthreads();
         float psum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) psum[e] = 0.f;
-        const f32x4 bd0 = *(const f32x4*)(p.b_dw + c + cg * 8), bd1 = *(const f32x4*)(p.b_dw + c + cg * 8 + 4);
 #pragma unroll
         for (int it = tid; it < NITEM; it += 256) {
             const int t = it / NCG;
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB_WAVES, M
             // one input row per trip of a ROLLED loop: unrolled, hipcc issues every LDS read of the item before its first tap (220 - 512
             // registers, spills at 5 x 5; scheduling barriers do not pin the taps, which are pure arithmetic)
             const char* rowp = s_exp + ((oyl * ST) * IW + sx * PIX * ST) * ESTR + cg * 16;
-            const float* wrow = s_w + cg * 8;
+            const float* wrow = s_w + slot * NWD + cg * 8;
 #pragma unroll 1
             for (int r = 0; r < KS; ++r) {
                 v8 col[NCOL];
@@ -421,33 +444,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB_WAVES, M
             for (int q = 0; q < PIX; ++q) {
                 const int ox = ox0 + sx * PIX + q;
                 if (oy < p.Ho && ox < p.Wo) {
+                    const f32x4 y0 = silu4((f32x4){acc[q][0], acc[q][1], acc[q][2], acc[q][3]} + bd0);
+                    const f32x4 y1 = silu4((f32x4){acc[q][4], acc[q][5], acc[q][6], acc[q][7]} + bd1);
                     v8 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float y = silu1(acc[q][e] + (e < 4 ? bd0[e] : bd1[e - 4]));
-                        h[e] = Half<T>::from(y);
-                        psum[e] += (float)h[e];
-                    }
+                    for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(y0[e]); h[4 + e] = Half<T>::from(y1[e]); }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) psum[e] += (float)h[e];
                     *(v8*)(out + ((int64_t)oy * p.Wo + ox) * cp + c + cg * 8) = h;
                 }
             }
         }
         if (p.part) {
-            // lanes with the same channel group: bits 2.. (NCG = 4) or 3.. (NCG = 8) of the lane number
+            // lanes with the same channel group are 4 apart: two DPP row shifts leave each 16-lane row's sums in its lanes 12 .. 15; the
+            // sixteen rows of a workgroup are added in a fixed order below (no shuffles through the LDS crossbar: 32 ds_bpermute per chunk)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float s = psum[e];
-#pragma unroll
-                for (int m = NCG; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x114, 0xf, 0xf, true));      // row_shr:4
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x118, 0xf, 0xf, true));      // row_shr:8
                 psum[e] = s;
             }
-            if (lane < NCG) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s_red[wave * CC + lane * 8 + e] = psum[e];
+            if ((lane & 15) >= 12) {
+                float* dst = s_red + (wave * 4 + (lane >> 4)) * CC + ((lane & 15) - 12) * 8;
+                *(f32x4*)dst = (f32x4){psum[0], psum[1], psum[2], psum[3]};
+                *(f32x4*)(dst + 4) = (f32x4){psum[4], psum[5], psum[6], psum[7]};
             }
         }
         __syncthreads();
-        if (p.part && tid < CC) p.part[((int64_t)b * gridDim.x + blockIdx.x) * cp + c + tid] = (s_red[tid] + s_red[CC + tid]) + (s_red[2 * CC + tid] + s_red[3 * CC + tid]);
+        if (p.part && tid < CC) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += s_red[r * CC + tid];
+            p.part[((int64_t)b * gridDim.x + blockIdx.x) * cp + c + tid] = s;
+        }
     }
     ovf_commit<T>(p.ovf, ovf_mx);
 }
@@ -558,7 +588,6 @@ namespace {
 // tile of the fused kernel for (stride, KIN): output rows x columns per workgroup and pixels along x per thread
 template <int ST, int KIN> struct MbTile;
 template <int KIN> struct MbTile<2, KIN> { static constexpr int TH = 4, TW = 16, PIX = 1; };
-template <> struct MbTile<1, 0>  { static constexpr int TH = 8, TW = 32, PIX = 4; };
 template <> struct MbTile<1, 32> { static constexpr int TH = 8, TW = 32, PIX = 4; };
 template <> struct MbTile<1, 64> { static constexpr int TH = 8, TW = 16, PIX = 2; };      // 144-byte input pixels: the narrower tile keeps two workgroups per CU
 
@@ -578,11 +607,10 @@ int mb_launch(const MbArgs& a0, int B, int64_t* n_tiles, hipStream_t s) {
 template <typename T>
 int mb_dispatch(const MbArgs& a, int B, int k, int st, int kin, int64_t* n_tiles, hipStream_t s) {
 #define AVX_MB(KS, ST, KIN) if (k == KS && st == ST && kin == KIN) return mb_launch<T, KS, ST, KIN>(a, B, n_tiles, s)
-    AVX_MB(3, 1, 0); AVX_MB(3, 2, 0); AVX_MB(5, 1, 0); AVX_MB(5, 2, 0);
     AVX_MB(3, 1, 32); AVX_MB(3, 2, 32); AVX_MB(5, 1, 32); AVX_MB(5, 2, 32);
     AVX_MB(3, 1, 64); AVX_MB(3, 2, 64); AVX_MB(5, 1, 64); AVX_MB(5, 2, 64);
 #undef AVX_MB
-    avexhip_set_error("mbconv_front: kernel %d stride %d K %d not built (k 3 | 5, stride 1 | 2, K 0 | 32 | 64)", k, st, kin);
+    avexhip_set_error("mbconv_front: kernel %d stride %d K %d not built (k 3 | 5, stride 1 | 2, K 32 | 64)", k, st, kin);
     return AVEXHIP_ERR_INVALID;
 }
 }  // namespace
@@ -598,15 +626,14 @@ int64_t mbconv_front_tiles(int H, int W, int k, int stride, int kin) {
     if (mb_dispatch<_Float16>(a, 1, k, stride, kin, &n, nullptr) != AVEXHIP_OK) return 0;
     return n;
 }
-// expansion (kin = 32 | 64 input channels read from rows of ld_in; kin = 0: none, the input already has cp_exp channels) + depthwise k x k
+// expansion (kin = 32 | 64 input channels read from rows of ld_in) + depthwise k x k
 // + SiLU + squeeze partials; in [B, H, W, ld_in], out [B, Ho, Wo, cp_exp] (cp_exp % 32 == 0), pool [B, cp_exp] or NULL with
 // part >= B * mbconv_front_tiles() * cp_exp floats
 int mbconv_front(const void* in, int B, int H, int W, int ld_in, int kin, const void* w_exp, int ldw, const float* b_exp, int k, int stride,
                  const float* w_dw, const float* b_dw, int cp_exp, void* out, float* pool, float* part, size_t part_bytes, unsigned int* ovf,
                  int dtype, hipStream_t s) {
     AVX_REQUIRE(in && w_dw && b_dw && out && B > 0 && H > 0 && W > 0 && cp_exp > 0 && cp_exp % 32 == 0 && B <= 65535, "mbconv_front: bad arguments");
-    AVX_REQUIRE(kin == 0 || (w_exp && b_exp && ld_in >= kin && ldw >= kin), "mbconv_front: expansion weights missing or rows shorter than K = %d", kin);
-    AVX_REQUIRE(kin != 0 || ld_in >= cp_exp, "mbconv_front: input rows of %d channels, %d wanted", ld_in, cp_exp);
+    AVX_REQUIRE(w_exp && b_exp && ld_in >= kin && ldw >= kin, "mbconv_front: expansion weights missing or rows shorter than K = %d", kin);
     MbArgs a;
     memset(&a, 0, sizeof(a));
     const int pad = (k - 1) / 2;

@@ -55,12 +55,12 @@ struct Block {
 
 // The front of a block (expansion + depthwise) in one kernel (avx::mbconv_front) where the block's input is narrow enough to expand on the
 // fly: K = 32 or 64 input channels (EfficientNet-B0: the five blocks at 64 x 501 ... 16 x 126, whose expanded tensors are the largest of
-// the network) and for the block without an expansion.  Returns -1 (unfused), 0 (no expansion), 32 or 64.  AVEX_AMD_MBCONV=0: never.
+// the network).  Returns -1 (unfused), 32 or 64.  AVEX_AMD_MBCONV=0: never.
 inline int fused_kin(const Block& b) {
     const char* e = getenv("AVEX_AMD_MBCONV");      // read per call: tests flip it inside one process
     const bool off = e && atoi(e) == 0;
     if (off || b.cp_exp % 32 != 0) return -1;
-    if (!b.has_expand) return b.cp_in >= b.cp_exp && b.cp_exp <= 64 ? 0 : -1;
+    if (!b.has_expand) return -1;
     if (b.cin <= 32 && b.cp_in >= 32) return 32;
     if (b.cin <= 64 && b.cp_in >= 64) return 64;
     return -1;
