@@ -29,13 +29,13 @@ using avxh::Table;
 namespace {
 
 inline int pad128(int c) { return ((c + 127) / 128) * 128; }
-// channels of an activation tensor in memory: 64 for the narrow block outputs of the first stages (16, 24, 40 channels at the largest
-// spatial sizes: padded to 128 they were 3 - 8x their size), else a multiple of 128.  GEMM outputs narrower than the 128-column tile
+inline bool skinny_enabled() { const char* e = getenv("AVEX_AMD_GEMM_SKINNY"); return !(e && atoi(e) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"); }
+// channels of an activation tensor in memory: 32 (16 and 24 channels) or 64 (40) for the narrow block outputs of the first stages (at the
+// largest spatial sizes: padded to 128 they were 3 - 8x their size; only the skinny streaming kernel takes 32), else a multiple of 128.  GEMM outputs narrower than the 128-column tile
 // are computed at pad128 and stored through GemmArgs::n_store.
-inline int padc(int c) { return c <= 64 ? 64 : pad128(c); }
+inline int padc(int c) { return c <= 32 && skinny_enabled() ? 32 : (c <= 64 ? 64 : pad128(c)); }
 // ... and of an EXPANDED tensor: 96 and 144 (-> 160) channels stay that narrow when the skinny streaming kernel is there to take K, N = 96 / 160
 // (padded to 128 / 256 the 144-channel tensors were 44 % padding)
-inline bool skinny_enabled() { const char* e = getenv("AVEX_AMD_GEMM_SKINNY"); return !(e && atoi(e) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"); }
 inline int padx(int c) {
     const int p32 = ((c + 31) / 32) * 32;
     return (skinny_enabled() && (p32 == 96 || p32 == 160)) ? p32 : padc(c);
@@ -368,7 +368,7 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             // long thin projections run in the skinny streaming kernel, which applies the squeeze-excitation scale to its A rows as it loads
             // them: the rescale pass over the expanded tensor (read + write) disappears
             static const bool no_se_fold = getenv("AVEX_AMD_SE_FOLD") && atoi(getenv("AVEX_AMD_SE_FOLD")) == 0;
-            const bool skinny_proj = skinny_enabled() && skinny_dim(b.cp_exp) && pad128(b.cout) * b.cp_exp <= 32768 && (b.cp_out == 64 || b.cp_out == 128 || b.cp_out == 256);
+            const bool skinny_proj = skinny_enabled() && skinny_dim(b.cp_exp) && pad128(b.cout) * b.cp_exp <= 32768 && (b.cp_out == 32 || b.cp_out == 64 || b.cp_out == 128 || b.cp_out == 256);
             bool se_fold = skinny_proj && (!no_se_fold || hooked);      // (the skinny kernel's raw tap comes with the scale)
             // the wider projections (K = 512 ... 1152): the register-staged form of the 128-tile kernel scales its A rows the same way
             static const bool se_fold_wide = !(getenv("AVEX_AMD_SE_FOLD_WIDE") && atoi(getenv("AVEX_AMD_SE_FOLD_WIDE")) == 0);
@@ -382,7 +382,7 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             g.n_store = b.cp_out < g.N ? b.cp_out : 0;
             if (skinny_proj) {      // whatever the row count: the 128-tile kernels do not take K = 32 or 64 columns
                 g.variant = 7;
-                if (b.cp_out == 64) { g.N = 64; g.n_store = 0; }
+                if (b.cp_out < 128) { g.N = b.cp_out; g.n_store = 0; }
                 if (se_fold) { g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }
             }
             if (wide_fold) { g.variant = 1; g.a_scale = w.scale; g.a_scale_rows = h2 * w2; g.a_scale_ld = b.cp_exp; }

@@ -1308,7 +1308,7 @@ static int launch_skinny(const avx::GemmArgs& a, hipStream_t s) {
 // does the skinny kernel take this product?  (half output only, no fp32 / raw outputs, no folded LayerNorm, no row mask)
 static bool skinny_ok(const avx::GemmArgs& a) {
     if (!(a.K == 32 || a.K == 64 || a.K == 96 || a.K == 128 || a.K == 160 || a.K == 256) ||
-        !(a.N == 64 || a.N == 96 || a.N == 128 || a.N == 160 || a.N == 256) || a.N * a.K > 32768) return false;
+        !(a.N == 32 || a.N == 64 || a.N == 96 || a.N == 128 || a.N == 160 || a.N == 256) || a.N * a.K > 32768) return false;
     if (!a.out_half || a.out_f32 || a.resid || a.row_zero || a.ln_rows || a.lnr_y || a.stats_out || a.pool_part) return false;
     if (a.lda % 8 || a.ldw % 8 || a.ldh % 8 || (a.resid_half && a.ldrh % 8) || (a.out_raw && a.ldraw % 4) || (a.n_store > 0 && a.n_store % 16)) return false;
     return true;
@@ -1319,12 +1319,13 @@ static int launch_skinny_any(const avx::GemmArgs& a, hipStream_t s) {
     // the raw fp32 tap exists for the projection widths (N = 64, 128, 256) in one form: with the A-row scale (a NULL a_scale is refused)
 #define AVX_SK(NTV, KSV) if (a.N == NTV * 16 && a.K == KSV * 32) { \
         if (a.out_raw) { \
-            if constexpr (NTV == 4 || NTV == 8 || NTV == 16) { if (a.a_scale) return launch_skinny<T, NTV, KSV, true, true>(a, s); } \
-            avexhip_set_error("gemm: the skinny kernel writes a raw tap only for N = 64 / 128 / 256 with a_scale (N=%d)", a.N); return AVEXHIP_ERR_INVALID; \
+            if constexpr (NTV == 2 || NTV == 4 || NTV == 8 || NTV == 16) { if (a.a_scale) return launch_skinny<T, NTV, KSV, true, true>(a, s); } \
+            avexhip_set_error("gemm: the skinny kernel writes a raw tap only for N = 32 / 64 / 128 / 256 with a_scale (N=%d)", a.N); return AVEXHIP_ERR_INVALID; \
         } \
         return a.a_scale ? launch_skinny<T, NTV, KSV, true, false>(a, s) : launch_skinny<T, NTV, KSV, false, false>(a, s); }
     AVX_SK(4, 1); AVX_SK(8, 1); AVX_SK(4, 2); AVX_SK(4, 4); AVX_SK(4, 8); AVX_SK(8, 2); AVX_SK(8, 4); AVX_SK(8, 8); AVX_SK(16, 2); AVX_SK(16, 4);
     AVX_SK(6, 2); AVX_SK(4, 3); AVX_SK(8, 3); AVX_SK(10, 2); AVX_SK(4, 5); AVX_SK(8, 5);      // EfficientNet's 96- and 144 (-> 160)-channel expansions
+    AVX_SK(2, 1); AVX_SK(2, 2); AVX_SK(2, 3); AVX_SK(2, 4); AVX_SK(2, 5); AVX_SK(2, 8); AVX_SK(6, 1); AVX_SK(10, 1); AVX_SK(16, 1);      // ... and its 16- and 24-channel block outputs kept at 32 channels in memory
 #undef AVX_SK
     avexhip_set_error("gemm: no skinny instantiation for N=%d K=%d", a.N, a.K);
     return AVEXHIP_ERR_INVALID;
@@ -1336,7 +1337,7 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     AVX_REQUIRE(!a.a_scale || ((a.variant == 7 || a.variant == 1) && a.a_scale_rows > 0 && a.a_scale_ld >= a.K && a.a_scale_ld % 4 == 0),
                 "gemm: a_scale is built for the skinny kernel (variant 7) and the register-staged 128-tile kernel (variant 1)");
     if (a.variant == 7) {
-        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K in {32, 64, 96, 128, 160, 256}, N in {64, 96, 128, 160, 256} with N K <= 32768, a half output (N=%d K=%d)", a.N, a.K);
+        AVX_REQUIRE(skinny_ok(a), "gemm: variant 7 (skinny) takes K in {32, 64, 96, 128, 160, 256}, N in {32, 64, 96, 128, 160, 256} with N K <= 32768, a half output (N=%d K=%d)", a.N, a.K);
         return launch_skinny_any<T>(a, s);
     }
     if (a.variant == 0 && a.M >= 32768 && a.K % 64 == 0 && (a.N == 64 || a.N % 128 == 0) && !a.out_raw && skinny_ok(a) &&
