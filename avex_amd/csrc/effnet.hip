@@ -231,6 +231,62 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
     }
 }
 
+// The same squeeze-excitation, taking the depthwise kernels' rows of partial sums directly (pool_sum_kernel's addition order: the same
+// pool bit for bit) and the second layer's weights TRANSPOSED ([Cs][C]): thread c's loads of w2[c][j] were Cs floats apart from its
+// neighbour's (a 128-byte line per lane and instruction; 32 us per launch at C = 1152, Cs = 48), w2t[j][c] is one line per 32 lanes.
+__global__ __launch_bounds__(1024) void se_pool_fc_kernel(const float* __restrict__ part, int nblk, float inv_hw, int C, int Cp, int Cs,
+                                                         const float* __restrict__ w1 /*[Cs][C]*/, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2t /*[Cs][C]*/, const float* __restrict__ b2,
+                                                         float* __restrict__ scale /*[B][Cp]*/) {
+    __shared__ float mean[2048];
+    __shared__ float hid[512];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        const float* p = part + (int64_t)b * nblk * Cp + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = 0;
+        for (; i + 4 <= nblk; i += 4) { s0 += p[(int64_t)i * Cp]; s1 += p[(int64_t)(i + 1) * Cp]; s2 += p[(int64_t)(i + 2) * Cp]; s3 += p[(int64_t)(i + 3) * Cp]; }
+        for (; i < nblk; ++i) s0 += p[(int64_t)i * Cp];
+        mean[c] = ((s0 + s1) + (s2 + s3)) * inv_hw;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // both layers request their weights EIGHT AT A TIME before the first multiply-add of the batch: with run-time trip counts hipcc waits
+    // for every load where it is used, and the 18 + 48 dependent round trips to L2 were the whole 32 us of a launch at C = 1152, Cs = 48.
+    // The order of the additions is unchanged.
+    for (int j = wave; j < Cs; j += 16) {
+        float s = 0.f;
+        const float* wr = w1 + (int64_t)j * C;
+        for (int c0 = lane; c0 < C; c0 += 512) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = c0 + 64 * u < C ? wr[c0 + 64 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + 64 * u < C) s = __builtin_fmaf(w[u], mean[c0 + 64 * u], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) hid[j] = silu1(s + b1[j]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cp; c += 1024) {
+        float v = 0.f;
+        if (c < C) {
+            float s = b2[c];
+            for (int j0 = 0; j0 < Cs; j0 += 8) {
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = j0 + u < Cs ? w2t[(int64_t)(j0 + u) * C + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < Cs) s = __builtin_fmaf(w[u], hid[j0 + u], s);
+            }
+            v = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * s));
+        }
+        scale[(int64_t)b * Cp + c] = v;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, int64_t hw, int Cp, const float* __restrict__ scale) {
     typedef typename Half<T>::v8 v8;
@@ -510,7 +566,6 @@ static int dw_launch(const void* in, int B, int H, int W, int Cp, int k, int st,
     const int pad = (k - 1) / 2;
     const int Ho = (H + 2 * pad - k) / st + 1, Wo = (W + 2 * pad - k) / st + 1;
     const dim3 grid((unsigned)dw_blocks(H, W, Cp, k, st), B);
-    if (!pool) part = nullptr;
 #define AVX_DW(KS, ST) hipLaunchKernelGGL((dwconv_kernel<T, KS, ST>), grid, dim3(256), 0, s, (const T*)in, H, W, Ho, Wo, Cp, w, bias, (T*)out, part)
     if (k == 3 && st == 1) AVX_DW(3, 1);
     else if (k == 3 && st == 2) AVX_DW(3, 2);
@@ -539,6 +594,7 @@ extern "C" int avexhip_effnet_dwconv(const void* in_dev, int B, int H, int W, in
                     "effnet_dwconv: the pooled form wants avexhip_effnet_dwconv_part_bytes() = %zu bytes of scratch, got %zu",
                     avexhip_effnet_dwconv_part_bytes(B, H, W, Cp, k, stride), part_bytes);
     }
+    if (!pool_dev) part_dev = nullptr;
     if (dtype == AVEXHIP_BF16) return dw_launch<__bf16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, part_dev, (hipStream_t)stream);
     return dw_launch<_Float16>(in_dev, B, H, W, Cp, k, stride, w_dev, bias_dev, out_dev, pool_dev, part_dev, (hipStream_t)stream);
 }
@@ -616,6 +672,29 @@ int mb_dispatch(const MbArgs& a, int B, int k, int st, int kin, int64_t* n_tiles
 }  // namespace
 
 namespace avx {
+// depthwise convolution that leaves its rows of squeeze partials in `part` WITHOUT reducing them (se_from_parts does); returns the rows per clip
+int dwconv_parts(const void* in, int B, int H, int W, int Cp, int k, int stride, const float* w, const float* bias, void* out, float* part, size_t part_bytes,
+                 int64_t* rows, int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && w && bias && out && part && rows && B > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0 && Cp <= 2048, "dwconv_parts: bad arguments");
+    AVX_REQUIRE(part_bytes >= avexhip_effnet_dwconv_part_bytes(B, H, W, Cp, k, stride), "dwconv_parts: %zu bytes of scratch wanted, %zu given",
+                avexhip_effnet_dwconv_part_bytes(B, H, W, Cp, k, stride), part_bytes);
+    *rows = dw_blocks(H, W, Cp, k, stride);
+    if (dtype == AVEXHIP_BF16) return dw_launch<__bf16>(in, B, H, W, Cp, k, stride, w, bias, out, nullptr, part, s);
+    return dw_launch<_Float16>(in, B, H, W, Cp, k, stride, w, bias, out, nullptr, part, s);
+}
+// squeeze-excitation scale [B][Cp] from `rows` rows of partial sums per clip; w2t is the second layer TRANSPOSED [Cs][C]; x (or NULL) is rescaled in place
+int se_from_parts(const float* part, int64_t rows, int B, int64_t hw, int C, int Cp, int Cs, const float* w1, const float* b1, const float* w2t,
+                  const float* b2, float* scale, void* x, int dtype, hipStream_t s) {
+    AVX_REQUIRE(part && w1 && b1 && w2t && b2 && scale && rows > 0 && B > 0 && hw > 0 && C > 0 && C <= 2048 && Cp >= C && Cp % 8 == 0 && Cs > 0 && Cs <= 512,
+                "se_from_parts: bad shape C=%d Cp=%d Cs=%d", C, Cp, Cs);
+    hipLaunchKernelGGL(se_pool_fc_kernel, dim3(B), dim3(1024), 0, s, part, (int)rows, 1.0f / (float)hw, C, Cp, Cs, w1, b1, w2t, b2, scale);
+    const dim3 grid(512, B);
+    if (!x) {}
+    else if (dtype == AVEXHIP_BF16) hipLaunchKernelGGL(scale_channels_kernel<__bf16>, grid, dim3(256), 0, s, (__bf16*)x, hw, Cp, scale);
+    else hipLaunchKernelGGL(scale_channels_kernel<_Float16>, grid, dim3(256), 0, s, (_Float16*)x, hw, Cp, scale);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
 // workgroups per clip of the fused kernel = rows of squeeze partials it leaves per clip
 int64_t mbconv_front_tiles(int H, int W, int k, int stride, int kin) {
     MbArgs a;
@@ -641,8 +720,9 @@ int mbconv_front(const void* in, int B, int H, int W, int ld_in, int kin, const 
     a.out = out; a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1; a.cp_exp = cp_exp; a.ovf = ovf;
     const int64_t tiles = mbconv_front_tiles(H, W, k, stride, kin);
     AVX_REQUIRE(tiles > 0, "mbconv_front: kernel %d stride %d K %d not built", k, stride, kin);
-    if (pool) {
-        AVX_REQUIRE(part && part_bytes >= sizeof(float) * (size_t)B * tiles * cp_exp, "mbconv_front: %zu bytes of squeeze scratch wanted, %zu given",
+    AVX_REQUIRE(!pool || part, "mbconv_front: the pooled form wants the scratch for its partial sums");
+    if (part) {
+        AVX_REQUIRE(part_bytes >= sizeof(float) * (size_t)B * tiles * cp_exp, "mbconv_front: %zu bytes of squeeze scratch wanted, %zu given",
                     sizeof(float) * (size_t)B * tiles * cp_exp, part_bytes);
         a.part = part;
     }

@@ -48,7 +48,7 @@ struct Block {
     bool has_expand = false, tap = false, residual = false;
     void* w_exp = nullptr; float* b_exp = nullptr;
     float* w_dw = nullptr; float* b_dw = nullptr;
-    float* se_w1 = nullptr; float* se_b1 = nullptr; float* se_w2 = nullptr; float* se_b2 = nullptr;
+    float* se_w1 = nullptr; float* se_b1 = nullptr; float* se_w2 = nullptr; float* se_b2 = nullptr;      // se_w2: [cs][cexp] (transposed)
     void* w_proj = nullptr; float* b_proj = nullptr;
     float* proj_scale = nullptr; float* proj_shift = nullptr;       // the folded BatchNorm of the projection, to undo it in a tap
 };
@@ -179,7 +179,14 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
                 if (!t1 || t1->numel <= 0) { avexhip_set_error("effnet_create: tensor '%sfc1.bias' missing", se.c_str()); return AVEXHIP_ERR_MISSING; }
                 b.cs = (int)t1->numel;
                 RC(avxh::dev_f32(h, tb, se + "fc1.weight", (int64_t)b.cs * b.cexp, &b.se_w1)); RC(avxh::dev_f32(h, tb, se + "fc1.bias", b.cs, &b.se_b1));
-                RC(avxh::dev_f32(h, tb, se + "fc2.weight", (int64_t)b.cexp * b.cs, &b.se_w2)); RC(avxh::dev_f32(h, tb, se + "fc2.bias", b.cexp, &b.se_b2));
+                {   // second layer transposed [cs][cexp]: coalesced in avx::se_from_parts
+                    std::vector<float> w2, w2t((size_t)b.cs * b.cexp);
+                    RC(avxh::host_f32(h, tb, se + "fc2.weight", (int64_t)b.cexp * b.cs, w2));
+                    for (int ch = 0; ch < b.cexp; ++ch)
+                        for (int j = 0; j < b.cs; ++j) w2t[(size_t)j * b.cexp + ch] = w2[(size_t)ch * b.cs + j];
+                    RC(upload_f32(h, w2t, &b.se_w2));
+                }
+                RC(avxh::dev_f32(h, tb, se + "fc2.bias", b.cexp, &b.se_b2));
             }
             std::vector<float> scp, shp;
             RC(pointwise(h, tb, p + std::to_string(d + 2) + ".0", p + std::to_string(d + 2) + ".1", b.cout, b.cexp, cp, &b.w_proj, &b.b_proj, &scp, &shp));
@@ -352,14 +359,16 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             }
             const int dw = (in_buf + 2) & 3;
             const int h2 = conv_out(hh, b.k, b.stride), w2 = conv_out(ww, b.k, b.stride);
+            int64_t part_rows = 0;                       // rows of squeeze partials per clip the depthwise kernel left
             if (kin >= 0) {
                 prof.begin("mbconv.front", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k + (b.has_expand ? 2.0 * M_in * (double)b.cexp * b.cin : 0.0));
                 RC(avx::mbconv_front(w.act[in_buf], Bc, hh, ww, b.cp_in, kin, b.w_exp, b.cp_in, b.b_exp, b.k, b.stride, b.w_dw, b.b_dw, b.cp_exp, w.act[dw],
-                                     w.pool, w.part, w.part_bytes, h->d_ovf, dt, s));
+                                     nullptr, w.part, w.part_bytes, h->d_ovf, dt, s));
+                part_rows = avx::mbconv_front_tiles(hh, ww, b.k, b.stride, kin);
                 prof.end();
             } else {
                 prof.begin("dwconv", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k);
-                RC(avexhip_effnet_dwconv(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.pool, w.part, w.part_bytes, dt, s));
+                RC(avx::dwconv_parts(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.part, w.part_bytes, &part_rows, dt, s));
                 prof.end();
             }
             const int M2 = Bc * h2 * w2;
@@ -375,7 +384,7 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
             const bool wide_fold = !skinny_proj && !no_se_fold && se_fold_wide && b.cp_exp % 64 == 0;
             se_fold = se_fold || wide_fold;
             prof.begin("se", 0.0);
-            RC(avexhip_effnet_se(w.pool, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, se_fold ? nullptr : w.act[dw], dt, s));
+            RC(avx::se_from_parts(w.part, part_rows, Bc, (int64_t)h2 * w2, b.cexp, b.cp_exp, b.cs, b.se_w1, b.se_b1, b.se_w2, b.se_b2, w.scale, se_fold ? nullptr : w.act[dw], dt, s));
             prof.end();
             memset(&g, 0, sizeof(g)); g.ovf = h->d_ovf;
             g.A = w.act[dw]; g.lda = b.cp_exp; g.W = b.w_proj; g.ldw = b.cp_exp; g.M = M2; g.N = pad128(b.cout); g.K = b.cp_exp; g.bias = b.b_proj; g.alpha = 1.0f;
