@@ -28,6 +28,8 @@ struct MelDev {
     const int* mel_len;
     const int* mel_off;
     const float* mel_w;
+    int mel_nnz;             // packed weights (floats); > 0 with mel_lds: the FFT kernel keeps the CSR bank in LDS
+    int mel_lds;
 };
 
 __device__ __forceinline__ int ord_key(float v) {            // monotonic float -> int
@@ -195,12 +197,47 @@ __device__ __forceinline__ void stockham_pass(const float2* __restrict__ in, flo
     }
 }
 
+// The same pass with N and Ns known at compile time (the EfficientNet frontend's 800 points): the butterflies of a lane are unrolled, so
+// their LDS reads go out together instead of one wait per butterfly, and the index arithmetic is constants.  Same operations in the same
+// order as stockham_pass: the same bits.
+template <int R, int N, int Ns>
+__device__ __forceinline__ void stockham_pass_ct(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int lane) {
+    constexpr int M = N / R, step = N / (Ns * R), NIT = (M + 63) / 64;
+    float2 v[NIT][R];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j = lane + 64 * it;
+        if (M % 64 == 0 || j < M) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[it][t] = in[j + t * M];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j = lane + 64 * it;
+        if (M % 64 == 0 || j < M) {
+            const int k = j % Ns;
+            if (Ns > 1) {
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[it][t] = c_mul(v[it][t], tw[t * k * step]);
+            }
+            if (R == 2) dft2(v[it]); else if (R == 3) dft3(v[it]); else if (R == 4) dft4(v[it]); else dft5(v[it]);
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) out[j0 + t * Ns] = v[it][t];
+        }
+    }
+}
+
 // STFT power spectra by FFT: every wave transforms frame PAIRS packed as one complex sequence (x_a + i x_b), 4 pairs per wave,
 // FB = 8 * waves frames per workgroup.  A wave finishes its two frames on its own -- power spectra into the idle half of its
 // ping-pong buffer, mel (CSR) / log into a [bin][frame] staging tile -- so the only workgroup-wide step is the final coalesced store
 // of that tile (128-byte rows of [clip][bin][frame]) with the per-clip min / max.  LDS: twiddles 8 N + 16 N per wave + the staging
 // tile (n_out x (FB + 1) floats): 74 KB for the EfficientNet setting (800 points, 128 mels), two workgroups per CU.
-template <int FB>
+#ifndef STFT_KNOCK
+#define STFT_KNOCK 0      // diagnostic builds: bit 0 no FFT passes, bit 1 no spectrum split, bit 2 no mel / log stage, bit 3 no sample loads (timing only, wrong results)
+#endif
+template <int FB, int NF = 0>      // NF: n_fft when its passes are compiled in (800: radices 5 5 4 4 2, the planner's order), 0 = any length at run time
 __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float* __restrict__ wav, int64_t T, int64_t stride, int frames,
                                                           float* __restrict__ out, int* __restrict__ minmax, int take_log) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -211,7 +248,16 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
     float2* tw = (float2*)smem;                                   // [N]
     float2* buf = tw + N + (size_t)wave * 2 * N;                  // this wave's ping-pong buffers
     float* stage = (float*)(tw + N + (size_t)NW * 2 * N);         // [n_out][FB + 1]
-    for (int i = tid; i < N; i += FB * 8) tw[i] = md.tw[i];
+    for (int i = tid; i < ((STFT_KNOCK & 16) ? 0 : N); i += FB * 8) tw[i] = md.tw[i];
+    // mel bank in LDS (planner: mel_lds): [n_out] start, [n_out] length, [n_out] offset, [nnz] weights
+    int* lb = (int*)(stage + (size_t)md.n_out * SLD);
+    const int* m_start = md.mel_start; const int* m_len = md.mel_len; const int* m_off = md.mel_off; const float* m_w = md.mel_w;
+    if (md.mel_lds) {
+        for (int i = tid; i < md.n_out; i += FB * 8) { lb[i] = md.mel_start[i]; lb[md.n_out + i] = md.mel_len[i]; lb[2 * md.n_out + i] = md.mel_off[i]; }
+        float* lw = (float*)(lb + 3 * md.n_out);
+        for (int i = tid; i < md.mel_nnz; i += FB * 8) lw[i] = md.mel_w[i];
+        m_start = lb; m_len = lb + md.n_out; m_off = lb + 2 * md.n_out; m_w = lw;
+    }
     __syncthreads();
     const float* src = wav + (int64_t)b * stride;
     for (int pr = 0; pr < 4; ++pr) {
@@ -226,9 +272,10 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         const bool interior = base >= 0 && base + md.hop + N <= T && fa + 1 < frames;
         if (interior && ((N | md.hop) & 3) == 0 && (((uintptr_t)(src + base) | (uintptr_t)md.win) & 15) == 0) {
             // ... four samples per lane and load when everything is 16-byte aligned (hop 160, 800 points, rows of 160 000 samples: always)
+            // (requesting the NEXT pair's samples ahead of this pair's passes was measured: no gain, the partner waves cover the round trip)
             const float* s0 = src + base;
             const int hop = md.hop;
-            for (int n = 4 * lane; n < N; n += 256) {
+            for (int n = 4 * lane; n < ((STFT_KNOCK & 8) ? 0 : N); n += 256) {
                 const f32x4 w = *(const f32x4*)(md.win + n), xa = *(const f32x4*)(s0 + n), xb = *(const f32x4*)(s0 + n + hop);
                 const f32x4 za = xa * w, zb = xb * w;
                 *(f32x4*)(A + n) = (f32x4){za[0], zb[0], za[1], zb[1]};
@@ -264,8 +311,21 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         }
         const bool live_a = __any(nza), live_b = __any(nzb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private buffers: a wave's LDS operations execute in order
+        if constexpr (NF == 800 && !(STFT_KNOCK & 1)) {
+            stockham_pass_ct<5, 800, 1>(A, Bf, tw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stockham_pass_ct<5, 800, 5>(Bf, A, tw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stockham_pass_ct<4, 800, 25>(A, Bf, tw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stockham_pass_ct<4, 800, 100>(Bf, A, tw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stockham_pass_ct<2, 800, 400>(A, Bf, tw, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float2* t_ = A; A = Bf; Bf = t_;             // five passes: the spectrum is in the second buffer
+        }
         int Ns = 1;
-        for (int p = 0; p < md.n_pass; ++p) {
+        for (int p = 0; p < (NF ? 0 : md.n_pass); ++p) {
             const int R = md.radix[p];
             if (R == 5) stockham_pass<5>(A, Bf, tw, N, Ns, lane);
             else if (R == 4) stockham_pass<4>(A, Bf, tw, N, Ns, lane);
@@ -278,7 +338,7 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         // split the two real spectra (conjugate symmetry); their power goes to the idle buffer (2 N floats >= 2 (N/2 + 2))
         float* pa = (float*)Bf;
         float* pb = pa + nf + 1;
-        for (int k = lane; k < nf; k += 64) {
+        for (int k = lane; k < ((STFT_KNOCK & 2) ? 0 : nf); k += 64) {
             const float2 zk = A[k], zn = A[k == 0 ? 0 : N - k];
             const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
             const float br = 0.5f * (zk.y + zn.y), bi = -0.5f * (zk.x - zn.x);
@@ -287,15 +347,26 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // mel (CSR) or plain bins, log -> staging tile
-        for (int m = lane; m < md.n_out; m += 64) {
+        for (int m = lane; m < ((STFT_KNOCK & 4) ? 0 : md.n_out); m += 64) {
             float ea, eb;
             if (md.use_mel) {
-                const int st = md.mel_start[m], len = md.mel_len[m], off = md.mel_off[m];
+                const int st = m_start[m], len = m_len[m], off = m_off[m];
                 ea = 0.f; eb = 0.f;
-                for (int q = 0; q < len; ++q) {
-                    const float w = md.mel_w[off + q];
-                    ea = __builtin_fmaf(pa[st + q], w, ea);
-                    eb = __builtin_fmaf(pb[st + q], w, eb);
+                // four taps requested together (weights from L1 / L2, spectra from LDS) before their multiply-adds: one wait per four taps
+                // instead of one per tap (the widest filters of 128 mels over 401 bins have 18).  Same order of additions.
+                for (int q0 = 0; q0 < len; q0 += 4) {
+                    float w[4], xa[4], xb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool on = q0 + u < len;
+                        w[u] = on ? m_w[off + q0 + u] : 0.f;
+                        xa[u] = on ? pa[st + q0 + u] : 0.f;
+                        xb[u] = on ? pb[st + q0 + u] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (q0 + u < len) { ea = __builtin_fmaf(xa[u], w[u], ea); eb = __builtin_fmaf(xb[u], w[u], eb); }
+                    }
                 }
             } else {
                 ea = pa[m]; eb = pb[m];
@@ -309,16 +380,25 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
     // coalesced store [clip][bin][frame] (FB consecutive frames per row) + per-clip min / max
     float mn = __builtin_inff(), mx = -__builtin_inff();
     const int f = tid % FB, fr_ok = f0 + f < frames;
-    for (int m = tid / FB; m < md.n_out; m += (FB * 8) / FB) {
+#pragma unroll 4
+    for (int m = tid / FB; m < ((STFT_KNOCK & 32) ? 0 : md.n_out); m += (FB * 8) / FB) {
         const float y = stage[m * SLD + f];
         if (fr_ok) {
             out[((int64_t)b * md.n_out + m) * frames + f0 + f] = y;
             mn = fminf(mn, y); mx = fmaxf(mx, y);
         }
     }
-    if (minmax) {
+    if (minmax && !(STFT_KNOCK & 64)) {
+        // one pair of atomics per workgroup (through the staging tile, which every wave has finished reading), not per wave: 65 k atomics
+        // on 512 addresses were 44 us of the kernel
         mn = -wave_max(-mn); mx = wave_max(mx);
-        if (lane == 0 && mx >= mn) { atomicMin(minmax + 2 * b, ord_key(mn)); atomicMax(minmax + 2 * b + 1, ord_key(mx)); }
+        __syncthreads();
+        if (lane == 0) { stage[2 * wave] = mn; stage[2 * wave + 1] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) { mn = fminf(mn, stage[2 * w]); mx = fmaxf(mx, stage[2 * w + 1]); }
+            if (mx >= mn) { atomicMin(minmax + 2 * b, ord_key(mn)); atomicMax(minmax + 2 * b + 1, ord_key(mx)); }
+        }
     }
 }
 
@@ -442,7 +522,14 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
     md.tw = (const float2*)(base + o_tw); md.win = (const float*)(base + o_win);
     const int nseg = hop * 31 + N;
     const int xs_words = nseg + (md.skew ? nseg / hop + 1 : 0);
-    if (use_fft) p->lds = sizeof(float2) * ((size_t)N + (size_t)(md.fb / 8) * 2 * N) + sizeof(float) * (size_t)n_out * (md.fb + 1);
+    md.mel_nnz = (int)packed.size(); md.mel_lds = 0;
+    if (use_fft) {
+        p->lds = sizeof(float2) * ((size_t)N + (size_t)(md.fb / 8) * 2 * N) + sizeof(float) * (size_t)n_out * (md.fb + 1);
+        // the mel bank (CSR: start / length / offset per mel + packed weights, ~5 KB at 128 mels over 401 bins) beside them when the
+        // workgroups per CU stay the same: its loads in the mel stage are then LDS reads instead of dependent trips to L1 / L2
+        const size_t bank = sizeof(int) * 3 * (size_t)n_out + sizeof(float) * packed.size();
+        if (md.use_mel && (160 * 1024) / (p->lds + bank) == (160 * 1024) / p->lds) { md.mel_lds = 1; p->lds += bank; }
+    }
     else p->lds = sizeof(float) * (((xs_words + 3) & ~3) + 32 * (size_t)(half + 1));
     if (p->lds > 160 * 1024) { avexhip_set_error("melspec_plan_create: hop=%d n_fft=%d need %zu bytes of LDS", hop, N, p->lds); (void)hipFree(d); delete p; return nullptr; }
     return p;
@@ -479,8 +566,15 @@ extern "C" int avexhip_melspec_forward(const avexhip_melspec_plan* p, const floa
         const int FB = p->dev.fb;
         const dim3 gridf((frames + FB - 1) / FB, B);
         if (FB == 32) {
-            AVX_ENSURE_LDS(stft_fft_kernel<32>, 160 * 1024);
-            hipLaunchKernelGGL(stft_fft_kernel<32>, gridf, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
+            static const bool generic = getenv("AVEX_AMD_STFT_GENERIC") && atoi(getenv("AVEX_AMD_STFT_GENERIC")) != 0;      // A/B: the run-time passes for 800 points too
+            const MelDev& d = p->dev;
+            if (d.n_fft == 800 && d.n_pass == 5 && d.radix[0] == 5 && d.radix[1] == 5 && d.radix[2] == 4 && d.radix[3] == 4 && d.radix[4] == 2 && !generic) {
+                AVX_ENSURE_LDS((stft_fft_kernel<32, 800>), 160 * 1024);
+                hipLaunchKernelGGL((stft_fft_kernel<32, 800>), gridf, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
+            } else {
+                AVX_ENSURE_LDS(stft_fft_kernel<32>, 160 * 1024);
+                hipLaunchKernelGGL(stft_fft_kernel<32>, gridf, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
+            }
         } else {
             AVX_ENSURE_LDS(stft_fft_kernel<16>, 160 * 1024);
             hipLaunchKernelGGL(stft_fft_kernel<16>, gridf, dim3(128), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
