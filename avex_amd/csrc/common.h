@@ -335,6 +335,9 @@ int64_t mbconv_front_tiles(int H, int W, int k, int stride, int kin);
 // the handle's squeeze path: depthwise kernels leave rows of partial sums (part), se_from_parts adds them in order and runs both layers
 int dwconv_parts(const void* in, int B, int H, int W, int Cp, int k, int stride, const float* w, const float* bias, void* out, float* part, size_t part_bytes,
                  int64_t* rows, int dtype, hipStream_t s);
+int64_t dwconv_lds_tiles(int H, int W, int k, int stride);
+int dwconv_lds_parts(const void* in, int B, int H, int W, int Cp, int k, int stride, const float* w, const float* bias, void* out, float* part,
+                     size_t part_bytes, int64_t* rows, int dtype, hipStream_t s);
 int se_from_parts(const float* part, int64_t rows, int B, int64_t hw, int C, int Cp, int Cs, const float* w1, const float* b1, const float* w2t,
                   const float* b2, float* scale, void* x, int dtype, hipStream_t s);
 int mbconv_front(const void* in, int B, int H, int W, int ld_in, int kin, const void* w_exp, int ldw, const float* b_exp, int k, int stride,

@@ -82,13 +82,23 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 #ifndef DW_PY
 #define DW_PY 1       // output rows per thread
 #endif
+#ifndef DW_ROLL
+#define DW_ROLL 0     // 1: the loop over input rows stays rolled (one row of loads live at a time: fewer registers, more waves per SIMD)
+#endif
+#ifndef DW_WAVES
+#define DW_WAVES 0    // > 0: amdgpu_waves_per_eu for dwconv_kernel
+#endif
 // one thread: 8 channels, PIX consecutive output pixels along x of PY consecutive output rows; squeeze sums leave as per-workgroup partials.  The kernel is
 // bound by its 16-byte loads from L2 (every input element is wanted by KS x KS outputs): a 1 x 4 tile makes 4.5 loads per output at 3 x 3
 // (13.5 ms per 256 clips of EfficientNet-B0 at the time), 1 x 8 3.75 (12.8 ms); wider tiles lose to their registers (1 x 12: 13.2, 1 x 16:
 // 14.1 ms), and two-row tiles, fewer loads still, do not pay either (on the final tree: 1 x 8 10.5 ms, 2 x 4 11.0, 2 x 6 10.6, 2 x 8 10.9).
 // Every output adds its taps in (ky, kx) order whatever the tile: the tile shape does not change a bit of the result.
 template <typename T, int KS, int ST>
-__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
+__global__ __launch_bounds__(256)
+#if DW_WAVES
+__attribute__((amdgpu_waves_per_eu(DW_WAVES, DW_WAVES)))
+#endif
+void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
                                                      const float* __restrict__ w /*[KS*KS][Cp]*/, const float* __restrict__ bias,
                                                      T* __restrict__ out, float* __restrict__ part /*[B][gridDim.x][Cp]*/) {
     typedef typename Half<T>::v8 v8;
@@ -114,7 +124,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, i
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[py][p][e] = 0.f;
         const T* src = in + (int64_t)b * H * W * Cp + c8;
+#if DW_ROLL
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
         for (int r = 0; r < NROW; ++r) {
             const int iy = oy0 * ST - PAD + r;
             if (iy < 0 || iy >= H) continue;
@@ -337,7 +351,7 @@ struct MbArgs {
 template <int KS, int ST, int KIN, int TH, int TW, int CC>
 struct MbGeo {
     static constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, NPIX = IH * IW, NPG = (NPIX + 15) / 16, NPX = NPG * 16;
-    static constexpr int ISTR = KIN * 2 + 16;      // bytes per input pixel in LDS (16 bytes of padding: the 16 pixels of an MFMA fragment read meet 16 distinct bank groups)
+    static constexpr int ISTR = KIN > 0 ? KIN * 2 + 16 : 0;      // bytes per input pixel in LDS (16 bytes of padding: the 16 pixels of an MFMA fragment read meet 16 distinct bank groups)
     static constexpr int ESTR = CC * 2 + 16;       // bytes per expanded pixel
     static constexpr int NWD = KS * KS * CC;       // depthwise weights per chunk (floats), double-buffered
     static constexpr int LDS = NPX * (ISTR + ESTR) + 2 * NWD * 4 + 16 * CC * 4;
@@ -641,6 +655,203 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }  // namespace
 
 namespace {
+// ---------------------------------------------------------------------------------------------
+// Depthwise convolution through LDS (the blocks the fused kernel above does not take: no expansion, or more than 64 input channels).
+// dwconv_kernel reads every input element KS times from L1 / L2 (once per input row of the outputs that want it) and is bound by those
+// loads; here a workgroup owns a TH x TW tile of output pixels, walks the channels in chunks of 32, and each chunk's input tile (halo
+// included) crosses L2 ONCE: requested into registers before the previous chunk's taps, written to the other LDS buffer after them --
+// before that chunk's output stores, so the wait for the loads never has to drain stores (see mbconv_kernel) -- and one barrier per
+// chunk.  Small feature maps (8 x 63, 4 x 32) have one or two tiles per clip: gridDim.z splits the chunks over several workgroups.
+// Taps in (ky, kx) order, SiLU, rounding and the squeeze partials (one row per TILE) as in dwconv_kernel: the same output bits.
+// ---------------------------------------------------------------------------------------------
+struct DwArgs {
+    const void* in; int H, W, Cp;
+    const float* w_dw; const float* b_dw;
+    void* out; int Ho, Wo;
+    float* part;                 // [B][tiles][Cp] or NULL
+    int tiles_x, chunks_per_wg;
+};
+
+template <typename T, int KS, int ST, int TH, int TW, int PIX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwconv_lds_kernel(const DwArgs p) {
+    typedef typename Half<T>::v8 v8;
+    typedef MbGeo<KS, ST, 0, TH, TW, 32> G;
+    constexpr int CC = 32, PAD = (KS - 1) / 2, IW = G::IW, NPIX = G::NPIX, NPX = G::NPX, ESTR = G::ESTR, NWD = G::NWD;
+    constexpr int NCOL = (PIX - 1) * ST + KS, SXN = TW / PIX, NCG = 4, NITEM = TH * SXN * NCG;
+    constexpr int NLD = (NPX * NCG + 255) / 256, NWR = (NWD + 255) / 256;
+    static_assert(TW % PIX == 0 && NITEM == 256, "dwconv_lds tile: one item per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_x = smem;                                    // [2][NPX * ESTR]
+    float* s_w = (float*)(smem + 2 * NPX * ESTR);        // [2][NWD]
+    float* s_red = s_w + 2 * NWD;                        // [2][16 * CC]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
+    const int cp = p.Cp;
+    const T* in = (const T*)p.in + (int64_t)b * p.H * p.W * cp;
+    T* out = (T*)p.out + (int64_t)b * p.Ho * p.Wo * cp;
+    const int cg = tid & 3;
+    const int c_begin = blockIdx.z * p.chunks_per_wg * CC;
+    const int c_end = c_begin + p.chunks_per_wg * CC < cp ? c_begin + p.chunks_per_wg * CC : cp;
+
+    // this thread's share of a chunk's input tile: element offsets (channel 0 of the chunk), -1 outside the image / tile
+    int off[NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int i = tid + 256 * r;
+        const int pix = i >> 2, ch = i & 3;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        off[r] = (i < NPX * NCG && pix < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (gy * p.W + gx) * cp + ch * 8 : -1;
+    }
+    struct Par { uint4 x[NLD]; float wd[NWR]; f32x4 bd0, bd1; };
+    auto request = [&](Par& q, int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            q.x[r] = (uint4){0u, 0u, 0u, 0u};
+            if (off[r] >= 0) q.x[r] = *(const uint4*)(in + off[r] + c);
+        }
+#pragma unroll
+        for (int r = 0; r < NWR; ++r) {
+            const int i = tid + 256 * r;
+            q.wd[r] = i < NWD ? p.w_dw[(int64_t)(i / CC) * cp + c + (i % CC)] : 0.f;
+        }
+        q.bd0 = *(const f32x4*)(p.b_dw + c + cg * 8);
+        q.bd1 = *(const f32x4*)(p.b_dw + c + cg * 8 + 4);
+    };
+    auto stage = [&](const Par& q, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int i = tid + 256 * r;
+            if (i < NPX * NCG) *(uint4*)(s_x + slot * (NPX * ESTR) + (i >> 2) * ESTR + (i & 3) * 16) = q.x[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NWR; ++r) {
+            const int i = tid + 256 * r;
+            if (i < NWD) s_w[slot * NWD + i] = q.wd[r];
+        }
+    };
+    Par nx;
+    request(nx, c_begin);
+    stage(nx, 0);
+    f32x4 bd0 = nx.bd0, bd1 = nx.bd1;
+    __syncthreads();
+    const int t = tid >> 2;
+    const int oyl = t / SXN, sx = t - oyl * SXN;
+    const int oy = oy0 + oyl;
+    int slot = 0;
+    for (int c = c_begin; c < c_end; c += CC, slot ^= 1) {
+        const bool more = c + CC < c_end;
+        if (more) request(nx, c + CC);
+        float acc[PIX][8];
+#pragma unroll
+        for (int q = 0; q < PIX; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+        const char* rowp = s_x + slot * (NPX * ESTR) + ((oyl * ST) * IW + sx * PIX * ST) * ESTR + cg * 16;
+        const float* wrow = s_w + slot * NWD + cg * 8;
+#pragma unroll 1
+        for (int r = 0; r < KS; ++r) {
+            v8 col[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) col[q] = *(const v8*)(rowp + q * ESTR);
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 w0 = *(const f32x4*)(wrow + kx * CC), w1 = *(const f32x4*)(wrow + kx * CC + 4);
+#pragma unroll
+                for (int q = 0; q < PIX; ++q) {
+                    const v8 x = col[q * ST + kx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[q][e] = __builtin_fmaf((float)x[e], w0[e], acc[q][e]);
+                        acc[q][4 + e] = __builtin_fmaf((float)x[4 + e], w1[e], acc[q][4 + e]);
+                    }
+                }
+            }
+            rowp += IW * ESTR;
+            wrow += KS * CC;
+        }
+        const f32x4 cb0 = bd0, cb1 = bd1;
+        if (more) {                                      // the next chunk's tile: consumed before this chunk's stores
+            stage(nx, slot ^ 1);
+            bd0 = nx.bd0; bd1 = nx.bd1;
+        }
+        float psum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < PIX; ++q) {
+            const int ox = ox0 + sx * PIX + q;
+            if (oy < p.Ho && ox < p.Wo) {
+                const f32x4 y0 = silu4((f32x4){acc[q][0], acc[q][1], acc[q][2], acc[q][3]} + cb0);
+                const f32x4 y1 = silu4((f32x4){acc[q][4], acc[q][5], acc[q][6], acc[q][7]} + cb1);
+                v8 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(y0[e]); h[4 + e] = Half<T>::from(y1[e]); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) psum[e] += (float)h[e];
+                *(v8*)(out + ((int64_t)oy * p.Wo + ox) * cp + c + cg * 8) = h;
+            }
+        }
+        float* red = s_red + slot * (16 * CC);
+        if (p.part) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = psum[e];
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x114, 0xf, 0xf, true));      // row_shr:4
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x118, 0xf, 0xf, true));      // row_shr:8
+                psum[e] = s;
+            }
+            if ((lane & 15) >= 12) {
+                float* dst = red + (wave * 4 + (lane >> 4)) * CC + ((lane & 15) - 12) * 8;
+                *(f32x4*)dst = (f32x4){psum[0], psum[1], psum[2], psum[3]};
+                *(f32x4*)(dst + 4) = (f32x4){psum[4], psum[5], psum[6], psum[7]};
+            }
+        }
+        __syncthreads();
+        if (p.part && tid < CC) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * CC + tid];
+            p.part[((int64_t)b * gridDim.x + blockIdx.x) * cp + c + tid] = s;
+        }
+    }
+}
+
+template <typename T, int KS, int ST>
+int dwl_launch(const DwArgs& a0, int B, int64_t* n_tiles, hipStream_t s) {
+    constexpr int TH = ST == 1 ? 8 : 4, TW = ST == 1 ? 32 : 16, PIX = ST == 1 ? 4 : 1;
+    typedef MbGeo<KS, ST, 0, TH, TW, 32> G;
+    constexpr int LDS = 2 * G::NPX * G::ESTR + 2 * G::NWD * 4 + 2 * 16 * 32 * 4;
+    DwArgs a = a0;
+    a.tiles_x = (a.Wo + TW - 1) / TW;
+    const int64_t tiles = (int64_t)a.tiles_x * ((a.Ho + TH - 1) / TH);
+    if (n_tiles) { *n_tiles = tiles; return AVEXHIP_OK; }
+    // enough workgroups for the chip (two per CU fit): split the channel chunks when the map has few tiles
+    const int nchunk = a.Cp / 32;
+    int64_t split = (1024 + tiles * B - 1) / (tiles * B);
+    split = split < 1 ? 1 : (split > nchunk ? nchunk : split);
+    a.chunks_per_wg = (int)((nchunk + split - 1) / split);
+    const int gz = (nchunk + a.chunks_per_wg - 1) / a.chunks_per_wg;
+    AVX_ENSURE_LDS((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX>), LDS);
+    hipLaunchKernelGGL((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX>), dim3((unsigned)tiles, B, gz), dim3(256), LDS, s, a);
+    AVX_LAUNCH_CHECK();
+    return AVEXHIP_OK;
+}
+template <typename T>
+int dwl_dispatch(const DwArgs& a, int B, int k, int st, int64_t* n_tiles, hipStream_t s) {
+    if (k == 3 && st == 1) return dwl_launch<T, 3, 1>(a, B, n_tiles, s);
+    if (k == 3 && st == 2) return dwl_launch<T, 3, 2>(a, B, n_tiles, s);
+    if (k == 5 && st == 1) return dwl_launch<T, 5, 1>(a, B, n_tiles, s);
+    if (k == 5 && st == 2) return dwl_launch<T, 5, 2>(a, B, n_tiles, s);
+    avexhip_set_error("dwconv_lds: kernel %d stride %d not built (3 or 5, stride 1 or 2)", k, st);
+    return AVEXHIP_ERR_INVALID;
+}
+}  // namespace
+
+namespace {
 // tile of the fused kernel for (stride, KIN): output rows x columns per workgroup and pixels along x per thread
 template <int ST, int KIN> struct MbTile;
 template <int KIN> struct MbTile<2, KIN> { static constexpr int TH = 4, TW = 16, PIX = 1; };
@@ -681,6 +892,32 @@ int dwconv_parts(const void* in, int B, int H, int W, int Cp, int k, int stride,
     *rows = dw_blocks(H, W, Cp, k, stride);
     if (dtype == AVEXHIP_BF16) return dw_launch<__bf16>(in, B, H, W, Cp, k, stride, w, bias, out, nullptr, part, s);
     return dw_launch<_Float16>(in, B, H, W, Cp, k, stride, w, bias, out, nullptr, part, s);
+}
+// the LDS form of the depthwise convolution (Cp % 32 == 0); rows of partials per clip = its tiles
+int64_t dwconv_lds_tiles(int H, int W, int k, int stride) {
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    const int pad = (k - 1) / 2;
+    a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;
+    int64_t n = 0;
+    if (dwl_dispatch<_Float16>(a, 1, k, stride, &n, nullptr) != AVEXHIP_OK) return 0;
+    return n;
+}
+int dwconv_lds_parts(const void* in, int B, int H, int W, int Cp, int k, int stride, const float* w, const float* bias, void* out, float* part,
+                     size_t part_bytes, int64_t* rows, int dtype, hipStream_t s) {
+    AVX_REQUIRE(in && w && bias && out && rows && B > 0 && B <= 65535 && H > 0 && W > 0 && Cp > 0 && Cp % 32 == 0 && Cp <= 2048, "dwconv_lds_parts: bad arguments");
+    AVX_REQUIRE((int64_t)H * W * Cp < (1ll << 31), "dwconv_lds_parts: a clip's feature map of %d x %d x %d elements does not fit 32-bit offsets", H, W, Cp);
+    const int64_t tiles = dwconv_lds_tiles(H, W, k, stride);
+    AVX_REQUIRE(tiles > 0, "dwconv_lds_parts: kernel %d stride %d not built", k, stride);
+    AVX_REQUIRE(!part || part_bytes >= sizeof(float) * (size_t)B * tiles * Cp, "dwconv_lds_parts: %zu bytes of scratch wanted, %zu given",
+                sizeof(float) * (size_t)B * tiles * Cp, part_bytes);
+    *rows = tiles;
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    const int pad = (k - 1) / 2;
+    a.in = in; a.H = H; a.W = W; a.Cp = Cp; a.w_dw = w; a.b_dw = bias; a.out = out; a.part = part;
+    a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;
+    return dtype == AVEXHIP_BF16 ? dwl_dispatch<__bf16>(a, B, k, stride, nullptr, s) : dwl_dispatch<_Float16>(a, B, k, stride, nullptr, s);
 }
 // squeeze-excitation scale [B][Cp] from `rows` rows of partial sums per clip; w2t is the second layer TRANSPOSED [Cs][C]; x (or NULL) is rescaled in place
 int se_from_parts(const float* part, int64_t rows, int B, int64_t hw, int C, int Cp, int Cs, const float* w1, const float* b1, const float* w2t,

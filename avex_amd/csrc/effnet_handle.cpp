@@ -66,6 +66,15 @@ inline int fused_kin(const Block& b) {
     return -1;
 }
 
+// the other blocks' depthwise convolution: through LDS (avx::dwconv_lds_parts) or the register-tile kernel (AVEX_AMD_DW_LDS=0)
+// Measured per 256 clips of EfficientNet-B0 (profiles/r04s_effnet_layers.txt): 32 channels at 64 x 501 414 -> 351 us, the 8 x 63 maps
+// 97 -> 85 (3 x 3), 144 -> 120 and 205 -> 182 us (5 x 5); the 4 x 32 maps and the stride-2 step onto them lose (74 -> 120 us: half of an
+// 8-row tile is outside the map and a chunk is too little work for its barrier), so those stay with the register-tile kernel.
+inline bool dw_lds(const Block& b, int H) {
+    const char* e = getenv("AVEX_AMD_DW_LDS");
+    if (e && atoi(e) == 2) return b.cp_exp % 32 == 0;      // every block (tests)
+    return !(e && atoi(e) == 0) && b.cp_exp % 32 == 0 && b.stride == 1 && H >= 8;
+}
 }  // namespace
 
 struct avexhip_effnet : avxh::HandleBase {
@@ -230,8 +239,12 @@ EffWs eff_carve(const avexhip_effnet* h, char* base, int Bc, int H, int W) {
     for (const Block& b : h->blocks) {
         if ((size_t)hh * ww * b.cp_exp * 2 > max_act) max_act = (size_t)hh * ww * b.cp_exp * 2;
         const int kin = fused_kin(b);
-        const size_t part = kin >= 0 ? sizeof(float) * (size_t)Bc * (size_t)avx::mbconv_front_tiles(hh, ww, b.k, b.stride, kin) * b.cp_exp
-                                     : avexhip_effnet_dwconv_part_bytes(Bc, hh, ww, b.cp_exp, b.k, b.stride);
+        size_t part = kin >= 0 ? sizeof(float) * (size_t)Bc * (size_t)avx::mbconv_front_tiles(hh, ww, b.k, b.stride, kin) * b.cp_exp
+                               : avexhip_effnet_dwconv_part_bytes(Bc, hh, ww, b.cp_exp, b.k, b.stride);
+        if (kin < 0 && dw_lds(b, hh)) {
+            const size_t pl = sizeof(float) * (size_t)Bc * (size_t)avx::dwconv_lds_tiles(hh, ww, b.k, b.stride) * b.cp_exp;
+            if (pl > part) part = pl;
+        }
         if (part > max_part) max_part = part;
         hh = conv_out(hh, b.k, b.stride); ww = conv_out(ww, b.k, b.stride);
         if ((size_t)hh * ww * b.cp_exp * 2 > max_act) max_act = (size_t)hh * ww * b.cp_exp * 2;
@@ -368,7 +381,8 @@ extern "C" int avexhip_effnet_forward(avexhip_effnet* h, const float* mel, int B
                 prof.end();
             } else {
                 prof.begin("dwconv", 2.0 * Bc * h2 * w2 * (double)b.cexp * b.k * b.k);
-                RC(avx::dwconv_parts(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.part, w.part_bytes, &part_rows, dt, s));
+                if (dw_lds(b, hh)) RC(avx::dwconv_lds_parts(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.part, w.part_bytes, &part_rows, dt, s));
+                else RC(avx::dwconv_parts(w.act[x], Bc, hh, ww, b.cp_exp, b.k, b.stride, b.w_dw, b.b_dw, w.act[dw], w.part, w.part_bytes, &part_rows, dt, s));
                 prof.end();
             }
             const int M2 = Bc * h2 * w2;

@@ -6,4 +6,4 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG} -- python3 $R/scripts/effnet_bench.py $B > $R/gpurun_out/${TAG}.log 2>&1
-python3 $R/scripts/parse_effnet_trace.py $(find $R/gpurun_out/${TAG} -name "*kernel_trace.csv" | head -1) 6 | tee $R/gpurun_out/${TAG}.txt
+python3 $R/scripts/parse_effnet_trace.py $(ls -t $(find $R/gpurun_out/${TAG} -name "*kernel_trace.csv") | head -1) | tee $R/gpurun_out/${TAG}.txt

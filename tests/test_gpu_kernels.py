@@ -918,8 +918,8 @@ def test_effnet_b0_matches_oracle(built_lib):
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("stages", ["b0", "b1"])
 def test_effnet_fused_block_front_matches_the_unfused_kernels(built_lib, monkeypatch, dtype, stages):
-    """avx::mbconv_front (expansion + depthwise convolution + squeeze sums in one kernel, effnet.hip) against the expansion GEMM and
-    dwconv_kernel it replaces (AVEX_AMD_MBCONV=0), on an image whose sizes are not multiples of any tile (ragged tiles on both axes, halos
+    """avx::mbconv_front (expansion + depthwise convolution + squeeze sums in one kernel, effnet.hip) and avx::dwconv_lds_parts (the
+    depthwise convolution through LDS) against the expansion GEMM and dwconv_kernel they replace (AVEX_AMD_MBCONV=0, AVEX_AMD_DW_LDS=0), on an image whose sizes are not multiples of any tile (ragged tiles on both axes, halos
     that leave the image on all four sides).  Both forms round at the same places and add their taps in the same order; what differs is
     the order in which the squeeze partial sums are added (one row per workgroup, different workgroups), i.e. fp32 rounding of the
     squeeze-excitation scale, which flips an occasional operand rounding downstream."""
@@ -930,14 +930,19 @@ def test_effnet_fused_block_front_matches_the_unfused_kernels(built_lib, monkeyp
     mel = _dev(np.abs(synth.normal("emelf", (3, 70, 133), 0.5)).astype(np.float32))
     enc = EfficientNetB0Encoder(sd, operand_dtype=dtype, **kw)
     names = enc.tap_names()
+    monkeypatch.setenv("AVEX_AMD_DW_LDS", "2")                    # the LDS depthwise kernel for every block it can take, small maps and stride 2 too
     fused = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
     monkeypatch.setenv("AVEX_AMD_MBCONV", "0")
+    monkeypatch.setenv("AVEX_AMD_DW_LDS", "0")                    # ... and the register-tile depthwise kernel instead of the LDS one for the other blocks
     plain = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
     monkeypatch.delenv("AVEX_AMD_MBCONV")
+    monkeypatch.delenv("AVEX_AMD_DW_LDS")
     tol = 2e-4 if dtype == "f16" else 1.5e-3
     assert torch.equal(fused["hooks"][names[0]], plain["hooks"][names[0]])          # the stem is not touched
     for n in names[1:]:
         assert rel_l2(fused["hooks"][n].cpu().numpy(), plain["hooks"][n].cpu().numpy()) < tol, n
     assert rel_l2(fused["pooled"].cpu().numpy(), plain["pooled"].cpu().numpy()) < tol
+    default = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)      # the shipped choice per block
+    assert rel_l2(default["pooled"].cpu().numpy(), plain["pooled"].cpu().numpy()) < tol
     again = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
-    assert torch.equal(again["features"], fused["features"]) and torch.equal(again["pooled"], fused["pooled"])
+    assert torch.equal(again["features"], default["features"]) and torch.equal(again["pooled"], default["pooled"])
