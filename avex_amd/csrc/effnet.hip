@@ -265,18 +265,18 @@ __global__ __launch_bounds__(1024) void se_pool_fc_kernel(const float* __restric
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // both layers request their weights EIGHT AT A TIME before the first multiply-add of the batch: with run-time trip counts hipcc waits
+    // both layers request their weights SIXTEEN AT A TIME before the first multiply-add of the batch: with run-time trip counts hipcc waits
     // for every load where it is used, and the 18 + 48 dependent round trips to L2 were the whole 32 us of a launch at C = 1152, Cs = 48.
     // The order of the additions is unchanged.
     for (int j = wave; j < Cs; j += 16) {
         float s = 0.f;
         const float* wr = w1 + (int64_t)j * C;
-        for (int c0 = lane; c0 < C; c0 += 512) {
-            float w[8];
+        for (int c0 = lane; c0 < C; c0 += 1024) {
+            float w[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = c0 + 64 * u < C ? wr[c0 + 64 * u] : 0.f;
+            for (int u = 0; u < 16; ++u) w[u] = c0 + 64 * u < C ? wr[c0 + 64 * u] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (c0 + 64 * u < C) s = __builtin_fmaf(w[u], mean[c0 + 64 * u], s);
         }
         s = wave_sum(s);
@@ -287,12 +287,12 @@ __global__ __launch_bounds__(1024) void se_pool_fc_kernel(const float* __restric
         float v = 0.f;
         if (c < C) {
             float s = b2[c];
-            for (int j0 = 0; j0 < Cs; j0 += 8) {
-                float w[8];
+            for (int j0 = 0; j0 < Cs; j0 += 16) {
+                float w[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = j0 + u < Cs ? w2t[(int64_t)(j0 + u) * C + c] : 0.f;
+                for (int u = 0; u < 16; ++u) w[u] = j0 + u < Cs ? w2t[(int64_t)(j0 + u) * C + c] : 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 16; ++u)
                     if (j0 + u < Cs) s = __builtin_fmaf(w[u], hid[j0 + u], s);
             }
             v = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * s));
@@ -683,6 +683,8 @@ namespace {
 // before that chunk's output stores, so the wait for the loads never has to drain stores (see mbconv_kernel) -- and one barrier per
 // chunk.  Small feature maps (8 x 63, 4 x 32) have one or two tiles per clip: gridDim.z splits the chunks over several workgroups.
 // Taps in (ky, kx) order, SiLU, rounding and the squeeze partials (one row per TILE) as in dwconv_kernel: the same output bits.
+// (Computing the first block's input tile in here -- the stem convolution on the mel patch, so that the stem's output never reaches HBM --
+// was built and measured: bit-identical, 693 us against 225 + 326 us for the two kernels; the halo's stem work outweighs the bytes.  Not kept.)
 // ---------------------------------------------------------------------------------------------
 struct DwArgs {
     const void* in; int H, W, Cp;
