@@ -261,7 +261,7 @@ def other_configs(steps: int = 5):
         small = torch.from_numpy(synth.noise_clips(2, n, seed=int(gold["effnet.seed"][0]))).cuda()
         p = enc.forward(plan(small), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
         out["c5_effnet"] = {"workload": "EfficientNet-B0 (torchvision features stack, BatchNorm folded), batch 1024 x 10 s @ 16 kHz, wav resident in HBM -> "
-                                        "mel 128 x 1001 -> pooled 1280-d; conv / depthwise HIP kernels, the 1x1 convolutions on the MFMA GEMMs",
+                                        "mel 128 x 1001 -> pooled 1280-d; expansion + depthwise + squeeze sums of the narrow-input blocks in one HIP kernel, depthwise through LDS, the other 1x1 convolutions on the MFMA GEMMs",
                             "ms_per_step": round(1e3 * dt, 3), "clips_per_s": round(B / dt, 1), "dtype": "f16",
                             "roofline": {"bound": "hbm", "achieved": round(B * nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(B * nbytes / dt / 1e9 / 8000.0, 4), "algorithmic_mb_per_clip": round(nbytes / 1e6, 2),

@@ -213,3 +213,30 @@ def test_model_class_exposes_the_alarm(built_lib, clips):
     m.extract_embeddings(torch.from_numpy(clips).cuda(), aggregation="mean")
     assert m.overflow_events() > 0
     m.deregister_all_hooks()
+
+
+def test_effnet_fused_block_front_keeps_the_alarm(built_lib, monkeypatch):
+    """The fused expansion + depthwise kernel (effnet.hip mbconv_kernel) rounds the expanded values to f16 inside the kernel: it has to count
+    what leaves the range exactly like the expansion GEMM it replaces.  Normal weights: no event in either form; the first expansion's
+    weights scaled by 1e6: events in both forms (the count is per (lane, launch) pair and the two forms tile differently, so only
+    'some' is comparable), saturated -- finite -- outputs in both."""
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    sd = synth.effnet_b0_state_dict()
+    mel = _dev(np.abs(synth.normal("emelo", (2, 64, 101), 0.5)).astype(np.float32))
+    enc = EfficientNetB0Encoder(sd)
+    enc.forward(mel, want_features=False, want_pooled=True)
+    assert enc.overflow_events() == 0
+    hot = dict(sd)
+    key = "model.features.2.0.block.0.0.weight"                  # the first expansion (16 -> 96), a block the fused kernel takes
+    assert key in hot
+    hot[key] = (hot[key] * np.float32(1e6)).astype(np.float32)
+    counts = {}
+    for form in ("fused", "unfused"):
+        if form == "unfused":
+            monkeypatch.setenv("AVEX_AMD_MBCONV", "0")
+        e2 = EfficientNetB0Encoder(hot)
+        out = e2.forward(mel, want_features=False, want_pooled=True)["pooled"]
+        counts[form] = e2.overflow_events()
+        assert torch.isfinite(out).all(), form
+    monkeypatch.delenv("AVEX_AMD_MBCONV")
+    assert counts["fused"] > 0 and counts["unfused"] > 0, counts
