@@ -30,10 +30,11 @@ namespace {
 
 inline int pad128(int c) { return ((c + 127) / 128) * 128; }
 inline bool skinny_enabled() { const char* e = getenv("AVEX_AMD_GEMM_SKINNY"); return !(e && atoi(e) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"); }
-// channels of an activation tensor in memory: 32 (16 and 24 channels) or 64 (40) for the narrow block outputs of the first stages (at the
-// largest spatial sizes: padded to 128 they were 3 - 8x their size; only the skinny streaming kernel takes 32), else a multiple of 128.  GEMM outputs narrower than the 128-column tile
+// channels of an activation tensor in memory: 64 for the narrow block outputs of the first stages (at the largest spatial sizes: padded
+// to 128 they were 3 - 8x their size), else a multiple of 128; block outputs of <= 32 channels are 32 wide where every consumer takes
+// K = 32 (effnet_build: narrow_ok).  GEMM outputs narrower than the 128-column tile
 // are computed at pad128 and stored through GemmArgs::n_store.
-inline int padc(int c) { return c <= 32 && skinny_enabled() ? 32 : (c <= 64 ? 64 : pad128(c)); }
+inline int padc(int c) { return c <= 64 ? 64 : pad128(c); }
 // ... and of an EXPANDED tensor: 96 and 144 (-> 160) channels stay that narrow when the skinny streaming kernel is there to take K, N = 96 / 160
 // (padded to 128 / 256 the 144-channel tensors were 44 % padding)
 inline int padx(int c) {
@@ -140,6 +141,23 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
     tb.strip1 = "model."; tb.strip2 = nullptr;
     int rc;
 #define RC(x) do { rc = (x); if (rc != AVEXHIP_OK) return rc; } while (0)
+    // May the tensor that block `idx` reads (the stem's output for idx = 0, else block idx - 1's) be 32 channels wide in memory?  Every
+    // consumer must take K = 32: the fused block front and the skinny GEMM do, the 128-tile kernels (K % 64) do not.  The head reads through
+    // the 128-tile kernel; a block without an expansion feeds its 32 channels to its projection, which is skinny only up to 256 columns.
+    struct Bl { bool ex; int cexp, cout; };
+    std::vector<Bl> plan;
+    for (int si = 0; si < c.n_stages; ++si)
+        for (int j = 0; j < c.stage[si][5]; ++j) {
+            const int ci = j == 0 ? c.stage[si][3] : c.stage[si][4];
+            plan.push_back({c.stage[si][0] != 1, ci * c.stage[si][0], c.stage[si][4]});
+        }
+    auto narrow_ok = [&](size_t idx, int ch) -> bool {
+        if (ch > 32 || !skinny_enabled() || idx >= plan.size()) return false;
+        const Bl& n = plan[idx];
+        if (n.ex) { const int ce = padx(n.cexp); return skinny_dim(ce) && ce * 32 <= 32768; }
+        return pad128(n.cout) <= 256;
+    };
+    h->cp0 = narrow_ok(0, h->c0) ? 32 : ((h->c0 + 63) / 64) * 64;
     {   // stem: Conv2d(3, c0, 3, s2) on three copies of one image = a 1-channel 3x3 convolution with channel-summed weights; [9, cp0]
         std::vector<float> w, sc, sh;
         RC(avxh::host_f32(h, tb, "features.0.0.weight", (int64_t)h->c0 * 3 * 9, w));
@@ -157,6 +175,7 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
     }
     int cp = h->cp0;
     h->n_taps = 1;
+    size_t bi = 0;                                         // index of the block being built in `plan`
     for (int si = 0; si < c.n_stages; ++si) {
         const int er = c.stage[si][0], k = c.stage[si][1], s = c.stage[si][2], cin = c.stage[si][3], cout = c.stage[si][4], reps = c.stage[si][5];
         for (int j = 0; j < reps; ++j) {
@@ -200,8 +219,9 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
             std::vector<float> scp, shp;
             RC(pointwise(h, tb, p + std::to_string(d + 2) + ".0", p + std::to_string(d + 2) + ".1", b.cout, b.cexp, cp, &b.w_proj, &b.b_proj, &scp, &shp));
             RC(upload_f32(h, scp, &b.proj_scale)); RC(upload_f32(h, shp, &b.proj_shift));
-            cp = padc(b.cout);
+            cp = narrow_ok(bi + 1, b.cout) ? 32 : padc(b.cout);
             b.cp_out = cp;
+            ++bi;
             if (b.tap) ++h->n_taps;
             h->blocks.push_back(b);
         }
@@ -292,7 +312,7 @@ extern "C" avexhip_effnet* avexhip_effnet_create(const avexhip_effnet_config* cf
     h->cfg = c;
     if (!(h->cfg.bn_eps > 0.f)) h->cfg.bn_eps = 1e-5f;
     h->dtype = c.operand_dtype;
-    h->c0 = c.stem_channels; h->cp0 = skinny_enabled() ? ((c.stem_channels + 31) / 32) * 32 : ((c.stem_channels + 63) / 64) * 64; h->head = c.head_channels;      // cp0 = 32 for B0 / B1: the stem's output and the first depthwise run at the real width
+    h->c0 = c.stem_channels; h->cp0 = ((c.stem_channels + 63) / 64) * 64; h->head = c.head_channels;      // (effnet_build narrows cp0 to 32 for B0 / B1: the stem's output and the first depthwise run at the real width)
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
     if (h->init_alarm() != AVEXHIP_OK || effnet_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
     return h;

@@ -946,3 +946,12 @@ def test_effnet_fused_block_front_matches_the_unfused_kernels(built_lib, monkeyp
     assert rel_l2(default["pooled"].cpu().numpy(), plain["pooled"].cpu().numpy()) < tol
     again = enc.forward(mel, hook_layers=names, want_features=True, want_pooled=True)
     assert torch.equal(again["features"], default["features"]) and torch.equal(again["pooled"], default["pooled"])
+
+
+def test_effnet_random_layouts_fuzz(built_lib):
+    """tests/tools/fuzz_effnet.py: ten random stage layouts / image sizes through the handle -- shipped kernels vs the unfused forms vs
+    the oracle, and repeatability."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "fuzz_effnet.py"), "10", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
