@@ -25,12 +25,20 @@ template <> struct Half<_Float16> {
         // saturate instead of producing inf: activations are O(1..1e3), this only guards outliers
         return (_Float16)__builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
     }
+    static __device__ __forceinline__ _Float16 from_hw(float x) { return (_Float16)x; }      // saturates through MODE.FP16_OVFL (below)
 };
 template <> struct Half<__bf16> {
     typedef bf16x8 v8;
     typedef bf16x4 v4;
     static __device__ __forceinline__ __bf16 from(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ __bf16 from_hw(float x) { return (__bf16)x; }
 };
+// The same saturation in HARDWARE: with MODE.FP16_OVFL set, v_cvt_f16_f32 / v_cvt_pk_f16_f32 round a finite value beyond the f16 range
+// to +-65504 instead of +-inf (measured on gfx950: scripts/micro/fp16_ovfl.hip, profiles/r04u_fp16_ovfl.txt; inf and NaN pass through,
+// where from() turns them into +-65504).  A kernel that calls Half<T>::from_hw must execute AVX_F16_SATURATE_ON() first: the bit is
+// per-wave state, clear at wave start.  The "memory" clobber keeps every load -- and with it every conversion of loaded or computed
+// values -- behind the mode write.  One v_med3_f32 less per stored element: a quarter of the vector work of a bias-only GEMM epilogue.
+#define AVX_F16_SATURATE_ON() asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory")
 
 // Range alarm of the f16 outputs (Half<_Float16>::from saturates silently): a kernel keeps the running max of |value| over
 // everything a lane rounds to f16 (v_max3_f32 with |.| modifiers: half a VALU slot per element) and commits once at its end.

@@ -23,6 +23,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, int H, int W, int Ho, int Wo,
                                                         const float* __restrict__ w /*[9][Cp]*/, const float* __restrict__ bias,
                                                         int Cp, T* __restrict__ out, float* __restrict__ raw /*[B,Ho,Wo,Cp] or null*/) {
+    AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v8 v8;
     constexpr int SP = STEM_PIX;
     const int cg = Cp >> 3;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         for (int e = 0; e < 8; ++e) {
             const float y = acc[p][e] + (e < 4 ? b0[e] : b1[e - 4]);
             if (raw) raw[o + e] = y;
-            h[e] = Half<T>::from(silu1(y));
+            h[e] = Half<T>::from_hw(silu1(y));
         }
         *(v8*)(out + o) = h;
     }
@@ -101,6 +102,7 @@ __attribute__((amdgpu_waves_per_eu(DW_WAVES, DW_WAVES)))
 void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int Cp,
                                                      const float* __restrict__ w /*[KS*KS][Cp]*/, const float* __restrict__ bias,
                                                      T* __restrict__ out, float* __restrict__ part /*[B][gridDim.x][Cp]*/) {
+    AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v8 v8;
     constexpr int PAD = (KS - 1) / 2, PIX = DW_PIX, PY = DW_PY;
     constexpr int NCOL = (PIX - 1) * ST + KS, NROW = (PY - 1) * ST + KS;
@@ -174,7 +176,7 @@ void dwconv_kernel(const T* __restrict__ in, int H, int W, int Ho, int Wo, int C
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float y = silu1(acc[py][p][e] + (e < 4 ? b0[e] : b1[e - 4]));
-                    h[e] = Half<T>::from(y);
+                    h[e] = Half<T>::from_hw(y);
                     psum[e] += (float)h[e];                    // the pool sees what the next layer will read
                 }
                 *(v8*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * Cp + c8) = h;
@@ -337,24 +339,6 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, 
 // at the top of the PREVIOUS chunk and consumed before that chunk's output stores are issued -- a wait placed after the stores would have
 // to be vmcnt(0) (the stores are conditional, the compiler cannot count them) and would drain them: 1 - 2 us per chunk of ~1 us of work.
 // ---------------------------------------------------------------------------------------------
-// Rounding to the operand type in the depthwise epilogues of the LDS kernels.  Half<_Float16>::from clamps to +-65504 (a VALU operation
-// per element) although no activation ever gets there; here the clamp runs only when a value of the wave's pixel left the range (same
-// results in both cases).  Measured in one process: the LDS depthwise kernel 84 -> 75, 112 -> 100, 166 -> 144 us per launch; in the
-// expansion stage of the fused kernel the same test costs 1.5 % (it stays unconditional there).
-template <typename T> static __device__ __forceinline__ bool mb_hot(float mx) {
-    if constexpr (__is_same(T, _Float16)) return __builtin_expect(__ballot(mx > 65504.0f) != 0ull, 0);
-    return false;
-}
-template <typename T, int N, typename V> static __device__ __forceinline__ void mb_round(V& h, int base, const float* v, bool hot) {
-    if (hot) {
-#pragma unroll
-        for (int e = 0; e < N; ++e) h[base + e] = Half<T>::from(v[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < N; ++e) h[base + e] = (T)v[e];
-    }
-}
-
 typedef int a_i32x2m __attribute__((ext_vector_type(2)));
 struct MbArgs {
     const void* in; int H, W, ld_in;
@@ -378,6 +362,7 @@ struct MbGeo {
 
 template <typename T, int KS, int ST, int KIN, int TH, int TW, int PIX, int CC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, ST, KIN, TH, TW, CC>::WPE, MbGeo<KS, ST, KIN, TH, TW, CC>::WPE))) void mbconv_kernel(const MbArgs p) {
+    AVX_F16_SATURATE_ON();                               // f16 outputs saturate through MODE.FP16_OVFL (common.h): no clamp instructions
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     typedef MbGeo<KS, ST, KIN, TH, TW, CC> G;
@@ -474,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, S
                 ovf_see4<T>(ovf_mx, v);
                 v4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = Half<T>::from(v[e]);      // (the conditional clamp of the depthwise epilogue costs more than it saves here: the branch splits the two interleaved groups)
+                for (int e = 0; e < 4; ++e) h[e] = Half<T>::from_hw(v[e]);
                 a_i32x2m hb = __builtin_bit_cast(a_i32x2m, h);
                 hb[0] = inside ? hb[0] : 0; hb[1] = inside ? hb[1] : 0;
                 *(a_i32x2m*)(s_exp + pix * ESTR + (16 * mt + 4 * lq) * 2) = hb;
@@ -535,10 +520,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, S
                     const f32x4 y0 = silu4((f32x4){acc[q][0], acc[q][1], acc[q][2], acc[q][3]} + bd0);
                     const f32x4 y1 = silu4((f32x4){acc[q][4], acc[q][5], acc[q][6], acc[q][7]} + bd1);
                     v8 h;
-                    float dmx = 0.f;
-                    ovf_see4<T>(dmx, y0); ovf_see4<T>(dmx, y1);
-                    const float yy[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-                    mb_round<T, 8>(h, 0, yy, mb_hot<T>(dmx));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from_hw(y0[e]); h[4 + e] = Half<T>::from_hw(y1[e]); }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) psum[e] += (float)h[e];
                     *(v8*)(out + ((int64_t)oy * p.Wo + ox) * cp + c + cg * 8) = h;
@@ -696,6 +679,7 @@ struct DwArgs {
 
 template <typename T, int KS, int ST, int TH, int TW, int PIX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwconv_lds_kernel(const DwArgs p) {
+    AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v8 v8;
     typedef MbGeo<KS, ST, 0, TH, TW, 32> G;
     constexpr int CC = 32, PAD = (KS - 1) / 2, IW = G::IW, NPIX = G::NPIX, NPX = G::NPX, ESTR = G::ESTR, NWD = G::NWD;
@@ -810,10 +794,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const f32x4 y0 = silu4((f32x4){acc[q][0], acc[q][1], acc[q][2], acc[q][3]} + cb0);
                 const f32x4 y1 = silu4((f32x4){acc[q][4], acc[q][5], acc[q][6], acc[q][7]} + cb1);
                 v8 h;
-                float dmx = 0.f;
-                ovf_see4<T>(dmx, y0); ovf_see4<T>(dmx, y1);
-                const float yy[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-                mb_round<T, 8>(h, 0, yy, mb_hot<T>(dmx));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from_hw(y0[e]); h[4 + e] = Half<T>::from_hw(y1[e]); }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) psum[e] += (float)h[e];
                 *(v8*)(out + ((int64_t)oy * p.Wo + ox) * cp + c + cg * 8) = h;

@@ -19,6 +19,15 @@
 
 #include "common.h"
 
+#ifndef GEMM_HW_SAT
+#define GEMM_HW_SAT 1      // 1: every kernel of this file sets MODE.FP16_OVFL at its top and its f16 outputs saturate through MODE.FP16_OVFL (common.h) instead of a v_med3_f32 per element
+#endif
+#if GEMM_HW_SAT
+#define HFROM(x) Half<T>::from_hw(x)
+#else
+#define HFROM(x) HFROM(x)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -29,6 +38,7 @@ typedef __attribute__((address_space(3))) void lptr_t;
 
 template <typename T, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
+    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -133,8 +143,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
                 const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);              \
                 v8 x = *(v8*)&ra##i;                                                           \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                \
-                    x[e] = Half<T>::from((float)x[e] * s0[e]);                                 \
-                    x[4 + e] = Half<T>::from((float)x[4 + e] * s1[e]);                         \
+                    x[e] = HFROM((float)x[e] * s0[e]);                                 \
+                    x[4 + e] = HFROM((float)x[4 + e] * s1[e]);                         \
                 }                                                                              \
                 ra##i = *(uint4*)&x;                                                           \
             }                                                                                  \
@@ -196,8 +206,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
             if (p.out_half) {
                 ovf_see4<T>(ovf_mx, v);
                 v4 h;
-                h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]);
-                h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+                h[0] = HFROM(v[0]); h[1] = HFROM(v[1]);
+                h[2] = HFROM(v[2]); h[3] = HFROM(v[3]);
                 *(v4*)((T*)p.out_half + (int64_t)m * p.ldh + n) = h;
             }
         }
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 // split-K partials [S][M][N] -> the epilogue of gemm_nt_kernel on their sum (added in split order: reproducible).  One thread = 4 columns.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, int S) {
+    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v4 v4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int nq = p.N >> 2;
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, i
             if (p.out_half) {
                 ovf_see4<T>(ovf_mx, v);
                 v4 h;
-                h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+                h[0] = HFROM(v[0]); h[1] = HFROM(v[1]); h[2] = HFROM(v[2]); h[3] = HFROM(v[3]);
                 *(v4*)((T*)p.out_half + (int64_t)m * p.ldh + n) = h;
             }
         }
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, i
 // Same per-row arithmetic as layernorm_half_kernel (two-pass statistics in registers, (v - mean) * rstd * w + b).
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_ln_epilogue_kernel(avx::GemmArgs p, int S) {
+    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v4 v4;
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256) void splitk_ln_epilogue_kernel(avx::GemmArgs p
         if (p.out_half || p.post_ln_round) {
             ovf_see4<T>(ovf_mx, a);
             v4 h;
-            h[0] = Half<T>::from(a[0]); h[1] = Half<T>::from(a[1]); h[2] = Half<T>::from(a[2]); h[3] = Half<T>::from(a[3]);
+            h[0] = HFROM(a[0]); h[1] = HFROM(a[1]); h[2] = HFROM(a[2]); h[3] = HFROM(a[3]);
             if (p.out_half) *(v4*)((T*)p.out_half + (int64_t)m * p.ldh + n) = h;
             if (p.post_ln_round) a = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
         }
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256) void splitk_ln_epilogue_kernel(avx::GemmArgs p
         if (p.post_ln_out_f32) *(f32x4*)(p.post_ln_out_f32 + (int64_t)m * p.post_ln_ldo + n) = y;
         if (p.post_ln_out_half) {
             v4 h;
-            h[0] = Half<T>::from(y[0]); h[1] = Half<T>::from(y[1]); h[2] = Half<T>::from(y[2]); h[3] = Half<T>::from(y[3]);
+            h[0] = HFROM(y[0]); h[1] = HFROM(y[1]); h[2] = HFROM(y[2]); h[3] = HFROM(y[3]);
             *(v4*)((T*)p.post_ln_out_half + (int64_t)m * p.post_ln_ldh + n) = h;
         }
     }
@@ -525,6 +537,7 @@ static_assert(L5_ROWS + 4096 <= 32768, "EPI 1 scratch above the stages");
 
 template <typename T, int EPI, int LN, int ACT>
 __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
+    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         ovf_see<T>(ovf_mx, v[q][0], v[q][1]);
-                        typename Half<T>::v4 h2 = {Half<T>::from(v[q][0]), Half<T>::from(v[q][1]), Half<T>::from(0.f), Half<T>::from(0.f)};
+                        typename Half<T>::v4 h2 = {HFROM(v[q][0]), HFROM(v[q][1]), HFROM(0.f), HFROM(0.f)};
                         hw[q] = __builtin_bit_cast(uint2, h2).x;
                     }
 #pragma unroll
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         ovf_see<T>(ovf_mx, v[2 * i][0], v[2 * i][1]);
                         ovf_see<T>(ovf_mx, v[2 * i + 1][0], v[2 * i + 1][1]);
                         v4 h;
-                        h[0] = Half<T>::from(v[2 * i][0]); h[1] = Half<T>::from(v[2 * i][1]); h[2] = Half<T>::from(v[2 * i + 1][0]); h[3] = Half<T>::from(v[2 * i + 1][1]);
+                        h[0] = HFROM(v[2 * i][0]); h[1] = HFROM(v[2 * i][1]); h[2] = HFROM(v[2 * i + 1][0]); h[3] = HFROM(v[2 * i + 1][1]);
                         *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;
                     }
 #else
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         else if constexpr (ACT == 2) v = silu4(v);
                         ovf_see4<T>(ovf_mx, v);
                         v4 h;
-                        h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]); h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
+                        h[0] = HFROM(v[0]); h[1] = HFROM(v[1]); h[2] = HFROM(v[2]); h[3] = HFROM(v[3]);
                         *(v4*)(slab + lc * HP_LD + 16 * i + 4 * lg) = h;
                     }
 #endif
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     ovf_see4<T>(ovf_mx, o0); ovf_see4<T>(ovf_mx, o1);
                     v8 h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(o0[e]); h[4 + e] = Half<T>::from(o1[e]); }
+                    for (int e = 0; e < 4; ++e) { h[e] = HFROM(o0[e]); h[4 + e] = HFROM(o1[e]); }
                     buf_st16<GEMM_NT ? 2 : 0>(h, obuf, ovoff + (16 * j + 8 * ps) * ldh * 2 + 128 * ih);
                     if (STATS) {
                         // partial LayerNorm statistics of the row segment (64 columns = the 8 lanes that share er), from the fp32 values
@@ -1088,7 +1101,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                                 ovf_see4<T>(ovf_mx, v0); ovf_see4<T>(ovf_mx, v1);
                                 v8 h;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { h[e] = Half<T>::from(v0[e]); h[4 + e] = Half<T>::from(v1[e]); }
+                                for (int e = 0; e < 4; ++e) { h[e] = HFROM(v0[e]); h[4 + e] = HFROM(v1[e]); }
                                 st_out((v8*)((T*)p.out_half + (int64_t)m * p.ldh + nb), h, p.nt);
                             }
                             if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
@@ -1161,6 +1174,7 @@ static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NT, int KS, bool SCALE, bool RAW>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p) {
+    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -1229,8 +1243,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                     const f32x4 s0 = *(const f32x4*)(sp + ks * 32), s1 = *(const f32x4*)(sp + ks * 32 + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        af[ks][rt][e] = Half<T>::from((float)af[ks][rt][e] * s0[e]);
-                        af[ks][rt][4 + e] = Half<T>::from((float)af[ks][rt][4 + e] * s1[e]);
+                        af[ks][rt][e] = HFROM((float)af[ks][rt][e] * s0[e]);
+                        af[ks][rt][4 + e] = HFROM((float)af[ks][rt][4 + e] * s1[e]);
                     }
                 }
             }
@@ -1278,7 +1292,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                         if (p.gelu) v = act4_any(v, p.gelu);
                         ovf_see4<T>(ovf_mx, v);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = Half<T>::from(v[e]);
+                        for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = HFROM(v[e]);
                     }
                     *(v8*)((T*)p.out_half + m * p.ldh + n) = h[0];
                     if (G == 4) *(v8*)((T*)p.out_half + m * p.ldh + n + 8) = h[1];

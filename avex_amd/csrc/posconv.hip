@@ -46,6 +46,7 @@ template <typename T>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, const T* __restrict__ wp,
                     const float* __restrict__ bias, int Tn, int E, int G, int nseg, float* __restrict__ out, T* __restrict__ out_h) {
+    AVX_F16_SATURATE_ON();                                            // from_hw below (common.h)
     extern __shared__ __attribute__((aligned(16))) char slab[];
     typedef typename Half<T>::v8 v8;
     char* wring = slab + SLAB_BYTES;
@@ -140,8 +141,8 @@ void posconv_kernel(const T* __restrict__ xh, const float* __restrict__ xf, cons
             if (out) *(f32x4*)(out + rowoff + n) = r;
             if (out_h) {
                 typename Half<T>::v4 h;
-                h[0] = Half<T>::from(r[0]); h[1] = Half<T>::from(r[1]);
-                h[2] = Half<T>::from(r[2]); h[3] = Half<T>::from(r[3]);
+                h[0] = Half<T>::from_hw(r[0]); h[1] = Half<T>::from_hw(r[1]);
+                h[2] = Half<T>::from_hw(r[2]); h[3] = Half<T>::from_hw(r[3]);
                 *(typename Half<T>::v4*)(out_h + rowoff + n) = h;
             }
         }
