@@ -19,6 +19,9 @@
 
 #include "common.h"
 
+#ifndef GEMM_GELU_H
+#define GEMM_GELU_H 1     // 1: the streaming kernel's bias + GELU epilogue (half output) evaluates the degree-4 fit; 0: the degree-6 one (A/B)
+#endif
 #ifndef GEMM_HW_SAT
 #define GEMM_HW_SAT 1      // 1: every kernel of this file sets MODE.FP16_OVFL at its top and its f16 outputs saturate through MODE.FP16_OVFL (common.h) instead of a v_med3_f32 per element
 #endif
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         } else {
                             v = acc[4 * ih + i][j] + bv[i];
                         }
-                        if constexpr (ACT == 1) v = gelu_erf4(v);
+                        if constexpr (ACT == 1) v = GEMM_GELU_H ? gelu_erf4_h(v) : gelu_erf4(v);      // half output: the degree-4 fit (common.h)
                         else if constexpr (ACT == 2) v = silu4(v);
                         ovf_see4<T>(ovf_mx, v);
                         v4 h;
