@@ -19,6 +19,9 @@
 
 #include "common.h"
 
+#ifndef GEMM_LNA_PK
+#define GEMM_LNA_PK 1     // 1: EPI 1's folded LayerNorm as packed FMAs on column pairs (0: four scalar fmaf, A/B)
+#endif
 #ifndef GEMM_GELU_H
 #define GEMM_GELU_H 1     // 1: the streaming kernel's bias + GELU epilogue (half output) evaluates the degree-4 fit; 0: the degree-6 one (A/B)
 #endif
@@ -475,6 +478,33 @@ static __device__ __forceinline__ float seg8_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
     return v;
 }
+// The same reduction for TWO values at once with the DPP operand INSIDE the add (v_add_f32_dpp): six adds and three one-cycle nops.  From
+// the builtin hipcc makes, per step, two v_mov_b32 0 (the `old` operand), two v_mov_b32_dpp and one packed add -- fifteen instructions per
+// row segment, 13 % of the residual epilogue's vector instructions.  Written as one asm block because the hazard recogniser does not look
+// inside inline assembly: a DPP read needs two wait states after the VALU write of its source (the partner chain's add is one, s_nop 0 the
+// other; s_nop 1 covers whatever wrote the inputs).  a + dpp(a) either way: the same bits.
+#ifndef GEMM_DPP_ADD
+#define GEMM_DPP_ADD 1
+#endif
+static __device__ __forceinline__ void seg8_sum2(float& s1, float& s2) {
+#if GEMM_DPP_ADD
+    float a, b;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0"
+        : "=&v"(a), "=&v"(b) : "v"(s1), "v"(s2));
+    s1 = a; s2 = b;
+#else
+    s1 = seg8_sum(s1); s2 = seg8_sum(s2);
+#endif
+}
 
 // Sum and sum of squares of a lane's 8 values x[0..3], y[0..3] (a row segment's share of the LayerNorm statistics), as PACKED operations down
 // the register pairs -- (x.01 + x.23) + (y.01 + y.23), the two halves added last -- 9 instructions.  (Written as a chain of scalar adds the
@@ -879,10 +909,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                     for (int i = 0; i < 4; ++i) {
                         f32x4 v;
                         if (LNA) {
-                            // LayerNorm of the A rows folded in: rstd * acc + ((-mu rstd) * s[n] + bias'[n])
+                            // LayerNorm of the A rows folded in: rstd * acc + ((-mu rstd) * s[n] + bias'[n]).  Written on column PAIRS: as four
+                            // scalar fmaf the compiler kept them scalar (256 v_fma_f32 per 128 outputs of a lane: half of QKV's epilogue arithmetic);
+                            // v_pk_fma_f32 with the row's two scalars broadcast does a pair per slot.  Same operations: same bits.
+#if GEMM_LNA_PK
+                            const f32x2 rx = {rst[j].x, rst[j].x}, ry = {rst[j].y, rst[j].y};
+                            const f32x4 a4 = acc[4 * ih + i][j];
+                            const f32x2 lo = __builtin_elementwise_fma(rx, (f32x2){a4[0], a4[1]}, __builtin_elementwise_fma(ry, (f32x2){sv[i][0], sv[i][1]}, (f32x2){bv[i][0], bv[i][1]}));
+                            const f32x2 hi = __builtin_elementwise_fma(rx, (f32x2){a4[2], a4[3]}, __builtin_elementwise_fma(ry, (f32x2){sv[i][2], sv[i][3]}, (f32x2){bv[i][2], bv[i][3]}));
+                            v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+#else
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 v[e] = __builtin_fmaf(rst[j].x, acc[4 * ih + i][j][e], __builtin_fmaf(rst[j].y, sv[i][e], bv[i][e]));
+#endif
                         } else {
                             v = acc[4 * ih + i][j] + bv[i];
                         }
@@ -1002,7 +1042,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         // (the rounding of the stored row moves the sums by ~2^-11 / sqrt(64) relative: far below LayerNorm's own error)
                         float s1, s2;
                         stats8(o0, o1, s1, s2);
-                        s1 = seg8_sum(s1); s2 = seg8_sum(s2);
+                        seg8_sum2(s1, s2);
                         __builtin_amdgcn_raw_buffer_store_b64((i32x2_buf){__builtin_bit_cast(int, s1), __builtin_bit_cast(int, s2)}, sbuf,
                                                               svoff + (16 * j + 8 * ps) * nseg_out * 8 + 8 * ih, 0, 0);
                     }
@@ -1110,7 +1150,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                             if (p.stats_out) {     // the 8 lanes of a row segment share m: all of them are here
                                 float s1, s2;
                                 stats8(v0, v1, s1, s2);      // the function EPI 2 uses: same bits
-                                s1 = seg8_sum(s1); s2 = seg8_sum(s2);
+                                seg8_sum2(s1, s2);
                                 if (ec == 0)
                                     *(float2*)(p.stats_out + ((int64_t)m * nseg_out + ((en0 + wm * 128 + 64 * ih) >> 6)) * 2) = make_float2(s1, s2);
                             }
@@ -1406,10 +1446,10 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         const char* fgen = getenv("AVEX_AMD_GEMM_GENERIC");
         const bool force_generic = fgen && atoi(fgen) != 0;     // tests: cross-check of the fast epilogues
         const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.pool_part && !a.resid && !a.row_zero && !force_generic;
-        const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out && a.gelu <= 2;      // the fast epilogue knows GELU and SiLU only
+        const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out && (a.gelu <= 2 || a.gelu == 6);      // the fast epilogue knows GELU and SiLU only
         const bool fast_resid = plain_out && (a.resid_half || a.lnr_y) && !a.gelu && !a.ln_rows;
         if (fast_half) {
-            if (a.gelu == 1) return a.ln_rows ? launch256<T, 1, 1, 1>(a5, grid, s) : launch256<T, 1, 0, 1>(a5, grid, s);
+            if (a.gelu == 1 || a.gelu == 6) return a.ln_rows ? launch256<T, 1, 1, 1>(a5, grid, s) : launch256<T, 1, 0, 1>(a5, grid, s);      // (half output only: both mean the degree-4 fit here)
             if (a.gelu == 2) return a.ln_rows ? launch256<T, 1, 1, 2>(a5, grid, s) : launch256<T, 1, 0, 2>(a5, grid, s);
             return a.ln_rows ? launch256<T, 1, 1, 0>(a5, grid, s) : launch256<T, 1, 0, 0>(a5, grid, s);
         }
@@ -1488,6 +1528,12 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
     if (dtype != AVEXHIP_F16 && dtype != AVEXHIP_BF16) {
         avexhip_set_error("gemm: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;
+    }
+    if (a.gelu == 1 && GEMM_GELU_H && a.out_half && !a.out_f32) {
+        // GELU whose only consumer reads the operand type: the degree-4 fit, in whichever kernel and epilogue form runs (activation code 6)
+        GemmArgs b = a;
+        b.gelu = 6;
+        return gemm(b, dtype, s);
     }
     if (a.lnr_y && !a.lnr_prefolded) {
         // the kernel takes alpha * gamma and bias + alpha * beta: callers that launch the same fold repeatedly keep those vectors
