@@ -588,6 +588,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ W = (const T*)p.W;
     const int nk = p.K / BK;   // >= 2 (launcher)
+    __builtin_assume(nk >= 2);      // (without it the residual epilogue's kernels zero the 128 accumulators twice per tile: once more on the path around an empty K loop)
     // blocks sharing blockIdx % 8 share an XCD: in round `it` they take 32 consecutive tiles
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7) >> 3;
     int m0 = 0, n0 = 0;
