@@ -19,6 +19,12 @@
 
 #include "common.h"
 
+#ifndef GEMM_SADDR
+#define GEMM_SADDR 0      // 1 (A/B builds): the streaming kernel's LDS-DMA addresses as scalar base + 32-bit lane offset instead of 64-bit pointers per lane.
+                          // MEASURED (profiles/r04w_epilogue_instructions.txt): the six DMAs of a K-tile's main path lose their v_lshl_add_u64, eight registers
+                          // come free -- and the step is 0.2 % SLOWER (every shape within +-0.4 %): the scalar unit now forms each base (s_mul / s_addc chains
+                          // between the s_mov m0 writes).  Not the default.
+#endif
 #ifndef GEMM_LNA_PK
 #define GEMM_LNA_PK 1     // 1: EPI 1's folded LayerNorm as packed FMAs on column pairs (0: four scalar fmaf, A/B)
 #endif
@@ -593,8 +599,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7) >> 3;
     int m0 = 0, n0 = 0;
 
+    // operand addresses of the LDS-DMA: a UNIFORM base per tile (the tile's first W row / A row: scalar registers) + a 32-bit byte offset per
+    // lane, so that the instruction takes the base from SGPRs and the K-tile's advance is scalar arithmetic.  As per-lane 64-bit pointers
+    // (GEMM_SADDR 0) every DMA cost a v_lshl_add_u64: eight 64-bit vector adds per K-tile and wave, and sixteen registers instead of eight.
+#if GEMM_SADDR
+    unsigned wsrc[2][2], xsrc[2][2];
+#else
     const T* wsrc[2][2];
     const T* xsrc[2][2];
+#endif
     int wdst[2][2], xdst[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -627,16 +640,26 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         } else if (grouped) tile_coords(tile, tiles_m, tiles_n, group_m, tm, tn);
         else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
         m0 = tm * T2; n0 = tn * T2;
+#if GEMM_SADDR
+        m0 = __builtin_amdgcn_readfirstlane(m0); n0 = __builtin_amdgcn_readfirstlane(n0);      // scalar registers, said explicitly: the DMA bases are formed from them
+        const int last = p.M - 1 - m0;                       // rows past M read row M - 1 (their outputs are never stored)
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int wr = 128 * q + 64 * h + 8 * wid + (lane >> 3);
-                wsrc[h][q] = W + (int64_t)(n0 + wr) * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3);
                 const int xr = 128 * q + 64 * (wid >> 2) + 32 * h + 8 * (wid & 3) + (lane >> 3);
+#if GEMM_SADDR
+                wsrc[h][q] = (unsigned)(((int64_t)wr * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3)) * 2);
+                const int ar = xr < last ? xr : last;
+                xsrc[h][q] = (unsigned)(((int64_t)ar * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3)) * 2);
+#else
+                wsrc[h][q] = W + (int64_t)(n0 + wr) * p.ldw + (((lane & 7) ^ ((wr >> 1) & 7)) << 3);
                 int arow = m0 + xr;
                 arow = arow < p.M ? arow : p.M - 1;
                 xsrc[h][q] = A + (int64_t)arow * p.lda + (((lane & 7) ^ ((xr >> 1) & 7)) << 3);
+#endif
             }
     };
     // GEMM_W_POLICY / GEMM_A_POLICY (A/B builds): cache-policy bits of the two operand streams' LDS-DMA (0 default, 2 = nt: stream, evict first).
@@ -645,13 +668,31 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     // pushes out of the caches are the next kernels' inputs.  (As a run-time branch around each DMA pair it also cost the loop 1.5 %.)
     auto dma_w = [&](int h, int kt, int stg) __attribute__((always_inline)) {
         char* base = smem + stg * STAGE2;
+#if GEMM_SADDR
+        const char* wk = (const char*)(W + (int64_t)n0 * p.ldw) + (int64_t)kt * (BK * 2);      // from the (scalar) tile coordinates every time: as a loop-carried pointer the base ends up in vector registers
+        // (the W offsets never change: left visible, their zero-extension is hoisted out of the loop as a 64-bit register pair and the DMA is
+        // back to a 64-bit vector address + v_lshl_add_u64; the empty asm keeps the extension at the instruction, where it is free)
+        unsigned w0 = wsrc[h][0], w1 = wsrc[h][1];
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wk + w0), (lptr_t*)(base + wdst[h][0]), 16, 0, GEMM_W_POLICY);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(wk + w1), (lptr_t*)(base + wdst[h][1]), 16, 0, GEMM_W_POLICY);
+#else
         __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][0] + kt * BK), (lptr_t*)(base + wdst[h][0]), 16, 0, GEMM_W_POLICY);
         __builtin_amdgcn_global_load_lds((gptr_t*)(wsrc[h][1] + kt * BK), (lptr_t*)(base + wdst[h][1]), 16, 0, GEMM_W_POLICY);
+#endif
     };
     auto dma_x = [&](int h, int kt, int stg) __attribute__((always_inline)) {
         char* base = smem + stg * STAGE2;
+#if GEMM_SADDR
+        const char* ak = (const char*)(A + (int64_t)m0 * p.lda) + (int64_t)kt * (BK * 2);
+        unsigned x0 = xsrc[h][0], x1 = xsrc[h][1];
+        asm volatile("" : "+v"(x0), "+v"(x1));
+        __builtin_amdgcn_global_load_lds((gptr_t*)(ak + x0), (lptr_t*)(base + xdst[h][0]), 16, 0, GEMM_A_POLICY);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(ak + x1), (lptr_t*)(base + xdst[h][1]), 16, 0, GEMM_A_POLICY);
+#else
         __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][0] + kt * BK), (lptr_t*)(base + xdst[h][0]), 16, 0, GEMM_A_POLICY);
         __builtin_amdgcn_global_load_lds((gptr_t*)(xsrc[h][1] + kt * BK), (lptr_t*)(base + xdst[h][1]), 16, 0, GEMM_A_POLICY);
+#endif
     };
     constexpr bool fast_half = EPI == 1, fast_resid = EPI == 2;
     constexpr bool LNA = EPI == 1 && (LN & 1), LNR = EPI == 2 && (LN & 1), STATS = EPI == 2 && (LN & 2);
