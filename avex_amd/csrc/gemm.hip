@@ -19,6 +19,9 @@
 
 #include "common.h"
 
+#ifndef GEMM_PEEL
+#define GEMM_PEEL 1       // 1: K-tile 0 of every output tile is a copy of the loop body whose first MFMA per accumulator has C = 0 (no zeroing pass); 0: A/B
+#endif
 #ifndef GEMM_SADDR
 #define GEMM_SADDR 0      // 1 (A/B builds): the streaming kernel's LDS-DMA addresses as scalar base + 32-bit lane offset instead of 64-bit pointers per lane.
                           // MEASURED (profiles/r04w_epilogue_instructions.txt): the six DMAs of a K-tile's main path lose their v_lshl_add_u64, eight registers
@@ -40,6 +43,7 @@
 #define HFROM(x) HFROM(x)
 #endif
 
+namespace { template <int N> struct a_ic { static constexpr int value = N; }; }
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -461,13 +465,15 @@ static int gemm_nt_mode(const avx::GemmArgs& a) {
 #ifndef AVX_SNAKE
 #define AVX_SNAKE 1
 #endif
+// (KT0: the first K-tile of an output tile -- its first MFMA per accumulator takes a literal zero as C, so the 128 accumulator registers are
+// never zeroed by v_mov_b32)
 #define AVX_HALF(hw)                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                         \
         const int j = AVX_SNAKE && (i & 1) ? 3 - jj : jj;                                      \
-        acc[4 * (hw) + i][j] = mfma16(wf[i][ks], xf[j][ks], acc[4 * (hw) + i][j]);             \
+        acc[4 * (hw) + i][j] = mfma16(wf[i][ks], xf[j][ks], (KT0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[4 * (hw) + i][j]);             \
     }                                                                                          \
     __builtin_amdgcn_s_setprio(0);
 #define AVX_BAR()                                   \
@@ -760,16 +766,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
     // pipeline never drains: no per-tile prologue, no workgroup turnaround, and the epilogue (private LDS slabs above the
     // stages, no barrier) runs with two K-tiles of the next tile already in flight.
     for (int it = 0;; ++it) {
+#if !GEMM_PEEL
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
         const bool stamp = stamp_on && tile < 8192;
         const int em0 = m0, en0 = n0;
         const int next_tile = xw ? t_lo + (it + 1) * per_xcd + slot : ((it + 1) * 8 + xcd) * per_xcd + slot;
         const bool has_next = next_tile < t_hi;
         AVX_STAMP(if (stamp) { g_gemm_stamps[4 * tile + 0] = g_gemm_stamps[4 * tile + 1] = __builtin_amdgcn_s_memrealtime(); g_gemm_clk[2 * tile] = __builtin_amdgcn_s_memtime(); });
-        for (int kt = 0; kt < nk; ++kt) {
+        auto k_tile = [&](int kt, auto kt0_tag) __attribute__((always_inline)) {
+            constexpr bool KT0 = decltype(kt0_tag)::value;
             const int st = (g0 + kt) & 1;
             AVX_STAMP(if (stamp && it == 2 && kt < 63 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + kt] = __builtin_amdgcn_s_memtime(););
             // A: W0 x (X0, X1); refill W1 of K-tile kt+1 (other stage, last read in B of K-tile kt-1)
@@ -804,7 +813,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             AVX_BAR();
             AVX_HALF(1);
             AVX_BAR();
-        }
+        
+        };
+#if GEMM_PEEL
+        k_tile(0, a_ic<1>{});                              // K-tile 0: C = 0
+        for (int kt = 1; kt < nk; ++kt) k_tile(kt, a_ic<0>{});
+#else
+        for (int kt = 0; kt < nk; ++kt) k_tile(kt, a_ic<0>{});
+#endif
         AVX_STAMP(if (stamp && it == 2 && nk < 64 && blockIdx.x < 256) g_gemm_kclk[blockIdx.x * 64 + nk] = __builtin_amdgcn_s_memtime(););
         // Re-align the two wave groups for the epilogue: left staggered, the lagging group cannot pass its last loop barrier before the
         // leading group reaches the next tile's first one, i.e. the two epilogues would run one after the other.
