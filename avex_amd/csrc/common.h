@@ -207,8 +207,9 @@ static __device__ __forceinline__ void gelu_erf2xN(f32x2 (&x)[N]) {
 // SiLU x * sigmoid(x) = x / (1 + 2^(-x log2 e)) (EfficientNet's activation), two elements at a time
 static __device__ __forceinline__ f32x2 silu2(f32x2 x) {
     const f32x2 t = x * (f32x2)(-1.4426950408889634f);
-    f32x2 d;
-    d[0] = 1.0f + __builtin_amdgcn_exp2f(t[0]); d[1] = 1.0f + __builtin_amdgcn_exp2f(t[1]);
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(t[0]); e[1] = __builtin_amdgcn_exp2f(t[1]);
+    const f32x2 d = e + (f32x2)(1.0f);          // one v_pk_add_f32 (written per element hipcc kept two v_add_f32)
     f32x2 r;
     r[0] = __builtin_amdgcn_rcpf(d[0]); r[1] = __builtin_amdgcn_rcpf(d[1]);
     return x * r;

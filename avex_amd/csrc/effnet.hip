@@ -339,6 +339,33 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, 
 // at the top of the PREVIOUS chunk and consumed before that chunk's output stores are issued -- a wait placed after the stores would have
 // to be vmcnt(0) (the stores are conditional, the compiler cannot count them) and would drain them: 1 - 2 us per chunk of ~1 us of work.
 // ---------------------------------------------------------------------------------------------
+// psum[e] += psum[e] of the lane 4 below, then of the lane 8 below, inside each 16-lane row (lanes without a source add 0): lanes 12 .. 15
+// of a row end with the row's four channel-group sums.  The DPP operand sits inside the add (v_add_f32_dpp): from the builtin hipcc makes a
+// v_mov_b32 0, a v_mov_b32_dpp and an add per step.  One asm block: the hazard recogniser does not look inside inline assembly -- a DPP read
+// needs two wait states after the VALU write of its source; the eight independent chains give the second step seven instructions of
+// distance, s_nop 1 covers whatever wrote the inputs.
+static __device__ __forceinline__ void row_quarter_sums(float (&p)[8]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+}
+
 typedef int a_i32x2m __attribute__((ext_vector_type(2)));
 struct MbArgs {
     const void* in; int H, W, ld_in;
@@ -531,13 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, S
         if (p.part) {
             // lanes with the same channel group are 4 apart: two DPP row shifts leave each 16-lane row's sums in its lanes 12 .. 15; the
             // sixteen rows of a workgroup are added in a fixed order below (no shuffles through the LDS crossbar: 32 ds_bpermute per chunk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float s = psum[e];
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x114, 0xf, 0xf, true));      // row_shr:4
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x118, 0xf, 0xf, true));      // row_shr:8
-                psum[e] = s;
-            }
+            row_quarter_sums(psum);
             if ((lane & 15) >= 12) {
                 float* dst = s_red + (wave * 4 + (lane >> 4)) * CC + ((lane & 15) - 12) * 8;
                 *(f32x4*)dst = (f32x4){psum[0], psum[1], psum[2], psum[3]};
@@ -803,13 +824,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         float* red = s_red + slot * (16 * CC);
         if (p.part) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float s = psum[e];
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x114, 0xf, 0xf, true));      // row_shr:4
-                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x118, 0xf, 0xf, true));      // row_shr:8
-                psum[e] = s;
-            }
+            row_quarter_sums(psum);
             if ((lane & 15) >= 12) {
                 float* dst = red + (wave * 4 + (lane >> 4)) * CC + ((lane & 15) - 12) * 8;
                 *(f32x4*)dst = (f32x4){psum[0], psum[1], psum[2], psum[3]};
