@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -144,16 +145,21 @@ int effnet_build(avexhip_effnet* h, const avexhip_tensor* tensors, int n) {
     // May the tensor that block `idx` reads (the stem's output for idx = 0, else block idx - 1's) be 32 channels wide in memory?  Every
     // consumer must take K = 32: the fused block front and the skinny GEMM do, the 128-tile kernels (K % 64) do not.  The head reads through
     // the 128-tile kernel; a block without an expansion feeds its 32 channels to its projection, which is skinny only up to 256 columns.
-    struct Bl { bool ex; int cexp, cout; };
+    // A block with a residual connection adds its INPUT rows to its output rows: the two tensors must have the same width, so its input may be
+    // narrow only if its output may be (found by tests/tools/fuzz_effnet.py: a 32-wide input added into a 64-wide output read every row's
+    // columns 32 .. 63 from the next row, and the last row's from stale memory).
+    struct Bl { bool ex, res; int cexp, cout; };
     std::vector<Bl> plan;
     for (int si = 0; si < c.n_stages; ++si)
         for (int j = 0; j < c.stage[si][5]; ++j) {
             const int ci = j == 0 ? c.stage[si][3] : c.stage[si][4];
-            plan.push_back({c.stage[si][0] != 1, ci * c.stage[si][0], c.stage[si][4]});
+            const int st = j == 0 ? c.stage[si][2] : 1;
+            plan.push_back({c.stage[si][0] != 1, st == 1 && ci == c.stage[si][4], ci * c.stage[si][0], c.stage[si][4]});
         }
-    auto narrow_ok = [&](size_t idx, int ch) -> bool {
+    std::function<bool(size_t, int)> narrow_ok = [&](size_t idx, int ch) -> bool {
         if (ch > 32 || !skinny_enabled() || idx >= plan.size()) return false;
         const Bl& n = plan[idx];
+        if (n.res && !narrow_ok(idx + 1, n.cout)) return false;
         if (n.ex) { const int ce = padx(n.cexp); return skinny_dim(ce) && ce * 32 <= 32768; }
         return pad128(n.cout) <= 256;
     };
