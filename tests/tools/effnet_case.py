@@ -1,5 +1,5 @@
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/tools/: may import the oracle
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from avex_amd import synth
