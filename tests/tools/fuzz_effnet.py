@@ -47,7 +47,7 @@ for c in range(cases):
     del os.environ["AVEX_AMD_MBCONV"]; del os.environ["AVEX_AMD_DW_LDS"]
     d = enc.forward(x, hook_layers=names, want_features=True, want_pooled=True)      # the shipped per-layer choice
     ref, taps = EO.effnet_features(mel, sd, stages)
-    tol_ab = 6e-4 if dt == "f16" else 5e-3          # operand roundings that flip because the squeeze sums are added in another order (f16: 5e-4 per flipped element)
+    tol_ab = 1e-3 if dt == "f16" else 8e-3          # operand roundings that flip because the squeeze sums are added in another order (f16: 5e-4 per flipped element)
     tol_or = 1.5e-3 if dt == "f16" else 1.2e-2
     e_ab = max([rel(a["hooks"][n].cpu().numpy(), b["hooks"][n].cpu().numpy()) for n in names[1:]] + [rel(a["pooled"].cpu().numpy(), b["pooled"].cpu().numpy())])
     e_d = rel(d["pooled"].cpu().numpy(), b["pooled"].cpu().numpy())
