@@ -230,7 +230,9 @@ typedef struct {
     const float* resid; int64_t ldr; float alpha;   /* fp32 residual, or ... */
     const void*  resid_half; int64_t ldrh;          /* ... residual in the operand type (resid == NULL) */
     int32_t gelu;                      /* activation after bias (+ residual): 0 none, 1 exact-erf GELU, 2 SiLU, 3 ReLU,
-                                          4 tanh-form GELU (modules.py:177-188), 5 tanh */
+                                          4 tanh-form GELU (modules.py:177-188), 5 tanh.  The erf GELU is evaluated to 4.5e-7
+                                          when an fp32 output is requested and to 6.3e-6 (a tenth of an f16 ulp at |gelu| = 0.1)
+                                          when the only output is in the operand type; whichever kernel runs, the same bits */
     float* out_f32;  int64_t ldo;
     void*  out_half; int64_t ldh;
     float* out_raw;  int64_t ldraw;
