@@ -1163,8 +1163,16 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
            const float* grep_a, const uint8_t* key_pad, void* out, int q_log2e, hipStream_t s) {
     AVX_ENSURE_LDS(attention_kernel<T>, ATT_LDS);
     static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
-    int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 2;   // 1 = stage-then-compute, 2 = persistent streamed
-    if (Tn > TMAX) variant = 2;          // variant 1 keeps a whole head in LDS (T <= 512)
+    // 1 = stage-then-compute, 2 = persistent streamed (32x32x16 MFMAs), 3 = persistent streamed on 16x16x32 MFMAs (attention16.hip; default up to 512 tokens)
+    int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 3;
+    if (Tn > TMAX) variant = 2;          // variants 1 and 3 are built for T <= 512
+    if (variant == 3) {
+        int n_cu = 256;
+        { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }
+        int n_wg = n_cu;
+        if (const char* fg = getenv("AVEX_AMD_ATT_GRID")) { const int g = atoi(fg); if (g > 0) n_wg = g; }
+        return avx::attention16(qkv, B, Tn, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, __is_same(T, _Float16) ? AVEXHIP_F16 : AVEXHIP_BF16, q_log2e, n_wg, s);
+    }
     if (variant == 2) {
         int n_cu = 256;
         { const int rc_ = avx::device_cu_count(&n_cu); if (rc_ != AVEXHIP_OK) return rc_; }

@@ -432,6 +432,9 @@ bool gemm_post_ln_ok(const GemmArgs& a);
 int attention(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w,
               const float* grep_b, const float* grep_a, const uint8_t* key_pad, void* out, int dtype,
               hipStream_t s, int q_log2e = 0);
+// variant 3 of the same (attention16.hip: 16x16x32 MFMAs, up to 512 tokens); avx::attention dispatches to it
+int attention16(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w, const float* grep_b, const float* grep_a,
+                const uint8_t* key_pad, void* out, int dtype, int q_log2e, int n_wg, hipStream_t s);
 int attention_hd(const void* qkv, int B, int T, int H, int head_dim, const uint8_t* key_pad, void* out, int dtype, hipStream_t s, int q_log2e = 0);
 int posconv_pack(const float* g, const float* v, int E, int groups, int K, void* w_packed, int dtype,
                  hipStream_t s);

@@ -397,9 +397,9 @@ def _toeplitz(table, T, nb, md):
     return tab
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("T", [496, 48, 384, 33, 512])
+@pytest.mark.parametrize("T", [496, 48, 384, 33, 512, 1, 17, 257, 300])
 def test_attention(built_lib, dtype, T, variant, monkeypatch):
     from avex_amd import kernels as K
     monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", variant)
@@ -475,7 +475,7 @@ def test_attention_key_padding_and_plain_bias(built_lib):
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("T,grid", [(496, 7), (200, 5), (300, 60), (512, 1)])
 def test_attention_persistent_items(built_lib, T, grid, variant, monkeypatch):
     """The persistent attention (variant 2) walks several (head, clip) items per workgroup: ranges that cross a head
@@ -500,7 +500,7 @@ def test_attention_persistent_items(built_lib, T, grid, variant, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 def test_attention_large_logits(built_lib, variant, dtype, monkeypatch):
     """Row maxima that keep growing along the keys exercise the deferred-maximum rescale of variant 2 (the branch is
     data dependent and rare on gaussian scores): q.k grows with the key index, so every tile moves the reference."""
