@@ -52,7 +52,13 @@ constexpr float A3_SUM_HI = 4096.f;                       // a half-row sum belo
 constexpr float A3_SUM_LO = 0.015625f;                    // first tile: a sum above 2^-6 means the row's numerators are not all deep in the subnormals
 
 #ifndef ATT3_PRIO
-#define ATT3_PRIO 1
+#define ATT3_PRIO 1      // 1: waves 4-7 at s_setprio 1 (one static raise); 2: waves 0-3 instead; 0: none
+#endif
+#ifndef ATT3_WG_STAGGER
+#define ATT3_WG_STAGGER 0   // workgroup w starts ((w >> 3) & 7) x this many 64-cycle sleeps late: the CUs' item ends (64 KiB of stores each) stop coinciding (A/B builds)
+#endif
+#ifndef ATT3_STAGGER
+#define ATT3_STAGGER 0   // waves 4-7 enter each phase's key tiles this many 64-cycle sleeps late (A/B builds)
 #endif
 // Diagnostics of the standalone harness (scripts/micro/att16_bench.hip); the library is built with both at 0, which compiles them out.
 #ifndef A3_KO
@@ -100,7 +106,8 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
     constexpr int NB = 4, NW = 8, NT = 512, NKT = 8;
     float* tab = (float*)(smem + A3_TAB_OFF);
     float* kadd = (float*)(smem + A3_KADD_OFF);
-    float* gw = (float*)(smem + A3_GW_OFF);
+    T* gwh = (T*)(smem + A3_GW_OFF);                     // gate weights: 4 rows of 64 halves
+    float* gwb = (float*)(smem + A3_GW_OFF + 512);      // the gate's two biases
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,23 +133,25 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
     // (the lane index goes through an empty asm in the three address-heavy blocks -- DMA issue, Q loads, output stores: the compiler would
     //  otherwise hoist their per-lane 64-bit offsets out of the phase loop, run out of registers and SPILL them, and a scratch reload drains
     //  vmcnt -- i.e. waits for the whole next K/V buffer -- in the middle of a phase: 4.5k cycles per phase and 12k per item, measured)
-    auto issue_next = [&](int ph) __attribute__((always_inline)) {
+    // One eighth of a wave's share of phase ph's buffer: piece u (0 .. 3) = one 1 KiB K piece and one 1 KiB V piece.  The pieces of phase
+    // ph + 1 go out INSIDE phase ph's first four key tiles (one per tile, in the stage that has no vector work), not as a burst at the phase
+    // boundary where every wave of the CU issued its eight at once and nothing else ran (2 - 4k cycles per phase, measured).
+    auto dma_piece = [&](int ph, int u) __attribute__((always_inline)) {
         const T* base = qkv + (int64_t)b_ld * Tn * ld + h_ld * 64;
         char* buf = smem + (ph & 1) * A3_HALF;
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ri = 4 * wave + u;                                   // 8-key group inside the half
-            const int kl = 8 * ri + (lane >> 3);
-            int key = half_ld * 256 + kl;
-            key = key < Tn ? key : Tn - 1;                                 // clamped rows are masked by kadd
-            const int chunk = (lane & 7) ^ ((kl >> 1) & 7);
-            a3_dma16(base + (int64_t)key * ld + E + chunk * 8, buf + ri * 1024);
-            int vkey = half_ld * 256 + 8 * ri + ((lane >> 1) & 7);         // piece = [16-d block = lane >> 4][key & 7][two 16-byte chunks]
-            vkey = vkey < Tn ? vkey : Tn - 1;
-            a3_dma16(base + (int64_t)vkey * ld + 2 * E + 16 * (lane >> 4) + 8 * (lane & 1), buf + A3_KBUF + ri * 1024);
-        }
+        const int ri = 4 * wave + u;                                   // 8-key group inside the half
+        const int kl = 8 * ri + (lane >> 3);
+        int key = half_ld * 256 + kl;
+        key = key < Tn ? key : Tn - 1;                                 // clamped rows are masked by kadd
+        const int chunk = (lane & 7) ^ ((kl >> 1) & 7);
+        a3_dma16(base + (int64_t)key * ld + E + chunk * 8, buf + ri * 1024);
+        int vkey = half_ld * 256 + 8 * ri + ((lane >> 1) & 7);         // piece = [16-d block = lane >> 4][key & 7][two 16-byte chunks]
+        vkey = vkey < Tn ? vkey : Tn - 1;
+        a3_dma16(base + (int64_t)vkey * ld + 2 * E + 16 * (lane >> 4) + 8 * (lane & 1), buf + A3_KBUF + ri * 1024);
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
         if (++half_ld == nh) { half_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } }
     };
     auto write_kadd = [&](int slot, int b) __attribute__((always_inline)) {
@@ -170,9 +179,12 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "=&v"(qf[nb][0]), "=&v"(qf[nb][1]) : "v"(src) : "memory");
         }
     };
-    if (ATT3_PRIO && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    if (ATT3_WG_STAGGER > 0) { for (int i = 0; i < (int)((blockIdx.x >> 3) & 7); ++i) __builtin_amdgcn_s_sleep(ATT3_WG_STAGGER); }
+    if ((ATT3_PRIO == 1 && wave >= NW / 2) || (ATT3_PRIO == 2 && wave < NW / 2)) __builtin_amdgcn_s_setprio(1);
     load_q(h_cur, b_cur);                                // older than the DMA below: waiting for it never waits for the DMA
-    issue_next(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma_piece(0, u);
+    dma_advance();
     write_kadd(0, b_cur);
     if (tid < 64) {
         float a = 0.f, bb = 0.f;
@@ -180,12 +192,17 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             a = (grep_w[0 * 64 + tid] + grep_w[1 * 64 + tid]) + (grep_w[2 * 64 + tid] + grep_w[3 * 64 + tid]);
             bb = (grep_w[4 * 64 + tid] + grep_w[5 * 64 + tid]) + (grep_w[6 * 64 + tid] + grep_w[7 * 64 + tid]);
         }
-        const float ginv = q_log2e ? 0.6931471805599453f : 1.0f;      // (see attention_kernel: the gate reads the unscaled q)
-        gw[tid] = a * ginv;
-        gw[64 + tid] = bb * ginv;
+        // The gate's two dot products q . wa, q . wb run on the matrix pipe against the SCALED query fragment (q log2(e) / 8 in either
+        // mode of q_log2e), so the weights take 8 ln 2; each is split into two halves-type rows hi + lo (hi = the rounded weight, lo = the
+        // rounded rest: 22 significant bits for f16, 16 for bf16), rows {wa_hi, wb_hi, wa_lo, wb_lo}.
+        const float wsc = 8.0f * 0.6931471805599453f;
+        const float wa = a * wsc, wb = bb * wsc;
+        const T wah = (T)wa, wbh = (T)wb;
+        gwh[0 * 64 + tid] = wah; gwh[1 * 64 + tid] = wbh;
+        gwh[2 * 64 + tid] = (T)(wa - (float)wah); gwh[3 * 64 + tid] = (T)(wb - (float)wbh);
         if (tid == 0) {
-            gw[128] = grep_w ? (grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]) : 0.f;
-            gw[129] = grep_w ? (grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]) : 0.f;
+            gwb[0] = grep_w ? (grep_b[0] + grep_b[1]) + (grep_b[2] + grep_b[3]) : 0.f;
+            gwb[1] = grep_w ? (grep_b[4] + grep_b[5]) + (grep_b[6] + grep_b[7]) : 0.f;
         }
     }
     if (tid < 4 * A3_TPAD) tab[(tid >> 6) * A3_TLD + (tid & 63)] = 0.f;      // the front pads (read, never used: finite)
@@ -223,18 +240,22 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             const float inv = __builtin_amdgcn_rcpf(l_tot);
             const int qrow = Q0 + 16 * nb + c;
             T* orow = out + ((int64_t)b * Tn + qrow) * E + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
+            const f32x2 inv2 = {inv, inv};
+            typedef typename a3_v2<T>::type v2;
+            // two halves per register; the empty asm keeps each conversion a plain packed multiply + packed convert (left alone, hipcc rebuilt the
+            // eight values of a store from mixed-precision FMAs, packs and align-bits: 26 instructions per store instead of 10)
+            auto pk = [&](const f32x4 v, int hi) __attribute__((always_inline)) -> unsigned {
+                const f32x2 x = (f32x2){v[2 * hi], v[2 * hi + 1]} * inv2;
+                // plain conversions: an output row is a convex combination of V rows, it cannot leave the operand type's range
+                const v2 h = {(T)x[0], (T)x[1]};
+                unsigned u = __builtin_bit_cast(unsigned, h);
+                asm volatile("" : "+v"(u));
+                return u;
+            };
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                v4 x, y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // plain conversions: an output row is a convex combination of V rows, it cannot leave the operand type's range
-                    x[e] = (T)(o[nb][2 * p][e] * inv);
-                    y[e] = (T)(o[nb][2 * p + 1][e] * inv);
-                }
-                const a3_i32x2 xi = __builtin_bit_cast(a3_i32x2, x), yi = __builtin_bit_cast(a3_i32x2, y);
-                const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)xi[0], (unsigned)yi[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)xi[1], (unsigned)yi[1], false, false);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pk(o[nb][2 * p], 0), pk(o[nb][2 * p + 1], 0), false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pk(o[nb][2 * p], 1), pk(o[nb][2 * p + 1], 1), false, false);
                 const a3_i32x4 w = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
                 if (qrow < Tn) *(a3_i32x4*)(orow + 32 * p) = w;
             }
@@ -289,35 +310,8 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                 bn = bn == Bc ? 0 : bn;
                 write_kadd(item_par ^ 1, bn);
             }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                gm[nb][0] = 1.f;
-                if (grep_w) {
-                    f32x2 pa = {0.f, 0.f}, pb = {0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                        for (int j4 = 0; j4 < 2; ++j4) {
-                            const f32x4 wa = *(const f32x4*)(gw + 32 * s + 8 * g + 4 * j4);
-                            const f32x4 wb = *(const f32x4*)(gw + 64 + 32 * s + 8 * g + 4 * j4);
-                            const f32x2 q01 = {(float)qf[nb][s][4 * j4], (float)qf[nb][s][4 * j4 + 1]};
-                            const f32x2 q23 = {(float)qf[nb][s][4 * j4 + 2], (float)qf[nb][s][4 * j4 + 3]};
-                            pa = __builtin_elementwise_fma((f32x2){wa[0], wa[1]}, q01, pa);
-                            pa = __builtin_elementwise_fma((f32x2){wa[2], wa[3]}, q23, pa);
-                            pb = __builtin_elementwise_fma((f32x2){wb[0], wb[1]}, q01, pb);
-                            pb = __builtin_elementwise_fma((f32x2){wb[2], wb[3]}, q23, pb);
-                        }
-                    }
-                    const float sa = a3_rows_sum(hsum2(pa)), sb = a3_rows_sum(hsum2(pb));
-                    const float ga = 1.f / (1.f + __expf(-(sa + gw[128])));
-                    const float gb = 1.f / (1.f + __expf(-(sb + gw[129])));
-                    gm[nb][0] = ga * (gb * grep_a[h_cur] - 1.f) + 2.f;
-                }
-            }
-        }
-        // (the setup's own global loads -- a new head's bias row, a key mask -- are waited for by the compiler where their values are used; from
-        //  here to the next boundary a phase touches only LDS and registers)
-        if (half == 0) {
+            // this item's fragment arrives unscaled; from here on it carries the score scale (1/8 is exact in the operand type; log2(e) is not
+            // -- bf16: 0.18 % off, a temperature error on every logit -- so the handles fold it into W_q in fp32: q_log2e)
             const T qs = (T)cs;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -325,8 +319,27 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int e8 = 0; e8 < 8; ++e8) qf[nb][s][e8] = qf[nb][s][e8] * qs;
+            // gate(b, h, i) = ga (gb a_h - 1) + 2, (ga, gb) = sigmoid(q . wa + ba, q . wb + bb) (backbone.py:543-551): two MFMAs per query
+            // block against the four weight rows repeated down the 16 operand rows, so EVERY lane ends with its query's four partial products
+            // in its own accumulator registers -- no cross-lane traffic (as vector code: 60 instructions and four lane exchanges per block)
+            if (grep_w) {
+                const v8 gA0 = *(const v8*)(gwh + (c & 3) * 64 + 8 * g), gA1 = *(const v8*)(gwh + (c & 3) * 64 + 32 + 8 * g);
+                const float ba = gwb[0], bb = gwb[1], ah = grep_a[h_cur];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f32x4 acc = mfma16(gA0, qf[nb][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    acc = mfma16(gA1, qf[nb][1], acc);
+                    const float sa = (acc[0] + acc[2]) + ba, sb = (acc[1] + acc[3]) + bb;
+                    const float ga = __builtin_amdgcn_rcpf(1.f + __expf(-sa)), gb = __builtin_amdgcn_rcpf(1.f + __expf(-sb));
+                    gm[nb][0] = ga * (gb * ah - 1.f) + 2.f;
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) gm[nb][0] = 1.f;
+            }
         }
-        if (ph + 1 < np) issue_next(ph + 1);
+        const bool do_dma = ph + 1 < np;
+        int dma_done = 0;                                 // pieces of phase ph + 1 this wave has issued (wave-uniform)
         A3_PT(2)
         if (has_q) {
             const char* Kb = smem + (ph & 1) * A3_HALF;
@@ -340,6 +353,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             const float* tp = tab + (e0 & 3) * A3_TLD + A3_TPAD + (e0 & ~3);
             const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + A3_KBUF + v_lane);
 
+            if (ATT3_STAGGER > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(ATT3_STAGGER);
             v8 kf[2][2];                                 // [k-step][key block]
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -473,6 +487,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                     if (!(A3_KO & 4)) Sq[0][kb] = mfma16(kf[s][kb], qf[0][s], Sq[0][kb]);
                     A3_FENCE();
                 }
+                if (kt < 4 && do_dma) { dma_piece(ph + 1, kt); dma_done = kt + 1; A3_FENCE(); }
                 {
                     // this tile's V fragments (transposed reads) and the next tile's bias runs go out AFTER every K fragment has met its first
                     // MFMA: the compiler counts only its own LDS reads, so a wait it places for a K fragment behind these would wait for them too
@@ -590,13 +605,19 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             if (7 < kt_end) tile(a3_ic<7>{});
 #undef A3_FENCE
         }
+        if (do_dma) {
+            for (int u = dma_done; u < 4; ++u) dma_piece(ph + 1, u);      // short clips, waves without query rows
+            dma_advance();
+        }
         A3_PT(11)
         if (last_half) {
             // the item is complete: its Q fragment is dead, the next item's goes straight into the same registers; then normalise and store
             int hn = h_cur, bn = b_cur + 1;
             if (bn == Bc) { bn = 0; ++hn; }
             if (more_items) load_q(hn, bn);
+            A3_PT(13)
             store_item(h_cur, b_cur);
+            A3_PT(14)
             item_par ^= 1;
             h_cur = hn; b_cur = bn;
 #pragma unroll

@@ -59,11 +59,11 @@ int main(int argc, char** argv) {
 #if A3_STAMPS
     std::vector<unsigned long long> st(16 * 8 * 16 * 16);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_a3_stamps), st.size() * 8);
-    const char* names[13] = {"top", "barrier", "setup", "t0", "t1", "t2", "t3", "t4", "t5", "t6", "t7", "tiles_end", "end"};
+    const char* names[15] = {"top", "barrier", "setup", "t0", "t1", "t2", "t3", "t4", "t5", "t6", "t7", "tiles_end", "end", "q_issued", "stored"};
     for (int ph = 6; ph <= 7; ++ph)
         for (int w = 0; w < 8; w += 4) {
             printf("phase %d wave %d: cycles since phase top (median over 16 blocks):", ph, w);
-            for (int i = 1; i < 13; ++i) {
+            for (int i = 1; i < 15; ++i) {
                 std::vector<long long> v;
                 for (int b = 0; b < 16; ++b) { const unsigned long long* d = &st[(((size_t)b * 8 + w) * 16 + ph) * 16]; if (d[i] && d[0]) v.push_back((long long)(d[i] - d[0])); }
                 std::sort(v.begin(), v.end());
