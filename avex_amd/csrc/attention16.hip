@@ -57,6 +57,9 @@ constexpr float A3_SUM_LO = 0.015625f;                    // first tile: a sum a
 #ifndef ATT3_WG_STAGGER
 #define ATT3_WG_STAGGER 0   // workgroup w starts ((w >> 3) & 7) x this many 64-cycle sleeps late: the CUs' item ends (64 KiB of stores each) stop coinciding (A/B builds)
 #endif
+#ifndef ATT3_FULL_LINES
+#define ATT3_FULL_LINES 0   // 1: output stores as whole 128-byte lines (see store_item; measured level with the default: 285.2 vs 285.1 us, profiles/r05a_attention16.txt)
+#endif
 #ifndef ATT3_STAGGER
 #define ATT3_STAGGER 0   // waves 4-7 enter each phase's key tiles this many 64-cycle sleeps late (A/B builds)
 #endif
@@ -68,7 +71,7 @@ constexpr float A3_SUM_LO = 0.015625f;                    // first tile: a sum a
 #define A3_STAMPS 0      // 1: s_memtime stamps per phase and key tile into g_a3_stamps
 #endif
 #if A3_STAMPS
-__device__ unsigned long long g_a3_stamps[16 * 8 * 16 * 16];      // [block < 16][wave][phase < 16][16]
+__device__ unsigned long long g_a3_stamps[3 * 16 * 8 * 16 * 16];      // [block < 16][wave][phase < 16][16]; with A3_STAMPS == 2 two more copies: the stage stamps of key tiles 1 and 6
 #endif
 
 // all-reduce over the four 16-lane rows of a wave (the lanes that share a query row) without LDS: two lane swaps
@@ -238,8 +241,6 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             if (Q0 + 16 * nb >= Tn) continue;                              // wave-uniform
             const float l_tot = a3_rows_sum(l_run[nb]);
             const float inv = __builtin_amdgcn_rcpf(l_tot);
-            const int qrow = Q0 + 16 * nb + c;
-            T* orow = out + ((int64_t)b * Tn + qrow) * E + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
             const f32x2 inv2 = {inv, inv};
             typedef typename a3_v2<T>::type v2;
             // two halves per register; the empty asm keeps each conversion a plain packed multiply + packed convert (left alone, hipcc rebuilt the
@@ -252,13 +253,40 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                 asm volatile("" : "+v"(u));
                 return u;
             };
+            // after the swaps lane (c, g) owns two 16-byte chunks of row c: chunk k0 = 2 (g & 1) + (g >> 1) of the row's first 64 bytes (w[0]) and the
+            // same chunk of its second 64 bytes (w[1])
+            int w[2][4];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const auto s0 = __builtin_amdgcn_permlane16_swap(pk(o[nb][2 * p], 0), pk(o[nb][2 * p + 1], 0), false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(pk(o[nb][2 * p], 1), pk(o[nb][2 * p + 1], 1), false, false);
-                const a3_i32x4 w = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-                if (qrow < Tn) *(a3_i32x4*)(orow + 32 * p) = w;
+                w[p][0] = (int)s0[0]; w[p][1] = (int)s1[0]; w[p][2] = (int)s0[1]; w[p][3] = (int)s1[1];
             }
+#if ATT3_FULL_LINES
+            // Full 128-byte lines per store instruction (8 rows x 128 B instead of 16 rows x 64 B; the store path is issue-bound at the end of an
+            // item and half lines cost it twice the requests): lanes c and c + 8 of a 16-lane row trade one chunk -- lane c < 8 gives its second-half
+            // chunk and takes lane c + 8's first-half chunk -- so the first store writes rows 0 .. 7 whole and the second rows 8 .. 15.  Three DPP
+            // moves per register (row rotate by 8 with a bank mask).
+            a3_i32x4 wa, wb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = __builtin_amdgcn_update_dpp(0, w[0][e], 0x128, 0xF, 0xF, false);            // t[i] = w0[(i + 8) % 16]
+                wa[e] = __builtin_amdgcn_update_dpp(w[0][e], w[1][e], 0x128, 0xF, 0xC, false);            // lanes 8-15: w1 of lane i - 8; lanes 0-7 keep w0
+                wb[e] = __builtin_amdgcn_update_dpp(w[1][e], t, 0xE4, 0xF, 0x3, false);                   // lanes 0-7: w0 of lane i + 8; lanes 8-15 keep w1
+            }
+            const int qrow = Q0 + 16 * nb + (c & 7);
+            T* orow = out + ((int64_t)b * Tn + qrow) * E + h * 64 + 16 * (g & 1) + 8 * (g >> 1) + 32 * (c >> 3);
+            if (qrow < Tn) *(a3_i32x4*)orow = wa;
+            if (qrow + 8 < Tn) *(a3_i32x4*)(orow + 8 * (int64_t)E) = wb;
+#else
+            const int qrow = Q0 + 16 * nb + c;
+            T* orow = out + ((int64_t)b * Tn + qrow) * E + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const a3_i32x4 wv = {w[p][0], w[p][1], w[p][2], w[p][3]};
+                if (qrow < Tn) *(a3_i32x4*)(orow + 32 * p) = wv;
+            }
+#endif
         }
     };
 
@@ -480,6 +508,9 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                     if ((A3_KO & 16) || !BIAS) { if (kb == 0) acc_plain(nn); }
                     else acc_start(nn, kb, run[(2 * (kt + 1) + kb - nn + 3) % 5]);
                 };
+#define A3_TS(i) if (A3_STAMPS == 2 && (kt == 6 || kt == 1)) { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+                unsigned long long ts[12];
+                A3_TS(0)
                 // ---- stage 0: S of query block 0
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -504,6 +535,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                     }
                     A3_FENCE();
                 }
+                A3_TS(1)
                 // ---- stages 1 .. 3: S of block n | exponentials of block n - 1 | conversions, sums, masks of block n - 2
 #pragma unroll
                 for (int nb = 1; nb < NB; ++nb) {
@@ -516,6 +548,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                         if (nb >= 2) X(nb - 2, i);
                         A3_FENCE();
                     }
+                    A3_TS(1 + nb)
                 }
                 check(0);
                 A3_FENCE();
@@ -535,6 +568,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                         for (int kb = 0; kb < 2; ++kb) kf[s][kb] = *(const v8*)(kp[s] + 4096 * (kt + 1) + 2048 * kb);
                 }
                 A3_FENCE();
+                A3_TS(5)
                 // ---- stage 4: P V of block 0 | exponentials of block 3 | conversions, sums, masks of block 2
                 {
                     const v8 pf = pfrag(0);
@@ -549,6 +583,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                 }
                 check(1);
                 A3_FENCE();
+                A3_TS(6)
                 // ---- stage 5: P V of block 1 | conversions, sums, masks of block 3 | the next key tile's accumulator starts 0, 1
                 {
                     const v8 pf = pfrag(1);
@@ -563,6 +598,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                 }
                 check(2);
                 A3_FENCE();
+                A3_TS(7)
                 // ---- stage 6: P V of block 2 | starts 2, 3, 4
                 {
                     const v8 pf = pfrag(2);
@@ -575,6 +611,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                 }
                 check(3);
                 A3_FENCE();
+                A3_TS(8)
                 // ---- stage 7: P V of block 3 | starts 5, 6, 7
                 {
                     const v8 pf = pfrag(3);
@@ -585,7 +622,16 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
                         if (db < 3) { acc_next(5 + db); A3_FENCE(); }
                     }
                 }
+                A3_TS(9)
                 if (kt + 1 < NKT && masked_at(kt + 1)) mask_acc(kt + 1);
+#if A3_STAMPS == 2
+                if ((kt == 6 || kt == 1) && blockIdx.x < 16 && lane == 0 && ph < 16) {
+                    unsigned long long* d = g_a3_stamps + (((size_t)(16 + blockIdx.x) * 8 + wave) * 16 + ph) * 16;
+                    if (kt == 6) d += 16 * 8 * 16 * 16;
+                    for (int i = 0; i < 10; ++i) d[i] = ts[i];
+                }
+#endif
+#undef A3_TS
             };
             A3_PT(3)
             if (0 < kt_end) tile(a3_ic<0>{});

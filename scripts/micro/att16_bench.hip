@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     const double fl = 4.0 * B * T * (double)T * H * 64;
     printf("A3_KO=%d B=%d T=%d: mean %.1f us  min %.1f us  (%.0f TFLOP/s at the mean)\n", (int)A3_KO, B, T, tot / 5 * 1e3, best * 1e3, fl / (tot / 5 * 1e-3) / 1e12);
 #if A3_STAMPS
-    std::vector<unsigned long long> st(16 * 8 * 16 * 16);
+    std::vector<unsigned long long> st(3 * 16 * 8 * 16 * 16);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_a3_stamps), st.size() * 8);
     const char* names[15] = {"top", "barrier", "setup", "t0", "t1", "t2", "t3", "t4", "t5", "t6", "t7", "tiles_end", "end", "q_issued", "stored"};
     for (int ph = 6; ph <= 7; ++ph)
@@ -71,6 +71,19 @@ int main(int argc, char** argv) {
             }
             printf("\n");
         }
+#if A3_STAMPS == 2
+    for (int tile = 0; tile < 2; ++tile)
+        for (int w = 0; w < 8; w += 4) {
+            printf("phase 6, key tile %d, wave %d: cycles per stage 0..7 + tail (median over 16 blocks):", tile ? 6 : 1, w);
+            for (int i = 1; i < 10; ++i) {
+                std::vector<long long> v;
+                for (int b = 0; b < 16; ++b) { const unsigned long long* d = &st[(size_t)(1 + tile) * 16 * 8 * 16 * 16 + (((size_t)b * 8 + w) * 16 + 6) * 16]; if (d[i] && d[i - 1]) v.push_back((long long)(d[i] - d[i - 1])); }
+                std::sort(v.begin(), v.end());
+                printf(" %lld", v.empty() ? -1 : v[v.size() / 2]);
+            }
+            printf("\n");
+        }
+#endif
 #endif
     return 0;
 }
