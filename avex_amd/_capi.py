@@ -54,7 +54,7 @@ class BeatsConfig(C.Structure):
                 ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float), ("fbank_mean", C.c_float),
                 ("fbank_std", C.c_float), ("operand_dtype", C.c_int32), ("max_chunk_clips", C.c_int32),
                 ("residual_dtype", C.c_int32), ("layer_norm_first", C.c_int32), ("activation_fn", C.c_int32),
-                ("conv_bias", C.c_int32)]
+                ("conv_bias", C.c_int32), ("hidden_shift", C.c_int32)]
 
 
 # activation_fn codes of BeatsConfig (AVEXHIP_FFN_* in include/avexhip.h), keyed by get_activation_fn's names (modules.py:203-237)

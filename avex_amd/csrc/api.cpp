@@ -220,6 +220,7 @@ struct avexhip_beats : avxh::HandleBase {
     avexhip_fbank_plan* fb = nullptr;
     void* w_patch = nullptr; float* b_patch = nullptr;      // b_patch: conv_bias=True (beats.py:263-269), else NULL
     bool pre_ln = false; int act = 1; bool glu = false;     // layer_norm_first / activation_fn of the config (CoreCfg)
+    int hidden_shift = 0;                                   // avexhip_beats_config::hidden_shift (CoreCfg)
     float* ln0_w = nullptr; float* ln0_b = nullptr;
     void* w_post = nullptr; float* b_post = nullptr;
     void* w_pc = nullptr; float* b_pc = nullptr;
@@ -243,7 +244,7 @@ struct avexhip_beats : avxh::HandleBase {
     CoreCfg core() const {
         CoreCfg c;
         c.E = E; c.F = F; c.H = H; c.L = L; c.alpha = alpha; c.eps = 1e-5f; c.hook_site = 0; c.fast = fast; c.fold = ln_fold;
-        c.fold_min_rows = ln_fold_min_rows; c.batch_invariant = batch_invariant; c.act = act; c.glu = glu; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
+        c.fold_min_rows = ln_fold_min_rows; c.batch_invariant = batch_invariant; c.act = act; c.glu = glu; c.hidden_shift = hidden_shift; c.pre_ln = pre_ln; c.final_ln_w = lnE_w; c.final_ln_b = lnE_b;
         return c;
     }
     ~avexhip_beats() override {
@@ -642,6 +643,10 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
         avexhip_set_error("beats_create: unknown operand dtype %d", c.operand_dtype);
         return nullptr;
     }
+    if (c.hidden_shift < 0 || c.hidden_shift > 24 || (c.hidden_shift > 0 && c.activation_fn == AVEXHIP_FFN_GLU)) {
+        avexhip_set_error("beats_create: hidden_shift must be 0..24 and is not built for the GLU feed-forward (got %d)", c.hidden_shift);
+        return nullptr;
+    }
     avexhip_beats* h = new avexhip_beats();
     h->cfg = c;
     h->dtype = c.operand_dtype;
@@ -659,6 +664,8 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
     }
     h->pre_ln = c.layer_norm_first != 0;
     h->glu = c.activation_fn == AVEXHIP_FFN_GLU;
+    h->hidden_shift = c.hidden_shift;
+    if (h->hidden_shift > 0) h->ln_fold = false;      // the folded epilogues are the fast ones, which do not scale (GemmArgs::half_scale)
     switch (c.activation_fn) {      // GemmArgs::gelu codes
         case AVEXHIP_FFN_GELU: h->act = 1; break;
         case AVEXHIP_FFN_RELU: h->act = 3; break;
@@ -694,7 +701,7 @@ extern "C" avexhip_beats* avexhip_beats_create(const avexhip_beats_config* cfg, 
         return nullptr;
     }
     h->alpha = c.deep_norm ? powf(2.0f * (float)c.encoder_layers, 0.25f) : 1.0f;
-    if (build(h, tensors, n_tensors) != AVEXHIP_OK) {
+    if (build(h, tensors, n_tensors) != AVEXHIP_OK || h->weights_fit() != AVEXHIP_OK) {
         delete h;
         return nullptr;
     }

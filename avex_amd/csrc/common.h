@@ -331,6 +331,8 @@ struct GemmArgs {
     void* out_half; int64_t ldh;
     float* out_raw; int64_t ldraw;
     const uint8_t* row_zero;  // optional [M] mask: rows with 1 store zeros to every output
+    float half_scale;         // 0 or 1: off.  Otherwise out_half receives value * half_scale (a power of two: the third rung of the f16 range ladder stores
+                              // fc1's hidden activations scaled down and folds the inverse into fc2's weights); generic epilogues only, fp32 outputs unscaled
     int variant;
     // ---- LayerNorm folded into the GEMMs around it (256-tile streaming kernel) --------------------------------------
     // A tensor y that is only ever consumed through LayerNorm is kept RAW in the operand type.  The GEMM that produces y writes
@@ -408,7 +410,8 @@ int lnr_fold(const float* gamma, const float* beta, const float* bias, float alp
 // exactly one of in / in_half is non-null
 int layernorm(const float* in, const void* in_half, int64_t ld_in, const float* w, const float* b, float eps, int M,
               int C, float* out_f32, int64_t ldo, void* out_half, int64_t ldh, int dtype, hipStream_t s);
-int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s);
+// ovf: optional device counter of the lanes that rounded a value beyond +-65504 to an f16 destination (see GemmArgs::ovf)
+int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s, unsigned int* ovf = nullptr);
 int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t s);
 int cast_to_f32(const void* in, float* out, int64_t n, int dtype, hipStream_t s);
 int mean_pool(const float* in, int B, int T, int C, const uint8_t* frame_pad, float* out, hipStream_t s);

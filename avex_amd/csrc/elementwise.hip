@@ -9,11 +9,13 @@
 namespace {
 
 template <typename T>
-__global__ void cast_to_half_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+__global__ void cast_to_half_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n, unsigned int* __restrict__ ovf) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    float ovf_mx = 0.f;      // range alarm of an f16 destination (values saturate at +-65504): a handle's weight upload refuses a checkpoint that does not fit
     for (; i + 3 < n; i += stride) {
         const f32x4 v = *(const f32x4*)(in + i);
+        ovf_see4<T>(ovf_mx, v);
         typename Half<T>::v4 h;
         h[0] = Half<T>::from(v[0]); h[1] = Half<T>::from(v[1]);
         h[2] = Half<T>::from(v[2]); h[3] = Half<T>::from(v[3]);
@@ -22,8 +24,10 @@ __global__ void cast_to_half_kernel(const float* __restrict__ in, T* __restrict_
     // tail (n % 4) handled by the first threads of block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t j = (n & ~(int64_t)3) + threadIdx.x;
+        ovf_see<T>(ovf_mx, in[j], 0.f);
         out[j] = Half<T>::from(in[j]);
     }
+    ovf_commit<T>(ovf, ovf_mx);
 }
 
 template <typename T>
@@ -523,16 +527,16 @@ int row_sum_half(const void* w, int N, int K, float* out, int dtype, hipStream_t
 }
 
 
-int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s) {
+int cast_to_half(const float* in, void* out, int64_t n, int dtype, hipStream_t s, unsigned int* ovf) {
     AVX_REQUIRE(in && out && n >= 0, "cast_to_half: bad arguments");
     if (n == 0) return AVEXHIP_OK;
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     if (dtype == AVEXHIP_F16)
-        hipLaunchKernelGGL(cast_to_half_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, in, (_Float16*)out, n);
+        hipLaunchKernelGGL(cast_to_half_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, in, (_Float16*)out, n, ovf);
     else if (dtype == AVEXHIP_BF16)
-        hipLaunchKernelGGL(cast_to_half_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, in, (__bf16*)out, n);
+        hipLaunchKernelGGL(cast_to_half_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, in, (__bf16*)out, n, ovf);
     else {
         avexhip_set_error("cast_to_half: unknown dtype %d", dtype);
         return AVEXHIP_ERR_INVALID;

@@ -182,7 +182,7 @@ extern "C" avexhip_eat* avexhip_eat_create(const avexhip_eat_config* cfg, const 
     h->P = c.patch_size;
     h->n_patches = (c.target_length / 16) * (c.n_mels / 16);
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
-    if (h->init_alarm() != AVEXHIP_OK || eat_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
+    if (h->init_alarm() != AVEXHIP_OK || eat_build(h, tensors, n_tensors) != AVEXHIP_OK || h->weights_fit() != AVEXHIP_OK) { delete h; return nullptr; }
     return h;
 }
 
@@ -337,6 +337,7 @@ extern "C" avexhip_stack* avexhip_stack_create(const avexhip_stack_config* cfg, 
     for (int i = 0; i < h->core.L; ++i)
         if (avxh::build_layer(h, tb, STACK_NAMES, h->core, h->layers, i) != AVEXHIP_OK) { delete h; return nullptr; }
     if (hipDeviceSynchronize() != hipSuccess) { avexhip_set_error("stack_create: upload failed"); delete h; return nullptr; }
+    if (h->weights_fit() != AVEXHIP_OK) { delete h; return nullptr; }
     return h;
 }
 
@@ -536,7 +537,7 @@ extern "C" avexhip_aves* avexhip_aves_create(const avexhip_aves_config* cfg, con
     h->core.batch_invariant = avxh::cfg_batch_invariant(c.residual_dtype);
     avxh::fold_policy(h->core.fast, c.embed_dim, c.ffn_dim, &h->core.fold, &h->core.fold_min_rows, h->core.batch_invariant);
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 64;       // layer 0 of the extractor holds 32 MB per 10 s clip
-    if (h->init_alarm() != AVEXHIP_OK || aves_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
+    if (h->init_alarm() != AVEXHIP_OK || aves_build(h, tensors, n_tensors) != AVEXHIP_OK || h->weights_fit() != AVEXHIP_OK) { delete h; return nullptr; }
     return h;
 }
 

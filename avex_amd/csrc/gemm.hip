@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
             if (p.gelu) v = act4_any(v, p.gelu);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
+                if (p.half_scale != 0.f) v = v * p.half_scale;      // (GemmArgs::half_scale; wave-uniform)
                 ovf_see4<T>(ovf_mx, v);
                 v4 h;
                 h[0] = HFROM(v[0]); h[1] = HFROM(v[1]);
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, i
             if (p.gelu) v = act4_any(v, p.gelu);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
+                if (p.half_scale != 0.f) v = v * p.half_scale;
                 ovf_see4<T>(ovf_mx, v);
                 v4 h;
                 h[0] = HFROM(v[0]); h[1] = HFROM(v[1]); h[2] = HFROM(v[2]); h[3] = HFROM(v[3]);
@@ -1199,6 +1201,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                                 st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1, p.nt);
                             }
                             if (p.out_half) {
+                                if (p.half_scale != 0.f) { v0 = v0 * p.half_scale; v1 = v1 * p.half_scale; }      // (after the fp32 output; stats_out is refused with it)
                                 ovf_see4<T>(ovf_mx, v0); ovf_see4<T>(ovf_mx, v1);
                                 v8 h;
 #pragma unroll
@@ -1425,6 +1428,7 @@ static bool skinny_ok(const avx::GemmArgs& a) {
     if (!(a.K == 32 || a.K == 64 || a.K == 96 || a.K == 128 || a.K == 160 || a.K == 256) ||
         !(a.N == 32 || a.N == 64 || a.N == 96 || a.N == 128 || a.N == 160 || a.N == 256) || a.N * a.K > 32768) return false;
     if (!a.out_half || a.out_f32 || a.resid || a.row_zero || a.ln_rows || a.lnr_y || a.stats_out || a.pool_part) return false;
+    if (a.half_scale != 0.f && a.half_scale != 1.f) return false;
     if (a.lda % 8 || a.ldw % 8 || a.ldh % 8 || (a.resid_half && a.ldrh % 8) || (a.out_raw && a.ldraw % 4) || (a.n_store > 0 && a.n_store % 16)) return false;
     return true;
 }
@@ -1503,7 +1507,8 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
         if (const char* fg = getenv("AVEX_AMD_GEMM_GRID")) { const int g = atoi(fg); if (g >= 8) grid = (g / 8) * 8; }   // tests: force many tiles per workgroup
         const char* fgen = getenv("AVEX_AMD_GEMM_GENERIC");
         const bool force_generic = fgen && atoi(fgen) != 0;     // tests: cross-check of the fast epilogues
-        const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.pool_part && !a.resid && !a.row_zero && !force_generic;
+        const bool scaled = a.half_scale != 0.f && a.half_scale != 1.f;      // the fast epilogues do not know GemmArgs::half_scale
+        const bool plain_out = a.out_half && a.bias && !a.out_f32 && !a.out_raw && !a.pool_part && !a.resid && !a.row_zero && !force_generic && !scaled;
         const bool fast_half = plain_out && !a.resid_half && !a.lnr_y && !a.stats_out && (a.gelu <= 2 || a.gelu == 6);      // the fast epilogue knows GELU and SiLU only
         const bool fast_resid = plain_out && (a.resid_half || a.lnr_y) && !a.gelu && !a.ln_rows;
         if (fast_half) {
@@ -1578,6 +1583,8 @@ int gemm(const GemmArgs& a, int dtype, hipStream_t s) {
                 "gemm: N=%d must be a multiple of %d (64 columns: the skinny streaming kernel only, >= 32768 rows)", a.N, BN);
     AVX_REQUIRE(a.K % BK == 0 || (a.K % 32 == 0 && a.variant == 7), "gemm: K=%d must be a multiple of %d (of 32 with the skinny kernel, variant 7)", a.K, BK);
     AVX_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
+    AVX_REQUIRE(a.half_scale == 0.f || a.half_scale == 1.f || (a.out_half && !a.stats_out && !a.post_ln_w && !a.pool_part && a.variant != 7 && a.half_scale > 0.f),
+                "gemm: half_scale goes with a plain half output (no row statistics, folded post-LayerNorm, pooled tap or skinny kernel)");
     AVX_REQUIRE(a.out_f32 || a.out_half || a.out_raw || (a.post_ln_w && (a.post_ln_out_f32 || a.post_ln_out_half)), "gemm: no output buffer");
     AVX_REQUIRE((!a.out_f32 || a.ldo % 4 == 0) && (!a.out_half || a.ldh % 4 == 0) &&
                     (!a.out_raw || a.ldraw % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&

@@ -71,6 +71,20 @@ struct HandleBase {
         AVX_HIP_CHECK(hipMemcpyAsync(h_ovf, d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
         return AVEXHIP_OK;
     }
+    // After the weights are packed and before any forward: the alarm counter holds what the UPLOAD clipped.  An f16 handle whose weights do
+    // not fit the f16 range would compute with saturated weights, silently (the alarm of a forward only sees activations): refuse it.
+    int weights_fit() {
+        if (!d_ovf) return AVEXHIP_OK;
+        unsigned int n = 0;
+        AVX_HIP_CHECK(hipDeviceSynchronize());
+        AVX_HIP_CHECK(hipMemcpy(&n, d_ovf, sizeof(n), hipMemcpyDeviceToHost));
+        if (n != 0) {
+            avexhip_set_error("%s: the checkpoint's weights do not fit the f16 range (+-65504): %u lane(s) clipped a value while packing them (a folded LayerNorm gain "
+                              "or hidden_shift counts).  Use operand_dtype bf16 (fp32's exponent range).", who, n);
+            return AVEXHIP_ERR_INVALID;
+        }
+        return AVEXHIP_OK;
+    }
     virtual ~HandleBase() {
         for (void* p : allocs) (void)hipFree(p);
         if (d_ovf) (void)hipFree(d_ovf);
@@ -186,7 +200,7 @@ inline int upload_half(HandleBase* h, const float* host_or_dev, int64_t numel, v
         avexhip_set_error("%s: copy of '%s' failed: %s", h->who, what, hipGetErrorString(e));
         rc = AVEXHIP_ERR_HIP;
     } else {
-        rc = avx::cast_to_half(tmp, dst, numel, h->dtype, nullptr);
+        rc = avx::cast_to_half(tmp, dst, numel, h->dtype, nullptr, h->d_ovf);      // (weights_fit below reads the counter when the handle is complete)
         if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) {
             avexhip_set_error("%s: cast of '%s' failed", h->who, what);
             rc = AVEXHIP_ERR_HIP;
@@ -249,7 +263,7 @@ inline int fold_ln(HandleBase* h, const std::vector<float>& W, const std::vector
         avexhip_set_error("%s: upload of folded weights failed", h->who);
         rc = AVEXHIP_ERR_HIP;
     }
-    if (rc == AVEXHIP_OK) rc = avx::cast_to_half(tmp, wd, (int64_t)N * K, h->dtype, nullptr);
+    if (rc == AVEXHIP_OK) rc = avx::cast_to_half(tmp, wd, (int64_t)N * K, h->dtype, nullptr, h->d_ovf);
     if (rc == AVEXHIP_OK) rc = avx::row_sum_half(wd, N, K, sd, h->dtype, nullptr);
     if (rc == AVEXHIP_OK && hipDeviceSynchronize() != hipSuccess) { avexhip_set_error("%s: folding failed", h->who); rc = AVEXHIP_ERR_HIP; }
     (void)hipFree(tmp);
@@ -302,6 +316,8 @@ struct CoreCfg {
                                   // clip's result never depends on the batch it came in)
     int act = 1;                  // GemmArgs::gelu code of the FFN activation (0 none, 1 erf GELU, 2 SiLU, 3 ReLU, 4 tanh GELU, 5 tanh)
     bool glu = false;             // fc1 is the reference's GLU_Linear(E, F, "swish"): one Linear to 2F, then value * swish(gate) (backbone.py:296-297)
+    int hidden_shift = 0;         // > 0: fc1's hidden activations are stored x 2^-shift and fc2's weights packed x 2^shift (exact in the fp32 accumulation):
+                                  // the f16 range ladder's rung for hidden activations beyond 65504 (the reference is fp32, backbone.py:365-370)
     bool pre_ln = false;          // pre-LN blocks (backbone.py:328-348): x += attn(LN1 x); x += ffn(LN2 x); `final_ln` after the stack (:146-147)
     bool batch_invariant = false; // residual_dtype bit 1 (AVEXHIP_RESIDUAL_BATCH_INVARIANT): a clip's outputs must not depend on the batch it arrives in --
                                   // fold at every size, no split-K, no LayerNorm inside a split-K epilogue, one final LayerNorm + pool path
@@ -370,7 +386,23 @@ inline int build_layer(HandleBase* h, const Table& tb, const LayerNames& nm, con
     const int F1 = c.glu ? 2 * F : F;      // GLU_Linear keeps its Linear(E, 2F) under ".linear"
     RC(dev_half(h, tb, fmt_name(nm.fc1, i, c.glu ? ".linear.weight" : ".weight"), (int64_t)F1 * E, &ly.w_fc1));
     RC(dev_f32(h, tb, fmt_name(nm.fc1, i, c.glu ? ".linear.bias" : ".bias"), F1, &ly.b_fc1));
-    RC(dev_half(h, tb, fmt_name(nm.fc2, i, ".weight"), (int64_t)E * F, &ly.w_fc2));
+    if (c.hidden_shift > 0) {
+        // fc2's weights x 2^shift: the power of two is exact in fp32 and in the operand type unless a weight leaves its range
+        std::vector<float> W2;
+        RC(host_f32(h, tb, fmt_name(nm.fc2, i, ".weight"), (int64_t)E * F, W2));
+        const float sc = ldexpf(1.0f, c.hidden_shift);
+        float mx = 0.f;
+        for (float& v : W2) { v *= sc; mx = fabsf(v) > mx ? fabsf(v) : mx; }
+        if (h->dtype == AVEXHIP_F16 && !(mx <= 65504.0f)) {
+            avexhip_set_error("%s: hidden_shift %d takes layer %d's fc2 weights out of the f16 range (max |w| 2^shift = %g)", h->who, c.hidden_shift, i, (double)mx);
+            return AVEXHIP_ERR_INVALID;
+        }
+        AVX_HIP_CHECK(hipMalloc(&ly.w_fc2, 2 * (size_t)E * F));
+        h->allocs.push_back(ly.w_fc2);
+        RC(upload_half(h, W2.data(), (int64_t)E * F, ly.w_fc2, "fc2.weight x 2^shift"));
+    } else {
+        RC(dev_half(h, tb, fmt_name(nm.fc2, i, ".weight"), (int64_t)E * F, &ly.w_fc2));
+    }
     RC(dev_f32(h, tb, fmt_name(nm.fc2, i, ".bias"), E, &ly.b_fc2));
     RC(dev_f32(h, tb, fmt_name(nm.ln2, i, ".weight"), E, &ly.ln2_w));
     RC(dev_f32(h, tb, fmt_name(nm.ln2, i, ".bias"), E, &ly.ln2_b));
@@ -497,6 +529,7 @@ inline int ffn_hidden(HandleBase* h, const CoreCfg& c, const CoreWs& w, avx::Gem
     const double flops = 2.0 * (double)M * (c.glu ? 2 * c.F : c.F) * c.E;
     int rc;
     if (c.glu) { g.N = 2 * c.F; g.gelu = 0; g.out_half = w.hh2; g.ldh = 2 * c.F; }
+    if (c.hidden_shift > 0) g.half_scale = ldexpf(1.0f, -c.hidden_shift);      // (refused with GLU when the handle is created)
     prof.begin("gemm.fc1", flops);
     pin_kernel(c, g);
     rc = avx::gemm(g, h->dtype, cs);

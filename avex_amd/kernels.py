@@ -629,7 +629,7 @@ def residual_code(residual, batch_invariant: bool = False) -> int:
 
 
 def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_clips: int = 0,
-                      residual="half", batch_invariant: bool = False) -> BeatsConfig:
+                      residual="half", batch_invariant: bool = False, hidden_shift: int = 0) -> BeatsConfig:
     act = str(cfg.get("activation_fn", "gelu"))
     if act not in _capi.FFN_CODES:
         raise RuntimeError(f"--activation-fn {act} not supported")      # the reference's own error (modules.py:237)
@@ -654,6 +654,7 @@ def make_beats_config(cfg: Mapping[str, object], operand_dtype="f16", max_chunk_
     c.operand_dtype = dtype_code(operand_dtype)
     c.max_chunk_clips = int(max_chunk_clips)
     c.residual_dtype = residual_code(residual, batch_invariant)
+    c.hidden_shift = int(hidden_shift)
     return c
 
 
@@ -744,15 +745,17 @@ class BeatsGraph:
 
     def replay(self) -> "BeatsGraph":
         """Launch the recorded forward.  The encoder's ``on_overflow`` policy applies to replays as to eager forwards -- ``"warn"`` (one call
-        late, no synchronisation) and ``"raise"`` (synchronises) -- except ``"retry"``: a graph has no bf16 twin to fall back to, so a clipped
-        f16 value raises there as well."""
+        late, no synchronisation) and ``"raise"`` (synchronises) -- except ``"retry"``: a graph replays the one mode it recorded and cannot
+        climb the retry ladder, so a clipped f16 value raises there as well, with the eager path's message."""
         check(lib().avexhip_beats_graph_launch(self._g, _stream()), "beats_graph_launch")
         enc = self._enc
         if enc.on_overflow != "ignore":
             new = enc._new_overflow(sync=enc.on_overflow in ("raise", "retry"))
             if new:
                 msg = (f"avex_amd: {new} lane(s) clipped a value to the f16 range (+-65504) inside a replayed BEATs forward: the result is not the "
-                       "reference's.  Use operand_dtype='bf16' with residual='f32' (fp32's exponent range); on_overflow='retry' is not available for graphs.")
+                       "reference's.  Use residual='f32' (out-of-range sums), hidden_shift=8 (out-of-range hidden activations), "
+                       "operand_dtype='bf16' with residual='f32' (fp32's exponent range); on_overflow='retry' is not available for graphs "
+                       "(a graph replays one recorded mode): run the batch through forward().")
                 if enc.on_overflow in ("raise", "retry"):
                     raise AvexHipError(msg)
                 warnings.warn(msg, RuntimeWarning, stacklevel=2)
@@ -775,24 +778,38 @@ class BeatsEncoder:
     """Owns an ``avexhip_beats`` handle built from an fp32 state dict (torch tensors or numpy arrays,
     host or device).  ``forward`` runs the whole path wav -> features / taps / pooled on the current stream."""
 
+    # The rungs on_overflow="retry" climbs when the f16 range alarm fires, in order.  f16 operands keep the default mode's accuracy (3e-4 of
+    # the reference, inside north_star's 1e-3); only the last rung gives that up (bf16 operands: 2e-3):
+    #   1. f16 operands + fp32 residual stream: the pre-LayerNorm sums never pass through f16 (an out-of-range SUM is the common case);
+    #   2./3. the same + hidden activations stored x 2^-8 / 2^-14 with the inverse folded into fc2's weights (exact powers of two:
+    #      ``hidden_shift``, avexhip_beats_config): fc1 outputs up to 1.6e7 / 1e9 fit;
+    #   4. bf16 operands + fp32 residual stream: fp32's exponent range everywhere.
+    RETRY_LADDER = (("f16 operands, fp32 residual stream", dict(operand_dtype="f16", residual="f32", hidden_shift=0)),
+                    ("f16 operands, fp32 residual stream, hidden activations x 2^-8", dict(operand_dtype="f16", residual="f32", hidden_shift=8)),
+                    ("f16 operands, fp32 residual stream, hidden activations x 2^-14", dict(operand_dtype="f16", residual="f32", hidden_shift=14)),
+                    ("bf16 operands, fp32 residual stream", dict(operand_dtype="bf16", residual="f32", hidden_shift=0)))
+
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype="f16",
-                 max_chunk_clips: int = 0, residual="half", on_overflow: Optional[str] = None, batch_invariant: bool = False) -> None:
+                 max_chunk_clips: int = 0, residual="half", on_overflow: Optional[str] = None, batch_invariant: bool = False,
+                 hidden_shift: int = 0) -> None:
         """``on_overflow``: what to do when an f16 conversion inside the forward clipped a value to +-65504 (the handle's sticky range
         alarm, ``avexhip_beats_overflow_count``; the reference computes in fp32 and has no such limit, backbone.py:350-375):
         ``"warn"`` (default; checked without synchronising, so the warning may come one call late), ``"raise"``, ``"retry"`` (the
-        batch is run again with bf16 operands and an fp32 residual stream -- fp32's exponent range, 2e-3 instead of 3e-4 of the
-        reference -- and that result is returned; both synchronise after every forward) or ``"ignore"``.  Environment default:
-        ``AVEX_AMD_ON_OVERFLOW``."""
+        batch is run again up ``RETRY_LADDER`` until a rung's own alarm stays quiet, and that result is returned; ``last_rung`` names
+        the rung that served the last forward, ``None`` = the handle itself; both synchronise after every forward) or ``"ignore"``.
+        Environment default: ``AVEX_AMD_ON_OVERFLOW``.  ``hidden_shift``: see ``RETRY_LADDER`` (0 = off)."""
         _capi.require_gpu()
         self.cfg = dict(cfg)
         self.on_overflow = (on_overflow or os.environ.get("AVEX_AMD_ON_OVERFLOW") or "warn").lower()
         if self.on_overflow not in ("warn", "raise", "retry", "ignore"):
             raise ValueError(f"on_overflow must be 'warn', 'raise', 'retry' or 'ignore', got {self.on_overflow!r}")
         self._overflow_seen = 0
-        self._fallback: Optional["BeatsEncoder"] = None
+        self.last_rung: Optional[str] = None
+        self._rungs: Dict[str, Optional["BeatsEncoder"]] = {}      # retry ladder, built on first need (each is a second copy of the weights on the device)
+        self._mode = (dtype_code(operand_dtype), residual_code(residual) & 1, int(hidden_shift))
         self._fallback_args = (dict(cfg), state, max_chunk_clips) if self.on_overflow == "retry" and dtype_code(operand_dtype) == _capi.F16 else None
         self.batch_invariant = bool(batch_invariant)      # a clip's outputs do not depend on the batch it arrives in (bit for bit); see residual_code
-        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual, self.batch_invariant)
+        self.ccfg = make_beats_config(cfg, operand_dtype, max_chunk_clips, residual, self.batch_invariant, hidden_shift)
         self.E = int(cfg["encoder_embed_dim"])
         self.L = int(cfg["encoder_layers"])
         arr, n, keep = tensor_table(state)
@@ -801,6 +818,30 @@ class BeatsEncoder:
         if not self._h:
             raise AvexHipError(f"beats_create failed: {_capi.last_error()}")
         self._ws: Optional[torch.Tensor] = None
+
+    def _retry(self, msg: str, wav, kw) -> Dict[str, object]:
+        """Climb ``RETRY_LADDER``: the first rung wider than this handle whose own alarm stays quiet serves the batch."""
+        fcfg, fstate, fchunk = self._fallback_args
+        for name, mode in self.RETRY_LADDER:
+            key = (dtype_code(mode["operand_dtype"]), residual_code(mode["residual"]) & 1, mode["hidden_shift"])
+            # skip rungs that are not wider than the handle: the same mode, or a narrower residual stream / shift
+            if key == self._mode or (key[0] == self._mode[0] and (key[1] > self._mode[1] or key[2] < self._mode[2])):
+                continue
+            if name not in self._rungs:
+                try:
+                    self._rungs[name] = BeatsEncoder(fcfg, fstate, max_chunk_clips=fchunk, on_overflow="ignore", batch_invariant=self.batch_invariant, **mode)
+                except AvexHipError as e:      # e.g. a shift that takes fc2's weights out of range, or a GLU feed-forward
+                    logger.warning("avex_amd: retry rung '%s' is not available for this checkpoint: %s", name, e)
+                    self._rungs[name] = None
+            enc = self._rungs[name]
+            if enc is None:
+                continue
+            out = enc.forward(wav, **kw)
+            if enc._new_overflow(sync=True) == 0:
+                logger.warning(msg + f"  Re-ran the batch with {name}.")
+                self.last_rung = name
+                return out
+        raise AvexHipError(msg + "  No rung of the retry ladder could hold the values.")      # (unreachable for f16 handles: bf16 cannot clip)
 
     def num_tokens(self, T: int) -> int:
         return int(lib().avexhip_beats_num_tokens(self._h, T))
@@ -851,20 +892,18 @@ class BeatsEncoder:
         check(lib().avexhip_beats_forward(self._h, _ptr(wav), B, T, wav.stride(0), _ptr(pad), mask, ptrs,
                                           code, _ptr(feats), _ptr(pooled), _ptr(ws), ws.numel(), _stream()),
               "beats_forward")
+        self.last_rung = None
         if self.on_overflow != "ignore":
             new = self._new_overflow(sync=self.on_overflow in ("raise", "retry"))
             if new:
                 msg = (f"avex_amd: {new} lane(s) clipped a value to the f16 range (+-65504) inside the BEATs forward: the result is not the "
-                       "reference's.  Use operand_dtype='bf16' with residual='f32' (fp32's exponent range), or on_overflow='retry'.")
+                       "reference's.  Use residual='f32' (out-of-range sums), hidden_shift=8 (out-of-range hidden activations), "
+                       "operand_dtype='bf16' with residual='f32' (fp32's exponent range), or on_overflow='retry' (tries them in that order).")
                 if self.on_overflow == "raise":
                     raise AvexHipError(msg)
                 if self.on_overflow == "retry" and self._fallback_args is not None:
-                    if self._fallback is None:
-                        fcfg, fstate, fchunk = self._fallback_args
-                        self._fallback = BeatsEncoder(fcfg, fstate, operand_dtype="bf16", max_chunk_clips=fchunk, residual="f32", on_overflow="ignore", batch_invariant=self.batch_invariant)
-                    logger.warning(msg + "  Re-running the batch with bf16 operands and an fp32 residual stream.")
-                    return self._fallback.forward(wav, hook_layers=hook_layers, hook_pooled=hook_pooled, want_features=want_features,
-                                                  want_pooled=want_pooled, frame_pad=frame_pad)
+                    return self._retry(msg, wav, dict(hook_layers=hook_layers, hook_pooled=hook_pooled, want_features=want_features,
+                                                      want_pooled=want_pooled, frame_pad=frame_pad))
                 warnings.warn(msg, RuntimeWarning, stacklevel=2)
         return {"features": feats, "pooled": pooled, "hooks": hooks, "tokens": Tt}
 
@@ -906,9 +945,10 @@ class BeatsEncoder:
         return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
 
     def close(self) -> None:
-        if getattr(self, "_fallback", None) is not None:
-            self._fallback.close()
-            self._fallback = None
+        for enc in list(getattr(self, "_rungs", {}).values()):
+            if enc is not None:
+                enc.close()
+        self._rungs = {}
         if getattr(self, "_h", None):
             lib().avexhip_beats_destroy(self._h)
             self._h = None

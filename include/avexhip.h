@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 7
+#define AVEXHIP_ABI_VERSION 8
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -386,6 +386,13 @@ typedef struct {
                                         (backbone.py:328-348, 146-147); excludes deep_norm (beats.py:275) */
     int32_t activation_fn;           /* AVEXHIP_FFN_* below (modules.py:203-237) */
     int32_t conv_bias;               /* 1: the patch embedding has a bias ("patch_embedding.bias", beats.py:263-269) */
+    /* ABI 8: a rung of the f16 range ladder (see "Range alarm" below).  k > 0: every layer's fc1 stores its hidden activations
+       x 2^-k and fc2's weights are packed x 2^k -- both exact powers of two, so the fp32 accumulation of fc2 sees the products
+       it would have seen; hidden activations up to 65504 x 2^k fit the f16 operand (the reference computes them in fp32,
+       backbone.py:365-370).  The handle then runs the LayerNorm kernels and the generic GEMM epilogues (slower; for the
+       retry of a batch whose default forward raised the alarm).  0 = off.  Refused with the GLU feed-forward and when a
+       fc2 weight x 2^k leaves the f16 range. */
+    int32_t hidden_shift;
 } avexhip_beats_config;
 
 #define AVEXHIP_RESIDUAL_BATCH_INVARIANT 2   /* OR into residual_dtype */

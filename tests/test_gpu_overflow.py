@@ -64,7 +64,8 @@ def test_gemm_range_alarm_counts_only_what_leaves_the_f16_range(built_lib, M):
 def _heavy_checkpoint(kind: str):
     """Synthetic BEATs-base weights with outliers: LayerNorm gains x50 on a few channels, input at 8x full scale, and
     kind "residual": three fc2 rows x 1e6 in layer 5 -> |x * alpha + fc2(h)| reaches ~8e4 on a few (token, channel) pairs;
-    kind "hidden":   two fc1 rows x 3e6 in layer 7 -> the GELU hidden activations themselves pass 65504."""
+    kind "hidden":   two fc1 rows x 3e5 in layer 7 -> the GELU hidden activations themselves pass 65504 (~2.5e5) while the WEIGHTS stay inside
+                     the f16 range (x 3e6 they do not: "weights" below, which an f16 handle refuses when it is created)."""
     sd = dict(synth.beats_state_dict(CFG, seed=0))
     k = "backbone.encoder.layers.3.final_layer_norm.weight"
     w = sd[k].copy(); w[[5, 77, 300, 511]] *= 50.0; sd[k] = w
@@ -75,7 +76,7 @@ def _heavy_checkpoint(kind: str):
         w = sd[k].copy(); w[[9, 130, 640]] *= 1.0e6; sd[k] = w
     else:
         k = "backbone.encoder.layers.7.fc1.weight"
-        w = sd[k].copy(); w[[21, 2000]] *= 3.0e6; sd[k] = w
+        w = sd[k].copy(); w[[21, 2000]] *= (3.0e6 if kind == "weights" else 3.0e5); sd[k] = w
     return sd
 
 
@@ -166,14 +167,38 @@ def test_overflow_policies(built_lib, clips):
     with pytest.raises(AvexHipError, match="f16 range"):
         enc.forward(x, want_features=False, want_pooled=True)
     enc.close()
-    # retry: the result IS the wide mode's result
+    # retry climbs the ladder (kernels.BeatsEncoder.RETRY_LADDER) and stops at the first rung whose own alarm stays quiet.  The "residual"
+    # outliers are out-of-range SUMS: the first rung (f16 operands, fp32 residual stream) holds them, the result IS that mode's result and
+    # it is inside north_star's 1e-3 of the CPU oracle (the reference computes in fp32 and has no range limit, backbone.py:350-375)
+    f_ref, _ = O.beats_forward(clips, sd, CFG)
     enc = K.BeatsEncoder(CFG, sd, on_overflow="retry")
     got = enc.forward(x, want_features=False, want_pooled=True)["pooled"]
+    rung = enc.last_rung
     enc.close()
-    wide = K.BeatsEncoder(CFG, sd, operand_dtype="bf16", residual="f32", on_overflow="ignore")
+    assert rung == "f16 operands, fp32 residual stream"
+    wide = K.BeatsEncoder(CFG, sd, operand_dtype="f16", residual="f32", on_overflow="ignore")
     want = wide.forward(x, want_features=False, want_pooled=True)["pooled"]
     wide.close()
     assert torch.equal(got, want)
+    e = rel_l2(got.cpu().numpy(), f_ref.mean(1))
+    print(f"retry, residual outliers: served by '{rung}', pooled rel-L2 vs the oracle {e:.2e}")
+    assert e < 1e-3
+    # the "hidden" outliers leave the f16 range in fc1's own output: the fp32 residual stream does not help, the next rung stores the hidden
+    # activations x 2^-8 and folds 2^8 into fc2's weights -- still f16 operands, still inside 1e-3
+    sd_h = _heavy_checkpoint("hidden")
+    f_ref_h, _ = O.beats_forward(clips, sd_h, CFG)
+    enc = K.BeatsEncoder(CFG, sd_h, on_overflow="retry")
+    got = enc.forward(x, want_features=False, want_pooled=True)["pooled"]
+    rung = enc.last_rung
+    # a batch that needs no retry afterwards is served by the handle itself again
+    clean_x = torch.from_numpy(synth.noise_clips(2, 32000, seed=3) * 1e-3).cuda()
+    enc.forward(clean_x, want_features=False, want_pooled=True)
+    rung_after = enc.last_rung
+    enc.close()
+    e = rel_l2(got.cpu().numpy(), f_ref_h.mean(1))
+    print(f"retry, hidden outliers: served by '{rung}', pooled rel-L2 vs the oracle {e:.2e}")
+    assert rung == "f16 operands, fp32 residual stream, hidden activations x 2^-8" and e < 1e-3
+    assert rung_after is None or "hidden" in str(rung_after)      # (the tiny input may still clip in the outlier layer; what matters is that it is re-decided per batch)
     # a recorded forward obeys the policy too: the warm-up forward of the capture is the first to see the clipping; a replay raises
     # ("retry" has no graph to fall back to and raises as well)
     for policy in ("raise", "retry"):
@@ -190,6 +215,56 @@ def test_overflow_policies(built_lib, clips):
     enc.forward(torch.from_numpy(synth.noise_clips(2, 32000, seed=3)).cuda(), want_features=False, want_pooled=True)
     assert enc.overflow_events() == 0
     enc.close()
+
+
+@pytest.mark.parametrize("shift", [8, 14])
+@pytest.mark.parametrize("batch", [2, 12])        # 128-tile kernels (split-K fc2) / the 256-tile streaming kernel's generic epilogue
+def test_hidden_shift_is_exact_scaling_on_a_clean_checkpoint(built_lib, shift, batch):
+    """avexhip_beats_config::hidden_shift: hidden activations x 2^-k, fc2 weights x 2^k.  On ordinary activations the mode must stay at the
+    default mode's distance from the CPU oracle (powers of two are exact; only values pushed into the f16 subnormals lose bits)."""
+    from avex_amd import kernels as K
+    sd = synth.beats_state_dict(CFG, seed=0)
+    x = synth.noise_clips(batch, 32000, seed=5)
+    f_ref, _ = O.beats_forward(x[:2], sd, CFG)
+    outs = {}
+    for k in (0, shift):
+        enc = K.BeatsEncoder(CFG, sd, operand_dtype="f16", residual="f32", hidden_shift=k, on_overflow="raise")
+        r = enc.forward(torch.from_numpy(x).cuda(), want_features=True, want_pooled=True)
+        outs[k] = (r["features"].cpu().numpy(), r["pooled"].cpu().numpy())
+        enc.close()
+    e0, ek = rel_l2(outs[0][1][:2], f_ref.mean(1)), rel_l2(outs[shift][1][:2], f_ref.mean(1))
+    print(f"hidden_shift {shift}, batch {batch}: pooled rel-L2 vs the oracle {ek:.2e} (shift 0: {e0:.2e}); frame-level {rel_l2(outs[shift][0][:2], f_ref):.2e}")
+    assert ek < 1e-3 and ek < 2.0 * e0 + 1e-4
+    assert rel_l2(outs[shift][0], outs[0][0]) < 1e-3
+
+
+def test_weights_outside_the_f16_range_are_refused(built_lib, clips):
+    """A checkpoint whose weights do not fit f16 would run with saturated weights and no forward's alarm would say so: the handle is not
+    created (bf16 operands have fp32's exponent range and take it; the reference keeps weights in fp32, beats.py:206-262)."""
+    from avex_amd import kernels as K
+    from avex_amd._capi import AvexHipError
+    sd = _heavy_checkpoint("weights")
+    assert np.abs(sd["backbone.encoder.layers.7.fc1.weight"]).max() > 65504.0
+    with pytest.raises(AvexHipError, match="do not fit the f16 range"):
+        K.BeatsEncoder(CFG, sd, operand_dtype="f16")
+    f_ref, _ = O.beats_forward(clips, sd, CFG)
+    enc = K.BeatsEncoder(CFG, sd, operand_dtype="bf16", residual="f32")
+    p = enc.forward(torch.from_numpy(clips).cuda(), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
+    enc.close()
+    assert rel_l2(p, f_ref.mean(1)) < 8e-3
+
+
+def test_hidden_shift_is_refused_where_it_cannot_hold(built_lib):
+    from avex_amd import kernels as K
+    from avex_amd._capi import AvexHipError
+    sd = dict(synth.beats_state_dict(CFG, seed=0))
+    k = "backbone.encoder.layers.2.fc2.weight"
+    w = sd[k].copy(); w[3, 7] = 400.0; sd[k] = w              # x 2^8 = 102 400 > 65 504
+    with pytest.raises(AvexHipError, match="hidden_shift"):
+        K.BeatsEncoder(CFG, sd, operand_dtype="f16", residual="f32", hidden_shift=8)
+    K.BeatsEncoder(CFG, sd, operand_dtype="bf16", residual="f32", hidden_shift=8).close()      # bf16 has fp32's exponent range
+    with pytest.raises(AvexHipError, match="hidden_shift"):
+        K.BeatsEncoder(CFG, synth.beats_state_dict(CFG, seed=0), hidden_shift=40)
 
 
 def test_model_class_exposes_the_alarm(built_lib, clips):
