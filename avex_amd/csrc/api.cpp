@@ -355,7 +355,16 @@ int build(avexhip_beats* h, const avexhip_tensor* tensors, int n) {
         AVX_HIP_CHECK(hipMalloc((void**)&h->d_bucket_lut, sizeof(int) * lut.size()));
         AVX_HIP_CHECK(hipMemcpy(h->d_bucket_lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice));
         const char* am = getenv("AVEX_AMD_BIAS_ARENA_MB");      // 0: no arena, every forward builds its table in the workspace
-        h->bias_arena_bytes = (size_t)(am ? atoi(am) : 16) << 20;
+        long arena_mb = 16;
+        if (am) {
+            char* end = nullptr;
+            arena_mb = strtol(am, &end, 10);
+            if (end == am || *end != '\0' || arena_mb < 0 || arena_mb > 4096) {
+                avexhip_set_error("beats_create: AVEX_AMD_BIAS_ARENA_MB must be an integer in 0..4096 (MiB), got '%s'", am);
+                return AVEXHIP_ERR_INVALID;
+            }
+        }
+        h->bias_arena_bytes = (size_t)arena_mb << 20;
         if (h->bias_arena_bytes) AVX_HIP_CHECK(hipMalloc((void**)&h->bias_arena, h->bias_arena_bytes));
     }
 #undef RC

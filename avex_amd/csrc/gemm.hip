@@ -40,7 +40,7 @@
 #if GEMM_HW_SAT
 #define HFROM(x) Half<T>::from_hw(x)
 #else
-#define HFROM(x) HFROM(x)
+#define HFROM(x) Half<T>::from(x)      // the software clamp (v_med3_f32 per element): the A side of profiles/r04u_fp16_ovfl.txt
 #endif
 
 namespace { template <int N> struct a_ic { static constexpr int value = N; }; }

@@ -15,6 +15,14 @@ import torch
 import torch.distributed as dist
 
 
+_WORK_GROUP = None      # the group the gathers run on by default: every rank, long collective timeout (init_distributed)
+
+
+def work_group():
+    """The process group ``init_distributed`` made for the data path (``None`` = the default group: single process, or initialised elsewhere)."""
+    return _WORK_GROUP
+
+
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise from torchrun's environment; returns ``(rank, world_size, local_rank)``.
     A single-process run (no WORLD_SIZE) initialises nothing."""
@@ -22,18 +30,28 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # dmabuf IPC only on these hosts (RCCL across processes).  ROCr reads the flag when the runtime starts, so it goes in BEFORE the first
+        # call that initialises HIP in this process -- torch.cuda.is_available() below is one.  (A process that touched the GPU earlier must
+        # have it exported by its launcher: bench.py's launcher does.)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         import datetime
-        timeout = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "180")))      # a rank that never arrives fails the job instead of hanging it
+        # Two timeouts.  The rendezvous and the first barrier get a short one: a rank that never arrives fails the job instead of hanging it.
+        # The working group gets a long one (torch's own default is 10 minutes): its timeout applies to EVERY collective, and a rank may
+        # legitimately spend minutes between two gathers (a first-use build of the extension, a slow dataloader).
+        t_rdv = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "180")))
+        t_run = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_COLLECTIVE_TIMEOUT_S", "1800")))
         if backend == "nccl":
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank), timeout=timeout)
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank), timeout=t_rdv)
         else:
-            dist.init_process_group(backend=backend, timeout=timeout)
+            dist.init_process_group(backend=backend, timeout=t_rdv)
+        dist.barrier()                                       # everyone is here (under the short timeout)
+        global _WORK_GROUP
+        _WORK_GROUP = dist.new_group(ranks=list(range(world)), timeout=t_run, backend=backend)
     return rank, world, local_rank
 
 
@@ -46,6 +64,7 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Gather ``[n_local, D]`` shards (possibly ragged) into ``[n_total, D]`` in rank order."""
+    group = group if group is not None else _WORK_GROUP
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
@@ -78,7 +97,7 @@ class PipelinedGather:
     """
 
     def __init__(self, group=None, force: bool = False, measure: bool = False) -> None:
-        self.group = group
+        self.group = group if group is not None else _WORK_GROUP
         # measure: time what the consumer actually WAITED for each gather (``exposed_ms``): on a GPU two events on the compute stream
         # around the stream dependency (0 when the collective had finished under the next batch's kernels), on the CPU the blocking wait
         self.measure = bool(measure)

@@ -41,22 +41,28 @@ def _stage(batch: Dict[str, Any], device: torch.device, stream: Optional["torch.
     return w, m, ev
 
 
-def _check_same_batches(batch: Dict[str, Any], tdist: Any, group: Any, device: torch.device) -> None:
-    """Sharded extraction assumes every rank iterates the same batches: compare the first batch's signature across ranks."""
-    wav = batch["raw_wav"]
-    lab = batch.get("label")
-    sig = [float(wav.shape[0]), float(wav.shape[-1]), float(wav.detach().double().abs().sum().item())]
-    if torch.is_tensor(lab):
-        sig.append(float(lab.detach().double().sum().item()))
+def _check_same_batches(batch: Optional[Dict[str, Any]], n_batches: Optional[int], tdist: Any, group: Any, device: torch.device) -> None:
+    """Sharded extraction assumes every rank iterates the same batches.  Every rank calls this UNCONDITIONALLY before it looks at its first
+    batch -- a rank whose dataloader is empty or shorter would otherwise leave the others in a collective it never joins -- with a signature
+    of what it is about to iterate: whether it has a first batch, ``len(dataloader)`` when the loader has one, and the first batch's clip
+    count, length and checksums of audio and labels.  (A sampler that diverges only AFTER the first batch at equal length is not detected:
+    the check is a guard against the common mis-configuration, a per-rank sampler, not a proof.)"""
+    sig = [1.0 if batch is not None else 0.0, float(n_batches) if n_batches is not None else -1.0, 0.0, 0.0, 0.0, 0.0]
+    if batch is not None:
+        wav = batch["raw_wav"]
+        lab = batch.get("label")
+        sig[2:5] = [float(wav.shape[0]), float(wav.shape[-1]), float(wav.detach().double().abs().sum().item())]
+        if torch.is_tensor(lab):
+            sig[5] = float(lab.detach().double().sum().item())
     backend = tdist.get_backend(group)
     t = torch.tensor(sig, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     lo, hi = t.clone(), t.clone()
     tdist.all_reduce(lo, op=tdist.ReduceOp.MIN, group=group)
     tdist.all_reduce(hi, op=tdist.ReduceOp.MAX, group=group)
     if not torch.equal(lo, hi):
-        raise RuntimeError("extract_embeddings_in_memory(sharded=True): the ranks do not iterate the same batches (first batch differs: "
-                           f"min {lo.tolist()} max {hi.tolist()}).  Sharded extraction splits every batch over the ranks; with a "
-                           "DistributedSampler (a different batch per rank) call it with sharded=False.")
+        raise RuntimeError("extract_embeddings_in_memory(sharded=True): the ranks do not iterate the same batches ([has a first batch, len(dataloader), "
+                           f"clips, samples, |audio| sum, label sum]: min {lo.tolist()} max {hi.tolist()}).  Sharded extraction splits every batch over "
+                           "the ranks; with a DistributedSampler (a different batch per rank) call it with sharded=False.")
 
 
 def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]], target_layers: List[Any],
@@ -73,7 +79,8 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
     reference's loop is single-device, run_evaluate.py:1053).  It is NOT the default: a multi-rank caller with a
     ``DistributedSampler`` -- the usual set-up -- hands every rank DIFFERENT batches, and sharding those would gather rows of unrelated
     clips beside the local labels without any visible failure.  The first batch's signature (clip count, samples, a checksum of the
-    audio and of the labels) is compared across ranks and a mismatch raises ``RuntimeError``.
+    audio and of the labels), whether there IS a first batch and ``len(dataloader)`` are compared across ranks before anything else and a
+    mismatch raises ``RuntimeError`` on every rank.
 
     ``batch_invariant`` (``True`` / ``False``; default: leave the model as it is): make the model's HIP handle give every clip the same
     bits whatever batch it arrives in -- the loop's last, partial batch then rounds exactly like the full ones (``kernels.residual_code``;
@@ -114,8 +121,12 @@ def extract_embeddings_in_memory(model: Any, dataloader: Iterable[Dict[str, Any]
             it = iter(dataloader)
             nxt = next(it, None)
             gathers: Dict[int, Any] = {}                        # position in the output list -> PipelinedGather
-            if sharded and nxt is not None:
-                _check_same_batches(nxt, tdist, group, device)
+            if sharded:
+                try:
+                    n_batches: Optional[int] = len(dataloader)      # type: ignore[arg-type]
+                except TypeError:
+                    n_batches = None
+                _check_same_batches(nxt, n_batches, tdist, group, device)
 
             def my_rows(b: Dict[str, Any]) -> Optional[Tuple[int, int]]:
                 return adist.shard_bounds(int(b["raw_wav"].shape[0]), rank, world) if sharded else None
