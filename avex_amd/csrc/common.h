@@ -22,8 +22,12 @@ template <> struct Half<_Float16> {
     typedef f16x8 v8;
     typedef f16x4 v4;
     static __device__ __forceinline__ _Float16 from(float x) {
-        // saturate instead of producing inf: activations are O(1..1e3), this only guards outliers
-        return (_Float16)__builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);
+        // saturate instead of producing inf: activations are O(1..1e3), this only guards outliers.  Compare + select, NOT fmin / fmax: those
+        // return their non-NaN operand, so a NaN came out as -65504 -- a poisoned clip (one NaN sample) got a FINITE embedding, found by
+        // tests/test_gpu_e2e.py::test_nan_input_stays_nan_and_stays_in_its_clip; the reference's fp32 path returns NaN for it.  A NaN fails
+        // both compares and passes through, like the hardware form below.
+        const float lo = x < -65504.0f ? -65504.0f : x;
+        return (_Float16)(lo > 65504.0f ? 65504.0f : lo);
     }
     static __device__ __forceinline__ _Float16 from_hw(float x) { return (_Float16)x; }      // saturates through MODE.FP16_OVFL (below)
 };

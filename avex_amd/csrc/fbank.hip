@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(avx::FbankDev fb, const floa
             const int f = f0 + fr;
             if (f >= out_frames) continue;
             float y;
-            if (f < frames) y = (logf(fmaxf(fr ? e1 : e0, fb.log_floor)) - fb.norm_mean) / fb.norm_div;
+            // (the floor as a compare + select, not fmaxf: fmaxf returns its non-NaN operand and would turn a NaN sample into the log floor -- a finite
+            //  embedding for a poisoned clip; torch.max(mel_energies, eps) in the reference's kaldi fbank propagates the NaN)
+            const float en = fr ? e1 : e0;
+            if (f < frames) y = (logf(en < fb.log_floor ? fb.log_floor : en) - fb.norm_mean) / fb.norm_div;
             else y = (0.f - fb.norm_mean) / fb.norm_div;      // zero-padded log-mel rows, normalised like the rest (audio_processor.py:121-135)
             if (out_f32) out_f32[((int64_t)b * out_frames + f) * nm + m] = y;
             if (out_patch) {

@@ -257,6 +257,17 @@ def other_configs(steps: int = 5):
         wav = torch.from_numpy(synth.noise_clips(B, n, seed=0)).cuda()      # the build's counter-based generator, as the C3 leg and the headline
         dt = timed(lambda: enc.forward(plan(wav), want_features=False, want_pooled=True)["pooled"])
         nbytes = effnet_algorithmic_bytes(synth.EFFNET_B0_STAGES, 128, 1 + n // 160, n)
+        counted = None      # HBM-side bytes per clip from the committed PMC passes of the same forward (scripts/pmc_effnet.sh), not measured in this run
+        try:
+            import glob
+            cf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_effnet_traffic.json")))
+            cj = json.load(open(cf[-1]))
+            counted = {"mb_per_clip": cj["counted_mb_per_clip"], "mb_per_clip_fetch_undoubled": cj["counted_mb_per_clip_fetch_undoubled"],
+                       "over_algorithmic": cj["counted_over_algorithmic"], "source": "profiles/" + os.path.basename(cf[-1]), "measured_in_this_run": False,
+                       "note": "FETCH_SIZE doubled (the gfx950 rule for wide coalesced reads: an upper bound for the narrower depthwise / squeeze reads) + WRITE_SIZE; "
+                               "below the algorithmic figure because the fused block fronts never write the 6 x expanded tensors"}
+        except Exception:  # noqa: BLE001
+            counted = None
         small = torch.from_numpy(synth.noise_clips(2, n, seed=int(gold["effnet.seed"][0]))).cuda()
         p = enc.forward(plan(small), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
         out["c5_effnet"] = {"workload": "EfficientNet-B0 (torchvision features stack, BatchNorm folded), batch 1024 x 10 s @ 16 kHz, wav resident in HBM -> "
@@ -264,6 +275,9 @@ def other_configs(steps: int = 5):
                             "ms_per_step": round(1e3 * dt, 3), "clips_per_s": round(B / dt, 1), "dtype": "f16",
                             "roofline": {"bound": "hbm", "achieved": round(B * nbytes / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(B * nbytes / dt / 1e9 / 8000.0, 4), "algorithmic_mb_per_clip": round(nbytes / 1e6, 2),
+                                         "traffic": counted,
+                                         "achieved_counted": (round(B * counted["mb_per_clip"] * 1e6 / dt / 1e9, 1) if counted else None),
+                                         "frac_counted": (round(B * counted["mb_per_clip"] * 1e6 / dt / 1e9 / 8000.0, 4) if counted else None),
                                          "how": "every layer's input read once + output written once at 2 bytes and the real channel counts, no fusion assumed (bench.py effnet_algorithmic_bytes)"},
                             "parity": {"reference": "tests/golden/family_small.npz:effnet.pooled (oracle/effnet_oracle.py, UNPINNED: torchvision is absent from the reference tree)",
                                        "how": "2 clips x 10 s", "pooled_rel_l2_f16": rel(p, gold["effnet.pooled"]), "tolerance": 1e-3}}

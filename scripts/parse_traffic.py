@@ -19,7 +19,7 @@ import json
 import os
 import sys
 
-SHORT = ("gemm256p_kernel", "gemm_nt_kernel", "attention2_kernel", "attention_tail_kernel", "attention_kernel", "layernorm_half_kernel",
+SHORT = ("gemm256p_kernel", "gemm_nt_kernel", "attention3_kernel", "attention2_kernel", "attention_tail_kernel", "attention_kernel", "layernorm_half_kernel",
          "layernorm_pool_kernel", "layernorm_kernel", "ln_rowstats_kernel", "posconv_kernel", "fbank_kernel", "mean_pool_kernel")
 LAYER = ("qkv", "out_proj", "fc1", "fc2")
 

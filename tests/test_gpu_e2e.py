@@ -148,6 +148,24 @@ def test_oracle_agrees_on_fresh_input(encoder, base_sd):
     assert rel_l2(r["hooks"][5].cpu().numpy().mean(1), taps["backbone.encoder.layers.4.fc2"].mean(1)) < tol
 
 
+def test_nan_input_stays_nan_and_stays_in_its_clip(encoder):
+    """A NaN sample must not be laundered into a finite embedding.  The fc1 epilogue's GELU (max(x, 0) - a q(a), common.h gelu_erf2_h) maps a
+    NaN pre-activation to a finite value -- fmax / fmin return their non-NaN operand -- and the range alarm does not see NaN; what keeps the
+    clip's output NaN is the residual stream beside the feed-forward branch (backbone.py:371-372: x = residual * alpha + ffn) and the
+    attention, where one NaN key poisons every query of its clip.  The reference (fp32 torch) returns NaN for such a clip; so does this
+    path, and the other clips of the batch are bit for bit what they are without it."""
+    x = synth.noise_clips(4, 32000, seed=31)
+    clean = encoder.forward(torch.from_numpy(x).cuda(), want_features=True, want_pooled=True)
+    cp, cf = clean["pooled"].cpu().numpy(), clean["features"].cpu().numpy()
+    bad = x.copy()
+    bad[2, 17000] = np.nan
+    r = encoder.forward(torch.from_numpy(bad).cuda(), want_features=True, want_pooled=True)
+    p, f = r["pooled"].cpu().numpy(), r["features"].cpu().numpy()
+    assert np.isnan(p[2]).all() and np.isnan(f[2]).any()
+    for i in (0, 1, 3):
+        assert np.array_equal(p[i], cp[i]) and np.array_equal(f[i], cf[i])
+
+
 def test_degenerate_signals(encoder, base_sd):
     """Signals at the ends of the frontend's range, GPU path vs the CPU oracle: digital silence (every mel bin at the log floor,
     every LayerNorm row of the patch embedding constant), a DC offset (removed per frame), one impulse, a full-scale square wave,

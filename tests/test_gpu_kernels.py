@@ -475,6 +475,31 @@ def test_attention_key_padding_and_plain_bias(built_lib):
     assert rel_l2(out.float().cpu().numpy(), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,grid", [(499, 0), (499, 5), (256, 3), (257, 2), (40, 9)])
+def test_attention_without_a_bias_table(built_lib, T, grid, dtype, monkeypatch):
+    """The encoders without relative position bias (AVES / wav2vec2 at 499 frames, EAT below 513 tokens) take the default kernel's BIAS = false
+    instantiation (variant 3 up to 512 tokens): plain softmax(q k^T / 8) v, with and without a key padding mask, workgroups that walk several
+    items, against fp64 -- and against variant 2 on the same inputs."""
+    from avex_amd import kernels as K
+    if grid:
+        monkeypatch.setenv("AVEX_AMD_ATT_GRID", str(grid))
+    B, H = 3, 12
+    E = H * 64
+    qkv = round_half(synth.normal(f"qkvnb{T}", (B * T, 3 * E), 1.0), dtype)
+    pad = np.zeros((B, T), bool); pad[1, T // 2:] = True; pad[2, :min(35, T - 1)] = True      # incl. a fully masked first key tile
+    tol = 1.5e-3 if dtype == "f16" else 1.2e-2
+    outs = {}
+    for variant in ("3", "2"):
+        monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", variant)
+        o1 = K.attention(_dev(qkv, _tdt(dtype)), B, T, H, None, None, None, None).float().cpu().numpy()
+        o2 = K.attention(_dev(qkv, _tdt(dtype)), B, T, H, None, None, None, None, key_pad=_dev(pad.astype(np.uint8), torch.uint8)).float().cpu().numpy()
+        outs[variant] = (o1, o2)
+        assert rel_l2(o1, _attention_ref(qkv, B, T, H, None, None, None, None)) < tol
+        assert rel_l2(o2, _attention_ref(qkv, B, T, H, None, None, None, None, key_pad=pad)) < tol
+    assert rel_l2(outs["3"][0], outs["2"][0]) < tol and rel_l2(outs["3"][1], outs["2"][1]) < tol
+
+
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("T,grid", [(496, 7), (200, 5), (300, 60), (512, 1)])
 def test_attention_persistent_items(built_lib, T, grid, variant, monkeypatch):
