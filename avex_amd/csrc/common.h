@@ -42,7 +42,20 @@ template <> struct Half<__bf16> {
 // where from() turns them into +-65504).  A kernel that calls Half<T>::from_hw must execute AVX_F16_SATURATE_ON() first: the bit is
 // per-wave state, clear at wave start.  The "memory" clobber keeps every load -- and with it every conversion of loaded or computed
 // values -- behind the mode write.  One v_med3_f32 less per stored element: a quarter of the vector work of a bias-only GEMM epilogue.
-#define AVX_F16_SATURATE_ON() asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory")
+// MODE.DX10_CLAMP clear: a `clamp` output modifier passes a NaN through instead of turning it into 0 (gelu_erf2_h below relies on it).  Part of both
+// epilogue macros; harmless for kernels that use no clamp modifier.
+#define AVX_NAN_CLAMP_OFF_ASM "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0\n\t"
+#define AVX_F16_SATURATE_ON() asm volatile(AVX_NAN_CLAMP_OFF_ASM "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory")
+// MEASURED ON gfx950 (scripts/micro/mfma_nan.hip, round 5): WITH MODE.FP16_OVFL SET, v_mfma_f32_{16x16x32,32x32x16}_f16 TREATS A NaN OPERAND AS 0 AND
+// AN INFINITE ONE AS A FINITE MAXIMUM -- a clip with one NaN sample went through every GEMM as ordinary numbers and came out with a finite
+// embedding (the reference's fp32 path returns NaN; tests/test_gpu_e2e.py::test_nan_input_stays_nan_and_stays_in_its_clip).  Kernels with MFMAs
+// therefore keep the bit CLEAR while their MFMAs run and set it around their conversions only: AVX_F16_SAT_BEGIN() at the start of an
+// epilogue, AVX_F16_SAT_END() behind it when more MFMAs follow.  These use the s_setreg builtin, which the compiler knows to write MODE: a
+// scheduling boundary no floating-point instruction crosses.  Kernels without MFMAs (depthwise, element-wise) keep the one-time form above.
+#define AVX_MODE_FP16_OVFL_HWREG 1473      // hwreg(HW_REG_MODE = 1, offset 23, size 1): id | offset << 6 | (size - 1) << 11
+#define AVX_MODE_DX10_CLAMP_HWREG 513      // hwreg(HW_REG_MODE, offset 8, size 1)
+#define AVX_F16_SAT_BEGIN() do { __builtin_amdgcn_s_setreg(AVX_MODE_DX10_CLAMP_HWREG, 0); __builtin_amdgcn_s_setreg(AVX_MODE_FP16_OVFL_HWREG, 1); asm volatile("" ::: "memory"); } while (0)
+#define AVX_F16_SAT_END() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_setreg(AVX_MODE_FP16_OVFL_HWREG, 0); } while (0)
 
 // Range alarm of the f16 outputs (Half<_Float16>::from saturates silently): a kernel keeps the running max of |value| over
 // everything a lane rounds to f16 (v_max3_f32 with |.| modifiers: half a VALU slot per element) and commits once at its end.
@@ -157,7 +170,35 @@ static __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 #ifndef AVX_GELUH_RELU
 #define AVX_GELUH_RELU 1
 #endif
+// NaN in, NaN out, at no extra instruction (round 5).  min(|x|, 5.7) and max(x, 0) return their non-NaN operand, so the form above turned a NaN
+// pre-activation into -3e-8: the fc2 hook taps of a clip with one NaN sample -- what extract_embeddings returns -- were finite (the reference's fp32
+// F.gelu gives NaN, backbone.py:368).  The clamp of |x| is now the CLAMP OUTPUT MODIFIER of a multiply, t = clamp01(|x| / 5.7), which passes a NaN
+// through when MODE.DX10_CLAMP is clear (AVX_NAN_CLAMP_OFF, set by the epilogue macros below); the polynomial is the same one written in t
+// (coefficient i times 5.7^i, log2(5.7) added to the constant so that 2^P'(t) = 5.7 q): |new - old| <= 7.3e-9 over [-12, 12], |gelu - exact| <= 6.1e-6
+// as before.  gelu = max(x, 0) - t * 2^P'(t): a NaN t makes the result NaN whatever max() returned.
+#define AVX_GELUH_T0 1.5104823112487793f
+#define AVX_GELUH_T1 -6.540023326873779f
+#define AVX_GELUH_T2 -15.205792427062988f
+#define AVX_GELUH_T3 -8.163202285766602f
+#define AVX_GELUH_T4 4.081258773803711f
+#define AVX_GELUH_INVA 0.17543859779834747f
+static __device__ __forceinline__ float gelu_clamp_t(float x) {
+    float t;
+    asm("v_mul_f32_e64 %0, |%1|, %2 clamp" : "=v"(t) : "v"(x), "v"(AVX_GELUH_INVA));
+    return t;
+}
 static __device__ __forceinline__ f32x2 gelu_erf2_h(f32x2 x) {
+#if AVX_GELUH_RELU
+    const f32x2 t = {gelu_clamp_t(x[0]), gelu_clamp_t(x[1])};
+    f32x2 p = __builtin_elementwise_fma((f32x2)(AVX_GELUH_T4), t, (f32x2)(AVX_GELUH_T3));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(AVX_GELUH_T2));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(AVX_GELUH_T1));
+    p = __builtin_elementwise_fma(p, t, (f32x2)(AVX_GELUH_T0));
+    f32x2 q, r;
+    q[0] = __builtin_amdgcn_exp2f(p[0]); q[1] = __builtin_amdgcn_exp2f(p[1]);
+    r[0] = __builtin_fmaxf(x[0], 0.f); r[1] = __builtin_fmaxf(x[1], 0.f);
+    return __builtin_elementwise_fma(-t, q, r);
+#else
     f32x2 a;
     a[0] = __builtin_fminf(__builtin_fabsf(x[0]), AVX_GELU_A); a[1] = __builtin_fminf(__builtin_fabsf(x[1]), AVX_GELU_A);
     f32x2 p = __builtin_elementwise_fma((f32x2)(AVX_GELUH_C4), a, (f32x2)(AVX_GELUH_C3));
@@ -166,11 +207,6 @@ static __device__ __forceinline__ f32x2 gelu_erf2_h(f32x2 x) {
     p = __builtin_elementwise_fma(p, a, (f32x2)(AVX_GELUH_C0));
     f32x2 q;
     q[0] = __builtin_amdgcn_exp2f(p[0]); q[1] = __builtin_amdgcn_exp2f(p[1]);
-#if AVX_GELUH_RELU
-    f32x2 r;
-    r[0] = __builtin_fmaxf(x[0], 0.f); r[1] = __builtin_fmaxf(x[1], 0.f);
-    return __builtin_elementwise_fma(-a, q, r);
-#else
     f32x2 ax;
     ax[0] = __builtin_fabsf(x[0]); ax[1] = __builtin_fabsf(x[1]);
     const f32x2 u = (f32x2)(0.5f) - q;

@@ -390,6 +390,10 @@ struct MbGeo {
 template <typename T, int KS, int ST, int KIN, int TH, int TW, int PIX, int CC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, ST, KIN, TH, TW, CC>::WPE, MbGeo<KS, ST, KIN, TH, TW, CC>::WPE))) void mbconv_kernel(const MbArgs p) {
     AVX_F16_SATURATE_ON();                               // f16 outputs saturate through MODE.FP16_OVFL (common.h): no clamp instructions
+    // KNOWN LIMIT (round 5, scripts/micro/mfma_nan.hip): with the bit set the expansion's MFMAs treat a NaN input pixel as 0.  The GEMM and pos-conv
+    // kernels clear it while their MFMAs run; here MFMAs and conversions alternate every few instructions inside a pixel group (two groups in
+    // flight for the transcendentals' latency), and a mode switch is a scheduling boundary: not done.  A NaN pixel survives through the blocks'
+    // residual connections, the depthwise taps and the squeeze sums, but a block front without a residual returns finite values for it.
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     typedef MbGeo<KS, ST, KIN, TH, TW, CC> G;

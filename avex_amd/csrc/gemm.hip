@@ -35,7 +35,7 @@
 #define GEMM_GELU_H 1     // 1: the streaming kernel's bias + GELU epilogue (half output) evaluates the degree-4 fit; 0: the degree-6 one (A/B)
 #endif
 #ifndef GEMM_HW_SAT
-#define GEMM_HW_SAT 1      // 1: every kernel of this file sets MODE.FP16_OVFL at its top and its f16 outputs saturate through MODE.FP16_OVFL (common.h) instead of a v_med3_f32 per element
+#define GEMM_HW_SAT 1      // 1: the kernels of this file set MODE.FP16_OVFL around their epilogues (NOT while their MFMAs run: common.h) and their f16 outputs saturate through it instead of a v_med3_f32 per element
 #endif
 #if GEMM_HW_SAT
 #define HFROM(x) Half<T>::from_hw(x)
@@ -54,7 +54,6 @@ typedef __attribute__((address_space(3))) void lptr_t;
 
 template <typename T, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
-    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -194,6 +193,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
         }
         return;
     }
+    if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();      // every MFMA of this workgroup has been issued: the f16 conversions below saturate in hardware (common.h)
     const float alpha = p.alpha;
     float ovf_mx = 0.f;
 #pragma unroll
@@ -584,7 +584,6 @@ static_assert(L5_ROWS + 4096 <= 32768, "EPI 1 scratch above the stages");
 
 template <typename T, int EPI, int LN, int ACT>
 __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
-    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -843,6 +842,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         asm volatile("" : "+v"(le));
         const int er = le >> 3, ec = le & 7, lc = le & 15, lg = le >> 4;
         float ovf_mx = 0.f;
+        if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();      // MODE.FP16_OVFL for the epilogue's conversions only: set, the MFMAs drop NaN operands (common.h)
 
         if constexpr (GEMM_NOEPI && (EPI == 1 || EPI == 2)) {
             // diagnostic build: NO epilogue at all (the accumulators are only kept alive) -- the upper bound of what any scheme that hides
@@ -1244,6 +1244,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
             }
         }
         ovf_lanes |= ovf_mask<T>(ovf_mx);
+        if (GEMM_HW_SAT) AVX_F16_SAT_END();
         AVX_STAMP(if (stamp) g_gemm_stamps[4 * tile + 3] = __builtin_amdgcn_s_memrealtime(););
         if (!has_next) break;
         {   // the next tile's 8 source pointers (16 registers) are computed a second time here instead of being carried through the
@@ -1278,7 +1279,6 @@ static int launch256(const avx::GemmArgs& a5, int grid, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NT, int KS, bool SCALE, bool RAW>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p) {
-    if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
@@ -1335,6 +1335,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
             load_rows(blk, af);
         }
         if constexpr (SCALE) {
+            if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();      // (the conversions of the scaled rows; cleared again in front of the MFMAs below)
             // A rows scaled per (clip, input channel) on their way into the product: EfficientNet's squeeze-excitation rescale without its
             // own pass over the expanded tensor.  Same arithmetic as scale_channels_kernel (fp32 product, rounded to the operand type).
 #pragma unroll
@@ -1357,6 +1358,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
         constexpr int NTP = (NT > 8 && NT % 8 == 0) ? 8 : NT;
 #pragma unroll
         for (int np = 0; np < NT; np += NTP) {
+            if (GEMM_HW_SAT && (SCALE || np > 0 || blk != blk0)) AVX_F16_SAT_END();      // MFMAs run with MODE.FP16_OVFL clear (common.h)
             f32x4 acc[NTP][2];
 #pragma unroll
             for (int nt = 0; nt < NTP; ++nt) { acc[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nt][1] = acc[nt][0]; }
@@ -1370,6 +1372,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                     acc[nt][1] = mfma16(wf, af[ks][1], acc[nt][1]);
                 }
             }
+            if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int64_t m = r0 + rt * 16 + lr;

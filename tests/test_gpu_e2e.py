@@ -149,19 +149,28 @@ def test_oracle_agrees_on_fresh_input(encoder, base_sd):
 
 
 def test_nan_input_stays_nan_and_stays_in_its_clip(encoder):
-    """A NaN sample must not be laundered into a finite embedding.  The fc1 epilogue's GELU (max(x, 0) - a q(a), common.h gelu_erf2_h) maps a
-    NaN pre-activation to a finite value -- fmax / fmin return their non-NaN operand -- and the range alarm does not see NaN; what keeps the
-    clip's output NaN is the residual stream beside the feed-forward branch (backbone.py:371-372: x = residual * alpha + ffn) and the
-    attention, where one NaN key poisons every query of its clip.  The reference (fp32 torch) returns NaN for such a clip; so does this
-    path, and the other clips of the batch are bit for bit what they are without it."""
+    """A NaN sample must not be laundered into a finite embedding: the reference (fp32 torch) returns NaN for such a clip -- features, pooled
+    vector and every hooked fc2 output, which is what extract_embeddings hands back (backbone.py:350-375) -- and so must this path, with the
+    other clips of the batch bit for bit what they are without it.  Round 5 found four places that turned the NaN into ordinary numbers: the
+    software f16 clamp and the filterbank's log floor (fmin / fmax return their non-NaN operand), the MFMAs under MODE.FP16_OVFL (a NaN
+    operand counts as 0: scripts/micro/mfma_nan.hip) and the half-output GELU's clamps (csrc/common.h)."""
     x = synth.noise_clips(4, 32000, seed=31)
-    clean = encoder.forward(torch.from_numpy(x).cuda(), want_features=True, want_pooled=True)
+    layers = [0, 1, 6, 12]
+    clean = encoder.forward(torch.from_numpy(x).cuda(), hook_layers=layers, want_features=True, want_pooled=True)
     cp, cf = clean["pooled"].cpu().numpy(), clean["features"].cpu().numpy()
+    ch = {i: clean["hooks"][i].cpu().numpy() for i in layers}
     bad = x.copy()
     bad[2, 17000] = np.nan
-    r = encoder.forward(torch.from_numpy(bad).cuda(), want_features=True, want_pooled=True)
+    r = encoder.forward(torch.from_numpy(bad).cuda(), hook_layers=layers, want_features=True, want_pooled=True)
     p, f = r["pooled"].cpu().numpy(), r["features"].cpu().numpy()
     assert np.isnan(p[2]).all() and np.isnan(f[2]).any()
+    for i in layers:
+        h = r["hooks"][i].cpu().numpy()
+        assert np.isnan(h[2]).any(), f"hook {i} of the poisoned clip is finite"
+        if i >= 1:      # behind the first attention every token of the clip has met the NaN key
+            assert np.isnan(h[2]).all(), f"hook {i}: {int(np.isfinite(h[2]).sum())} finite values"
+        for c in (0, 1, 3):
+            assert np.array_equal(h[c], ch[i][c])
     for i in (0, 1, 3):
         assert np.array_equal(p[i], cp[i]) and np.array_equal(f[i], cf[i])
 
