@@ -11,6 +11,9 @@
 //   scale_channels x[b, p, c] *= s[b, c] (the excitation), in place
 #include "common.h"
 
+#ifndef MBCONV_MODE_TOGGLE
+#define MBCONV_MODE_TOGGLE 1
+#endif
 namespace {
 
 __device__ __forceinline__ float silu1(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -367,6 +370,7 @@ static __device__ __forceinline__ void row_quarter_sums(float (&p)[8]) {
 }
 
 typedef int a_i32x2m __attribute__((ext_vector_type(2)));
+template <int N> struct a_icm { static constexpr int value = N; };
 struct MbArgs {
     const void* in; int H, W, ld_in;
     const void* w_exp; int ldw; const float* b_exp;
@@ -389,11 +393,10 @@ struct MbGeo {
 
 template <typename T, int KS, int ST, int KIN, int TH, int TW, int PIX, int CC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, ST, KIN, TH, TW, CC>::WPE, MbGeo<KS, ST, KIN, TH, TW, CC>::WPE))) void mbconv_kernel(const MbArgs p) {
-    AVX_F16_SATURATE_ON();                               // f16 outputs saturate through MODE.FP16_OVFL (common.h): no clamp instructions
-    // KNOWN LIMIT (round 5, scripts/micro/mfma_nan.hip): with the bit set the expansion's MFMAs treat a NaN input pixel as 0.  The GEMM and pos-conv
-    // kernels clear it while their MFMAs run; here MFMAs and conversions alternate every few instructions inside a pixel group (two groups in
-    // flight for the transcendentals' latency), and a mode switch is a scheduling boundary: not done.  A NaN pixel survives through the blocks'
-    // residual connections, the depthwise taps and the squeeze sums, but a block front without a residual returns finite values for it.
+    // f16 outputs saturate through MODE.FP16_OVFL (common.h): no clamp instructions.  With the bit set the MFMAs treat a NaN operand as 0
+    // (scripts/micro/mfma_nan.hip), so it is set per pair of pixel groups, behind their MFMAs and in front of their conversions, and around the
+    // depthwise stage (MBCONV_MODE_TOGGLE; 0 = round 4's form, the bit set once at the top: the A side of profiles/r05b_mbconv_mode.txt).
+    if (!MBCONV_MODE_TOGGLE) AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
     typedef MbGeo<KS, ST, KIN, TH, TW, CC> G;
@@ -475,37 +478,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, S
         const bool more = c + CC < cp;
         Par nxt;
         if (more) request(nxt, c + CC);                  // in flight under the expansion below
-        auto expand_group = [&](int j) __attribute__((always_inline)) {
-            const int pix = (wave + 4 * j) * 16 + lr;
-            const bool inside = (inside_bits >> j) & 1u;
-            v8 xf[KST];
+        // NG (1 or 2) pixel groups at a time: their MFMAs first, then -- MODE.FP16_OVFL set -- bias, SiLU and the conversions of both (two
+        // independent chains for the transcendentals), then the bit cleared again for the next groups' MFMAs
+        auto expand_groups = [&](int j0, auto NGc) __attribute__((always_inline)) {
+            constexpr int NG = decltype(NGc)::value;
+            f32x4 accs[NG][MT];
 #pragma unroll
-            for (int ks = 0; ks < KST; ++ks) xf[ks] = *(const v8*)(s_in + pix * ISTR + ks * 64 + lq * 16);
+            for (int u = 0; u < NG; ++u) {
+                const int pix = (wave + 4 * (j0 + u)) * 16 + lr;
+                v8 xf[KST];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < KST; ++ks) xf[ks] = *(const v8*)(s_in + pix * ISTR + ks * 64 + lq * 16);
 #pragma unroll
-                for (int ks = 0; ks < KST; ++ks) acc = mfma16(cur.wf[mt][ks], xf[ks], acc);
-                const f32x4 v = silu4(acc + cur.be[mt]);
-                ovf_see4<T>(ovf_mx, v);
-                v4 h;
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = Half<T>::from_hw(v[e]);
-                a_i32x2m hb = __builtin_bit_cast(a_i32x2m, h);
-                hb[0] = inside ? hb[0] : 0; hb[1] = inside ? hb[1] : 0;
-                *(a_i32x2m*)(s_exp + pix * ESTR + (16 * mt + 4 * lq) * 2) = hb;
+                    for (int ks = 0; ks < KST; ++ks) acc = mfma16(cur.wf[mt][ks], xf[ks], acc);
+                    accs[u][mt] = acc;
+                }
             }
+            if (MBCONV_MODE_TOGGLE) AVX_F16_SAT_BEGIN();
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int pix = (wave + 4 * (j0 + u)) * 16 + lr;
+                const bool inside = (inside_bits >> (j0 + u)) & 1u;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 v = silu4(accs[u][mt] + cur.be[mt]);
+                    ovf_see4<T>(ovf_mx, v);
+                    v4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = Half<T>::from_hw(v[e]);
+                    a_i32x2m hb = __builtin_bit_cast(a_i32x2m, h);
+                    hb[0] = inside ? hb[0] : 0; hb[1] = inside ? hb[1] : 0;
+                    *(a_i32x2m*)(s_exp + pix * ESTR + (16 * mt + 4 * lq) * 2) = hb;
+                }
+            }
+            if (MBCONV_MODE_TOGGLE) AVX_F16_SAT_END();
         };
-        // every wave has NPG / 4 groups (two at a time: independent chains for the transcendentals), the first NPG % 4 waves one more
-#pragma unroll 2
-        for (int j = 0; j < NPG / 4; ++j) expand_group(j);
-        if (NPG % 4 != 0 && wave < NPG % 4) expand_group(NPG / 4);
+        // every wave has NPG / 4 groups, the first NPG % 4 waves one more
+#pragma unroll
+        for (int j = 0; j + 1 < NPG / 4; j += 2) expand_groups(j, a_icm<2>{});
+        if ((NPG / 4) % 2) expand_groups(NPG / 4 - 1, a_icm<1>{});
+        if (NPG % 4 != 0 && wave < NPG % 4) expand_groups(NPG / 4, a_icm<1>{});
         const f32x4 bd0 = cur.bd0, bd1 = cur.bd1;
         if (more) {                                      // every load of this chunk is consumed HERE, before the taps' stores
             stage_wd(nxt, slot ^ 1);
             cur = nxt;
         }
         __syncthreads();
+        if (MBCONV_MODE_TOGGLE) AVX_F16_SAT_BEGIN();      // the depthwise stage's output conversions; cleared at the end of the chunk
         float psum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) psum[e] = 0.f;
@@ -576,6 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MbGeo<KS, S
             for (int r = 0; r < 16; ++r) s += s_red[r * CC + tid];
             p.part[((int64_t)b * gridDim.x + blockIdx.x) * cp + c + tid] = s;
         }
+        if (MBCONV_MODE_TOGGLE) AVX_F16_SAT_END();      // the next chunk's MFMAs run with MODE.FP16_OVFL clear
     }
     ovf_commit<T>(p.ovf, ovf_mx);
 }

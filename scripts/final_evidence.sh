@@ -1,6 +1,6 @@
 #!/bin/bash
 # evidence on the final tree of a round (run on the GPU box through gpurun):  bash scripts/final_evidence.sh <tag>
-TAG=${1:-r04z}
+TAG=${1:-r05z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
