@@ -372,6 +372,24 @@ def test_config_c5_full_size_efficientnet(built_lib):
         assert torch.equal(one, full[r:r + 1])
 
 
+def test_config_c5_nan_stays_in_its_clip(built_lib):
+    """EfficientNet path (mel frontend -> stem -> fused block fronts -> GEMMs -> pool): a NaN sample makes ITS clip's pooled vector NaN -- the
+    reference's torchvision stack in fp32 propagates it (efficientnet.py:163-215) -- and leaves the other clips bit for bit unchanged.  The fused
+    block front dropped it in round 4: its MFMAs ran with MODE.FP16_OVFL set, which makes them read a NaN operand as 0 (scripts/micro/mfma_nan.hip)."""
+    from avex_amd import kernels as K
+    from avex_amd.effnet_encoder import EfficientNetB0Encoder
+    enc = EfficientNetB0Encoder(synth.effnet_b0_state_dict())
+    plan = K.MelspecPlan(n_fft=800, hop_length=160, n_mels=128, normalize=True)
+    x = synth.noise_clips(4, 160000, seed=5)
+    clean = enc.forward(plan(torch.from_numpy(x).cuda()), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
+    bad = x.copy()
+    bad[2, 80000] = np.nan
+    p = enc.forward(plan(torch.from_numpy(bad).cuda()), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
+    assert np.isnan(p[2]).all()
+    for i in (0, 1, 3):
+        assert np.array_equal(p[i], clean[i])
+
+
 def test_bias_table_cache_is_bounded_and_eviction_is_invisible(built_lib, base_sd):
     """Variable-length inference: each token count needs its own Toeplitz bias table (api.cpp bias_tab_for); the cache holds 16 of them,
     least recently used out.  40 different lengths, then the first one again: same bits as its first run."""
