@@ -126,3 +126,34 @@ def test_config_c3_full_size(built_lib, monkeypatch):
         small = enc.forward(wav[rows].contiguous(), want_features=False, pooling="mean")["pooled"]
         assert rel_l2(small.cpu().numpy(), full[rows].cpu().numpy()) < bar, fold
         del enc
+
+
+def test_nan_sample_stays_nan_and_in_its_clip_eat_and_aves(built_lib):
+    """The families that share the BEATs kernels: a NaN sample gives NaN for its clip and leaves the others bit for bit unchanged (EAT: 513 tokens
+    through the long-clip attention; AVES: conv feature extractor -- GroupNorm over time -- then the transformer at a length the default attention
+    kernel takes without a bias table).  The references compute in fp32 and propagate it (eat_hf.py:241-289, aves_model.py:62-151)."""
+    import numpy as np
+    from avex_amd.eat_encoder import EatEncoder
+    from avex_amd.aves_encoder import AvesEncoder
+    enc = EatEncoder(synth.EAT_BASE_CFG, synth.eat_state_dict(synth.EAT_BASE_CFG), operand_dtype="f16")
+    x = synth.noise_clips(3, 80000, seed=14)
+    clean = enc.forward(torch.from_numpy(x).cuda(), hook_layers=[11], pooling="mean")
+    bad = x.copy(); bad[1, 40000] = np.nan
+    r = enc.forward(torch.from_numpy(bad).cuda(), hook_layers=[11], pooling="mean")
+    for key in ("pooled", "features"):
+        a, c = r[key].cpu().numpy(), clean[key].cpu().numpy()
+        assert np.isnan(a[1]).all(), ("eat", key)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[2], c[2]), ("eat", key)
+    assert np.isnan(r["hooks"][11].cpu().numpy()[1]).all()
+    enc.close()
+    cfg = dict(synth.AVES_BASE_CFG, encoder_num_layers=2)
+    aenc = AvesEncoder(cfg, synth.aves_state_dict(cfg))
+    x = synth.noise_clips(3, 40000, seed=15)
+    clean = aenc.forward(torch.from_numpy(x).cuda(), hook_layers=[1], want_features=True, want_pooled=True)
+    bad = x.copy(); bad[1, 20000] = np.nan
+    r = aenc.forward(torch.from_numpy(bad).cuda(), hook_layers=[1], want_features=True, want_pooled=True)
+    for key in ("pooled", "features"):
+        a, c = r[key].cpu().numpy(), clean[key].cpu().numpy()
+        assert np.isnan(a[1]).all(), ("aves", key)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[2], c[2]), ("aves", key)
+    assert np.isnan(r["hooks"][1].cpu().numpy()[1]).all()
