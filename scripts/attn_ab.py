@@ -14,11 +14,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["2", "3"]
 T = int(os.environ.get("ATT_T", "496")); H = 12
+NOBIAS = os.environ.get("ATT_NOBIAS", "0") == "1"      # the encoders without relative position bias (EAT, AVES): plain softmax(q k^T / 8) v
 per = 12      # launches per group (one step's worth)
 torch.manual_seed(0)
 qkv = torch.randn(B * T, 3 * H * 64, device="cuda").half()
 tab = torch.randn(H, 2 * T - 1, device="cuda") * 0.3
 gw = torch.randn(8, 64, device="cuda") * 0.1; gb = torch.randn(8, device="cuda") * 0.1; ga = torch.ones(H, device="cuda")
+if NOBIAS:
+    tab = gw = gb = ga = None
 outs = {}
 for v in variants:
     os.environ["AVEX_AMD_ATT_VARIANT"] = v
