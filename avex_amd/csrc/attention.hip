@@ -1191,7 +1191,12 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         const int per_block = (n_units + n_wg - 1) / n_wg;
         const int grid = (n_units + per_block - 1) / per_block;
         if (Tn > TMAX) {
-            if (bias_tab) {
+            // EAT's shape (513 .. 544 tokens, no bias table, the rows beyond 512 in the tail kernel): the main block on variant 3's nine-tile form
+            const bool v3_long = !(getenv("AVEX_AMD_ATT_VARIANT") && atoi(getenv("AVEX_AMD_ATT_VARIANT")) == 2);      // (read per launch: A/B in one process)
+            if (!bias_tab && use_tail && nqb_main == 1 && Tn <= TMAX + 32 && v3_long && !getenv("AVEX_AMD_ATT_NO_XT")) {
+                const int rc3 = avx::attention16(qkv, B, Tn, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, __is_same(T, _Float16) ? AVEXHIP_F16 : AVEXHIP_BF16, q_log2e, n_wg, s);
+                if (rc3 != AVEXHIP_OK) return rc3;
+            } else if (bias_tab) {
                 AVX_ENSURE_LDS((attention2_kernel<T, true, true>), ATT2L_LDS);
                 hipLaunchKernelGGL((attention2_kernel<T, true, true>), dim3(grid), dim3(512), ATT2L_LDS, s, (const T*)qkv, Tn, H, B, per_block, nqb_main, bias_tab,
                                    grep_w, grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);

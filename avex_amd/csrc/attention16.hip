@@ -23,7 +23,7 @@
 //   * V image in LDS: [8-key group][16-d block][key & 7][32 B], so a 32-lane half's transposed read covers 256 contiguous bytes
 //     (conflict-free); K image as in variant 2 (128-B rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7: conflict-free for the
 //     16-row x 4-chunk read of this operand map as well, checked with the bank rules of the LDS table).
-// Long clips (> 512 tokens) stay on variant 2.
+// Longer clips stay on variant 2, except 513 .. 544 tokens without a bias table (EAT): the XT instantiation below.
 #include <stdlib.h>
 
 #include "common.h"
@@ -43,6 +43,14 @@ constexpr int A3_HALF = 65536;                            // K + V of 256 keys
 constexpr int A3_TPAD = 64;                               // floats in front of each shifted copy (indices down to -64 are read, never used)
 constexpr int A3_TLD = A3_TPAD + 1040;                    // floats per shifted copy of the bias row
 constexpr int A3_TAB_OFF = 2 * A3_HALF;
+// XT (no bias table only): up to 32 keys beyond 512 -- EAT's 513 tokens -- ride in the second half's phase as a NINTH key tile instead of a phase of
+// their own: buffers of 288 keys (the LDS the bias table would take is free), a key mask of 544 entries; the queries beyond 512 go to the tail kernel
+constexpr int A3X_KBUF = 9 * 4096;                         // 288 keys x 128 B
+constexpr int A3X_HALF = 2 * A3X_KBUF;
+constexpr int A3X_KN = 544;                                // key-mask entries per item
+constexpr int A3X_KADD_OFF = 2 * A3X_HALF;
+constexpr int A3X_GW_OFF = A3X_KADD_OFF + 2 * A3X_KN * 4;
+constexpr int ATT3X_LDS = A3X_GW_OFF + 136 * 4;
 constexpr int A3_TAB_BYTES = 4 * A3_TLD * 4;
 constexpr int A3_KADD_OFF = A3_TAB_OFF + A3_TAB_BYTES;
 constexpr int A3_GW_OFF = A3_KADD_OFF + 2 * A3_TMAX * 4;
@@ -98,19 +106,22 @@ static __device__ __forceinline__ void a3_dma16(const void* src, const char* lds
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
 }
 
-template <typename T, bool BIAS>
-__global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ qkv, int Tn, int H, int Bc, int per_block,
+template <typename T, bool BIAS, bool XT = false>
+__global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ qkv, int Tn, int Tq, int H, int Bc, int per_block,
                                                         const float* __restrict__ bias_tab, const float* __restrict__ grep_w,
                                                         const float* __restrict__ grep_b, const float* __restrict__ grep_a,
                                                         const uint8_t* __restrict__ key_pad, T* __restrict__ out, int q_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Half<T>::v8 v8;
     typedef typename Half<T>::v4 v4;
-    constexpr int NB = 4, NW = 8, NT = 512, NKT = 8;
+    static_assert(!XT || !BIAS, "the nine-tile last phase takes the bias table's LDS");
+    // Tn = keys (tokens of the clip), Tq = query rows this kernel computes (= Tn, or 512 with XT: the rows beyond go to the tail kernel)
+    constexpr int NB = 4, NW = 8, NT = 512, NKT = XT ? 9 : 8;
+    constexpr int KBUF = XT ? A3X_KBUF : A3_KBUF, HALF = XT ? A3X_HALF : A3_HALF, KN = XT ? A3X_KN : A3_TMAX;
     float* tab = (float*)(smem + A3_TAB_OFF);
-    float* kadd = (float*)(smem + A3_KADD_OFF);
-    T* gwh = (T*)(smem + A3_GW_OFF);                     // gate weights: 4 rows of 64 halves
-    float* gwb = (float*)(smem + A3_GW_OFF + 512);      // the gate's two biases
+    float* kadd = (float*)(smem + (XT ? A3X_KADD_OFF : A3_KADD_OFF));
+    T* gwh = (T*)(smem + (XT ? A3X_GW_OFF : A3_GW_OFF));                     // gate weights: 4 rows of 64 halves
+    float* gwb = (float*)(smem + (XT ? A3X_GW_OFF : A3_GW_OFF) + 512);      // the gate's two biases
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
     const int np = (w1 - w0) * nh;
     const int nkt = (Tn + 31) >> 5;
     const int Q0 = 64 * wave;
-    const bool has_q = Q0 < Tn;                           // wave-uniform
+    const bool has_q = Q0 < Tq;                           // wave-uniform
 
     int h_cur = w0 / Bc, b_cur = w0 - h_cur * Bc;
     int half = 0;
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
     // boundary where every wave of the CU issued its eight at once and nothing else ran (2 - 4k cycles per phase, measured).
     auto dma_piece = [&](int ph, int u) __attribute__((always_inline)) {
         const T* base = qkv + (int64_t)b_ld * Tn * ld + h_ld * 64;
-        char* buf = smem + (ph & 1) * A3_HALF;
+        char* buf = smem + (ph & 1) * HALF;
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int ri = 4 * wave + u;                                   // 8-key group inside the half
@@ -152,16 +163,26 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
         a3_dma16(base + (int64_t)key * ld + E + chunk * 8, buf + ri * 1024);
         int vkey = half_ld * 256 + 8 * ri + ((lane >> 1) & 7);         // piece = [16-d block = lane >> 4][key & 7][two 16-byte chunks]
         vkey = vkey < Tn ? vkey : Tn - 1;
-        a3_dma16(base + (int64_t)vkey * ld + 2 * E + 16 * (lane >> 4) + 8 * (lane & 1), buf + A3_KBUF + ri * 1024);
+        a3_dma16(base + (int64_t)vkey * ld + 2 * E + 16 * (lane >> 4) + 8 * (lane & 1), buf + KBUF + ri * 1024);
+        if (XT && u == 3 && half_ld == nh - 1 && wave < 4) {               // the ninth key tile: four more 8-key groups, one per wave 0 .. 3, with the wave's last piece
+            const int rx = 32 + wave;
+            const int klx = 8 * rx + (lane >> 3);
+            int kx = half_ld * 256 + klx;
+            kx = kx < Tn ? kx : Tn - 1;
+            a3_dma16(base + (int64_t)kx * ld + E + ((lane & 7) ^ ((klx >> 1) & 7)) * 8, buf + rx * 1024);
+            int vx = half_ld * 256 + 8 * rx + ((lane >> 1) & 7);
+            vx = vx < Tn ? vx : Tn - 1;
+            a3_dma16(base + (int64_t)vx * ld + 2 * E + 16 * (lane >> 4) + 8 * (lane & 1), buf + KBUF + rx * 1024);
+        }
     };
     auto dma_advance = [&]() __attribute__((always_inline)) {
         if (++half_ld == nh) { half_ld = 0; if (++b_ld == Bc) { b_ld = 0; ++h_ld; } }
     };
     auto write_kadd = [&](int slot, int b) __attribute__((always_inline)) {
-        for (int j = tid; j < A3_TMAX; j += NT) {
+        for (int j = tid; j < KN; j += NT) {
             bool ok = j < Tn;
             if (ok && key_pad) ok = key_pad[(int64_t)b * Tn + j] == 0;
-            kadd[slot * A3_TMAX + j] = ok ? 0.f : NEG_INF;
+            kadd[slot * KN + j] = ok ? 0.f : NEG_INF;
         }
     };
 
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             int q = Q0 + 16 * nb + c;
-            q = q < Tn ? q : Tn - 1;                     // clamped for loads; stores are masked
+            q = q < Tq ? q : Tq - 1;                     // clamped for loads; stores are masked
             const T* src = base + (int64_t)q * ld + 8 * g;
             // Inline assembly: the compiler must not know these loads.  It cannot count the conditional output stores issued behind them, so any
             // wait IT places for a Q register waits for every store as well (and an asm statement that redefines the registers gets a vmcnt(0)
@@ -235,10 +256,10 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
         asm volatile("" : "+v"(lane));
         const int c = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) n_st += Q0 + 16 * nb < Tn ? 2 : 0;
+        for (int nb = 0; nb < NB; ++nb) n_st += Q0 + 16 * nb < Tq ? 2 : 0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            if (Q0 + 16 * nb >= Tn) continue;                              // wave-uniform
+            if (Q0 + 16 * nb >= Tq) continue;                              // wave-uniform
             const float l_tot = a3_rows_sum(l_run[nb]);
             const float inv = __builtin_amdgcn_rcpf(l_tot);
             const f32x2 inv2 = {inv, inv};
@@ -276,15 +297,15 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             }
             const int qrow = Q0 + 16 * nb + (c & 7);
             T* orow = out + ((int64_t)b * Tn + qrow) * E + h * 64 + 16 * (g & 1) + 8 * (g >> 1) + 32 * (c >> 3);
-            if (qrow < Tn) *(a3_i32x4*)orow = wa;
-            if (qrow + 8 < Tn) *(a3_i32x4*)(orow + 8 * (int64_t)E) = wb;
+            if (qrow < Tq) *(a3_i32x4*)orow = wa;
+            if (qrow + 8 < Tq) *(a3_i32x4*)(orow + 8 * (int64_t)E) = wb;
 #else
             const int qrow = Q0 + 16 * nb + c;
             T* orow = out + ((int64_t)b * Tn + qrow) * E + h * 64 + 16 * (g & 1) + 8 * (g >> 1);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const a3_i32x4 wv = {w[p][0], w[p][1], w[p][2], w[p][3]};
-                if (qrow < Tn) *(a3_i32x4*)(orow + 32 * p) = wv;
+                if (qrow < Tq) *(a3_i32x4*)(orow + 32 * p) = wv;
             }
 #endif
         }
@@ -370,16 +391,17 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
         int dma_done = 0;                                 // pieces of phase ph + 1 this wave has issued (wave-uniform)
         A3_PT(2)
         if (has_q) {
-            const char* Kb = smem + (ph & 1) * A3_HALF;
-            const float* kad = kadd + item_par * A3_TMAX + half * 256 + 4 * g;     // + 32 kt + 16 kb: the lane's four keys of a block
-            int kt_end = nkt - half * 8 < NKT ? nkt - half * 8 : NKT;
+            const char* Kb = smem + (ph & 1) * HALF;
+            const float* kad = kadd + item_par * KN + half * 256 + 4 * g;     // + 32 kt + 16 kb: the lane's four keys of a block
+            const int kt_lim = (XT && last_half) ? 9 : 8;
+            int kt_end = nkt - half * 8 < kt_lim ? nkt - half * 8 : kt_lim;
             const char* kp[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) kp[s] = Kb + c * 128 + (((4 * s + g) ^ ((c >> 1) & 7)) << 4);
             // bias run of (key tile k, key block b, query block n): floats tab[e0 + 16 (2k + b - n) + 0..3], e0 = 4g - (Q0 + c) + (Tn - 1) + 256 half
             const int e0 = 4 * g - (Q0 + c) + (Tn - 1) + 256 * half;
             const float* tp = tab + (e0 & 3) * A3_TLD + A3_TPAD + (e0 & ~3);
-            const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + A3_KBUF + v_lane);
+            const unsigned vaddr = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)(Kb + KBUF + v_lane);
 
             if (ATT3_STAGGER > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(ATT3_STAGGER);
             v8 kf[2][2];                                 // [k-step][key block]
@@ -649,6 +671,7 @@ __global__ __launch_bounds__(512) void attention3_kernel(const T* __restrict__ q
             if (6 < kt_end) tile(a3_ic<6>{});
             A3_PT(10)
             if (7 < kt_end) tile(a3_ic<7>{});
+            if constexpr (XT) { if (8 < kt_end) tile(a3_ic<8>{}); }
 #undef A3_FENCE
         }
         if (do_dma) {
@@ -691,13 +714,18 @@ int launch3(const void* qkv, int B, int Tn, int H, const float* bias_tab, const 
     const int n_units = B * H;
     const int per_block = (n_units + n_wg - 1) / n_wg;
     const int grid = (n_units + per_block - 1) / per_block;
-    if (bias_tab) {
+    const int Tq = Tn < A3_TMAX ? Tn : A3_TMAX;
+    if (Tn > A3_TMAX) {
+        AVX_ENSURE_LDS((attention3_kernel<T, false, true>), ATT3X_LDS);
+        hipLaunchKernelGGL((attention3_kernel<T, false, true>), dim3(grid), dim3(512), ATT3X_LDS, s, (const T*)qkv, Tn, Tq, H, B, per_block, bias_tab, grep_w,
+                           grep_b, grep_a, key_pad, (T*)out, q_log2e);
+    } else if (bias_tab) {
         AVX_ENSURE_LDS((attention3_kernel<T, true>), ATT3_LDS);
-        hipLaunchKernelGGL((attention3_kernel<T, true>), dim3(grid), dim3(512), ATT3_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab, grep_w, grep_b,
+        hipLaunchKernelGGL((attention3_kernel<T, true>), dim3(grid), dim3(512), ATT3_LDS, s, (const T*)qkv, Tn, Tq, H, B, per_block, bias_tab, grep_w, grep_b,
                            grep_a, key_pad, (T*)out, q_log2e);
     } else {
         AVX_ENSURE_LDS((attention3_kernel<T, false>), ATT3_LDS);
-        hipLaunchKernelGGL((attention3_kernel<T, false>), dim3(grid), dim3(512), ATT3_LDS, s, (const T*)qkv, Tn, H, B, per_block, bias_tab, grep_w, grep_b,
+        hipLaunchKernelGGL((attention3_kernel<T, false>), dim3(grid), dim3(512), ATT3_LDS, s, (const T*)qkv, Tn, Tq, H, B, per_block, bias_tab, grep_w, grep_b,
                            grep_a, key_pad, (T*)out, q_log2e);
     }
     AVX_LAUNCH_CHECK();
@@ -708,10 +736,11 @@ int launch3(const void* qkv, int B, int Tn, int H, const float* bias_tab, const 
 
 namespace avx {
 
-// Variant 3 (T <= 512): called by avx::attention (attention.hip), which has validated the arguments.
+// Variant 3: called by avx::attention (attention.hip), which has validated the arguments.  T <= 512: the whole product.  512 < T <= 544 without a
+// bias table (EAT's 513 tokens): query rows 0 .. 511 against all T keys (nine-tile last phase); the caller computes the rows beyond with the tail kernel.
 int attention16(const void* qkv, int B, int T, int H, const float* bias_tab, const float* grep_w, const float* grep_b, const float* grep_a,
                 const uint8_t* key_pad, void* out, int dtype, int q_log2e, int n_wg, hipStream_t s) {
-    AVX_REQUIRE(T > 0 && T <= A3_TMAX, "attention16: T=%d tokens (1..512)", T);
+    AVX_REQUIRE(T > 0 && (T <= A3_TMAX || (T <= A3_TMAX + 32 && !bias_tab)), "attention16: T=%d tokens (1..512, or up to 544 without a bias table)", T);
     AVX_REQUIRE((int64_t)B * H < (1ll << 31), "attention16: too many (clip, head) items");
     if (dtype == AVEXHIP_F16) return launch3<_Float16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, q_log2e, n_wg, s);
     if (dtype == AVEXHIP_BF16) return launch3<__bf16>(qkv, B, T, H, bias_tab, grep_w, grep_b, grep_a, key_pad, out, q_log2e, n_wg, s);

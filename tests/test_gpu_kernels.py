@@ -588,7 +588,17 @@ def test_attention_long_clips(built_lib, T, grid, monkeypatch):
         out2 = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None)
         monkeypatch.delenv("AVEX_AMD_ATT_NO_TAIL")
         o1, o2 = out.float().cpu().numpy().reshape(B, T, E), out2.float().cpu().numpy().reshape(B, T, E)
-        assert np.array_equal(o1[:, :T - T % 512], o2[:, :T - T % 512])                 # the main blocks are untouched by the split
+        # With the tail, the main block of a clip of up to 544 tokens runs on variant 3's nine-tile form (round 5), without it on variant 2's
+        # query blocks: two kernels, agreement to the tolerance; beyond 544 tokens both paths are variant 2 and the main blocks are bit-identical
+        if T <= 544:
+            assert rel_l2(o1[:, :T - T % 512], o2[:, :T - T % 512]) < 1.5e-3
+            monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", "2")                           # the same split on variant 2: bit for bit
+            monkeypatch.setenv("AVEX_AMD_ATT_TAIL_ROWS", "32")
+            o3 = K.attention(_dev(qkv, torch.float16), B, T, H, None, None, None, None).float().cpu().numpy().reshape(B, T, E)
+            monkeypatch.delenv("AVEX_AMD_ATT_VARIANT"); monkeypatch.delenv("AVEX_AMD_ATT_TAIL_ROWS")
+            assert np.array_equal(o3[:, :T - T % 512], o2[:, :T - T % 512])
+        else:
+            assert np.array_equal(o1[:, :T - T % 512], o2[:, :T - T % 512])             # the main blocks are untouched by the split
         assert rel_l2(o1[:, T - T % 512:], o2[:, T - T % 512:]) < 1.5e-3
 
 
