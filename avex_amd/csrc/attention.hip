@@ -1122,33 +1122,55 @@ __global__ __launch_bounds__(256) void attention_tail_kernel(const T* __restrict
 #pragma unroll
     for (int r = 0; r < RW; ++r) l[r] = (part[RW * 4 + r * 4] + part[RW * 4 + r * 4 + 1]) + (part[RW * 4 + r * 4 + 2] + part[RW * 4 + r * 4 + 3]);
     __syncthreads();                                         // `part` is reused for the partial outputs
-    // P V: wave w takes keys [w Tq, (w + 1) Tq), lanes on the output dimension
+    // P V: wave w takes keys [w Tq, (w + 1) Tq).  A lane owns 8 consecutive output columns (16-byte V loads) of every eighth key of the wave's range:
+    // one wave instruction fetches eight whole V rows (1 KiB), eight of them in flight per lane.  (Round 5: with the lanes on the 64 output columns a
+    // wave instruction fetched ONE row -- 2 bytes per lane, 128 wave loads per wave behind each other at 16 in flight: 16 of the kernel's ~30 us per
+    // workgroup, and the tail kernel is a fifth of EAT's attention.)  The eight key-subsets of a wave are added with lane exchanges, the four waves
+    // through `part` as before.
     const int Tq = (Tn + 3) >> 2;
     const int j0 = wave * Tq, j1 = (j0 + Tq) < Tn ? (j0 + Tq) : Tn;
-    const T* vcol = base + 2 * E + lane;
-    float o[RW][4];
+    const int ks = lane >> 3, dc = lane & 7;
+    typedef typename Half<T>::v8 v8t;
+    const T* vbase = base + 2 * E + 8 * dc;
+    float o[RW][8];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) { o[r][0] = 0.f; o[r][1] = 0.f; o[r][2] = 0.f; o[r][3] = 0.f; }
-    int j = j0;
-#pragma unroll 4
-    for (; j + 4 <= j1; j += 4) {      // (16 V loads in flight per lane: one load per trip made the loop latency-bound)
-        const float v0 = (float)vcol[(int64_t)j * ld], v1 = (float)vcol[(int64_t)(j + 1) * ld];
-        const float v2 = (float)vcol[(int64_t)(j + 2) * ld], v3 = (float)vcol[(int64_t)(j + 3) * ld];
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            o[r][0] = __builtin_fmaf(sc[r * Tn + j], v0, o[r][0]);
-            o[r][1] = __builtin_fmaf(sc[r * Tn + j + 1], v1, o[r][1]);
-            o[r][2] = __builtin_fmaf(sc[r * Tn + j + 2], v2, o[r][2]);
-            o[r][3] = __builtin_fmaf(sc[r * Tn + j + 3], v3, o[r][3]);
+        for (int e = 0; e < 8; ++e) o[r][e] = 0.f;
+    for (int jj = j0; jj < j1; jj += 64) {                   // eight 8-key groups per trip
+        v8t vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int key = jj + 8 * u + ks;
+            key = key < j1 ? key : j1 - 1;                   // (clamped: its probability is taken as 0 below)
+            vv[u] = *(const v8t*)(vbase + (int64_t)key * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int key = jj + 8 * u + ks;
+            const bool on = key < j1;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float pj = on ? sc[r * Tn + key] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[r][e] = __builtin_fmaf(pj, (float)vv[u][e], o[r][e]);
+            }
         }
     }
-    for (; j < j1; ++j) {
-        const float v0 = (float)vcol[(int64_t)j * ld];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) o[r][0] = __builtin_fmaf(sc[r * Tn + j], v0, o[r][0]);
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = o[r][e];
+            x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+            o[r][e] = x;
+        }
+    if (ks == 0) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[(wave * RW + r) * 64 + 8 * dc + e] = o[r][e];      // (`part` is only 4-byte aligned: its offset depends on Tn)
     }
-#pragma unroll
-    for (int r = 0; r < RW; ++r) part[(wave * RW + r) * 64 + lane] = (o[r][0] + o[r][1]) + (o[r][2] + o[r][3]);
     __syncthreads();
     for (int r = wave; r < RW; r += 4) {
         if (T0 + grp * RW + r < T0 + R) {
