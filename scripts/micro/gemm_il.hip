@@ -24,6 +24,9 @@
 #ifndef IL_KO
 #define IL_KO 0          // knock-outs: 1 no stores, 2 no epilogue arithmetic, 4 no lane swaps, 8 no MODE toggles, 16 no fences
 #endif
+#ifndef IL_ST_AUX
+#define IL_ST_AUX 2      // cache policy of the output stores: 2 = nt (the product kernel's), 0 = default
+#endif
 
 constexpr int BK = 64, NK = 12, K = NK * BK;
 constexpr int STAGE = 49152;                   // W half-tile 128 rows (16 KiB) + X tile 256 rows (32 KiB)
@@ -57,12 +60,17 @@ constexpr int NS = 14, NT = 5, CH_STEPS = 4 * NS + NT, PASS_STEPS = 4 * CH_STEPS
 constexpr int NSLOT = NK * 32;                                                          // 384 MFMAs per pass
 constexpr int step_lo(int slot) { return (int)(((long long)slot * PASS_STEPS) / NSLOT); }
 // the stores of chunk c are step c * 61 + 60: the MFMA slot that carries it, and from it the K-tile whose MFMA segment issues them
+#ifndef IL_DEFER
+#define IL_DEFER 0       // 1: the stores of chunks 0 - 2 leave at the START of the next K-tile's MFMA segment (slot 96 (c + 1) + 2) instead of at the end of
+#endif                   //    their own (the counted waits are in order: a store must be acknowledged by the second wait behind it).  MEASURED: 617 against 612 us, no gain
 constexpr int store_slot(int c) {
+    if (IL_DEFER && c < 3) return 96 * (c + 1) + 2;
     const int s = c * CH_STEPS + CH_STEPS - 1;
     int q = 0;
     while (!(step_lo(q) <= s && s < step_lo(q + 1))) ++q;
     return q;
 }
+constexpr bool is_deferred_store(int s) { return IL_DEFER && s % CH_STEPS == CH_STEPS - 1 && s / CH_STEPS < 3; }
 constexpr bool stores_in_ktile(int kt) {
     for (int c = 0; c < 4; ++c)
         if (store_slot(c) / 32 == kt) return true;
@@ -72,7 +80,7 @@ constexpr bool stores_in_ktile(int kt) {
 struct PassCoord { int m0, n0; };
 
 __global__ __launch_bounds__(512) void il_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W, _Float16* __restrict__ out,
-                                                 const float* __restrict__ bias, int M, int N, unsigned long long* __restrict__ clk) {
+                                                 const float* __restrict__ bias, int M, int N, unsigned long long* __restrict__ clk, int ring_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef f16x8 v8;
     const int tid = threadIdx.x;
@@ -249,14 +257,14 @@ __global__ __launch_bounds__(512) void il_kernel(const _Float16* __restrict__ A,
                     for (int h = 0; h < 2; ++h) {
                         pin(hA[2 * h]);
                         const i32x4_st d = {(int)hA[2 * h], (int)hB[2 * h], (int)hA[2 * h + 1], (int)hB[2 * h + 1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(d, rs, st_voff + 64 * h, j * (16 * N * 2), 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rs, st_voff + 64 * h, j * (16 * N * 2), IL_ST_AUX);
                     }
                 }
             }
         }
     };
     auto out_rsrc = [&](int em0, int en0) __attribute__((always_inline)) -> __amdgpu_buffer_rsrc_t {
-        const uint64_t a = (uint64_t)(out + (int64_t)(em0 + 64 * wn) * N + en0 + 64 * wm);
+        const uint64_t a = (uint64_t)(out + (int64_t)(em0 % ring_rows + 64 * wn) * N + en0 + 64 * wm);      // ring_rows = M: the plain output; fewer: the same rows over and over (does the Infinity Cache absorb the stores?)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a)),
                                                  0, 64 * N * 2, 0x00020000);
     };
@@ -299,9 +307,12 @@ __global__ __launch_bounds__(512) void il_kernel(const _Float16* __restrict__ A,
             // K-tile kt + 1 (requested one K-tile ago) must have landed; what may stay in flight: this K-tile's 6 DMAs and the stores that the
             // MFMA segment between the two requests issued (younger than the request that is waited for)
             {
-                constexpr bool sprev = drain && !(IL_KO & 1) && stores_in_ktile((kt + NK - 1) % NK) && kt != 0;
-                if constexpr (sprev) VMCNT(8);
-                else VMCNT(6);
+                constexpr bool sprev = drain && !(IL_KO & 1) && stores_in_ktile((kt + NK - 1) % NK);
+                if constexpr (sprev && kt != 0) VMCNT(8);
+                else if constexpr (sprev) {      // K-tile 0: the stores are those of the pass before, which drained if it was not the first
+                    if (pp >= 2) VMCNT(8);
+                    else VMCNT(6);
+                } else VMCNT(6);
             }
             LGKM0();
             BAR();
@@ -315,7 +326,10 @@ __global__ __launch_bounds__(512) void il_kernel(const _Float16* __restrict__ A,
                 if constexpr (drain) {
                     constexpr int slot_id = 32 * kt + q;
                     FENCE();
-                    static_for<step_lo(slot_id), step_lo(slot_id + 1)>([&](auto S) __attribute__((always_inline)) { estep(IC<other>{}, S, en0, rs); });
+                    static_for<step_lo(slot_id), step_lo(slot_id + 1)>([&](auto S) __attribute__((always_inline)) {
+                        if constexpr (!is_deferred_store(decltype(S)::value)) estep(IC<other>{}, S, en0, rs);
+                    });
+                    if constexpr (IL_DEFER && slot_id % 96 == 2 && slot_id >= 96) estep(IC<other>{}, IC<(slot_id / 96) * CH_STEPS - 1>{}, en0, rs);
                     FENCE();
                 }
             });
@@ -342,14 +356,14 @@ __global__ __launch_bounds__(512) void il_kernel(const _Float16* __restrict__ A,
     }
 }
 
-static double run(const _Float16* A, const _Float16* W, _Float16* out, const float* bias, int M, int N, unsigned long long* clk, int iters, double* ghz) {
+static double run(const _Float16* A, const _Float16* W, _Float16* out, const float* bias, int M, int N, unsigned long long* clk, int iters, double* ghz, int ring) {
     CK(hipFuncSetAttribute((const void*)il_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(il_kernel, dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk);      // clocks settle under load
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(il_kernel, dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk, ring);      // clocks settle under load
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(il_kernel, dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(il_kernel, dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk, ring);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -366,6 +380,7 @@ int main(int argc, char** argv) {
     const bool check = argc > 1 && !strcmp(argv[1], "check");
     const int M = check ? 8192 : 126976, N = 3072;      // check: 384 tiles on 256 workgroups, one or two tiles each
     const int iters = (!check && argc > 1) ? atoi(argv[1]) : 200;
+    const int ring = (!check && argc > 2) ? atoi(argv[2]) : M;      // second argument: output rows wrap at this many (a multiple of 256)
     _Float16 *A, *W, *out;
     float* bias;
     unsigned long long* clk;
@@ -385,7 +400,7 @@ int main(int argc, char** argv) {
     if (check) {
         CK(hipMemset(out, 0xff, (size_t)M * N * 2));
         CK(hipFuncSetAttribute((const void*)il_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        hipLaunchKernelGGL(il_kernel, dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk);
+        hipLaunchKernelGGL(il_kernel, dim3(256), dim3(512), LDS_BYTES, 0, A, W, out, bias, M, N, clk, M);
         CK(hipDeviceSynchronize());
         std::vector<_Float16> ho((size_t)M * N);
         CK(hipMemcpy(ho.data(), out, ho.size() * 2, hipMemcpyDeviceToHost));
@@ -429,7 +444,8 @@ int main(int argc, char** argv) {
     const double flop = 2.0 * M * N * K;
     for (int rep = 0; rep < 3; ++rep) {
         double g;
-        const double us = run(A, W, out, bias, M, N, clk, iters, &g);
+        const double us = run(A, W, out, bias, M, N, clk, iters, &g, ring);
+        if (ring != M) printf("(output rows wrap at %d: %.0f MB) ", ring, (double)ring * N * 2 / 1e6);
         printf("IL_KO %d: two passes of 128 x 256, the epilogue between the next pass's MFMAs: %7.1f us (%6.1f TFLOP/s, %.3f GHz)\n", IL_KO, us, flop / us / 1e6, g);
     }
     return 0;
