@@ -172,8 +172,9 @@ int avexhip_flac_decode_i32(const avexhip_flac* h, int32_t* out_dev, int left_ju
 /* First layer of the wav2vec2 / AVES convolutional feature extractor (avex/models/aves_model.py:25-33,86 ->
  * torchaudio wav2vec2 ConvLayerBlock 0, extractor_mode "group_norm", no conv bias):
  *   Conv1d(1, 512, k=10, s=5) -> GroupNorm(512, 512, eps) over time per (clip, channel) -> GELU
- * wav_dev [B, T] fp32; w_dev [512, 10] fp32; gn_w/gn_b [512]; stats_dev: avexhip_wavconv0_stats_floats(B, T) floats of scratch
- * (per-workgroup partial sums, combined in a fixed order: results are bit-reproducible);
+ * wav_dev [B, T] fp32; w_dev [512, 10] fp32; gn_w/gn_b [512]; stats_dev: avexhip_wavconv0_stats_floats(B, T) floats of scratch,
+ * 8-byte aligned (the clip's 65 second-order moments per 1 024-frame block in fp64 -- the layer is linear, so every channel's mean and
+ * variance follow from them -- combined in a fixed order: results are bit-reproducible -- and the 512 (scale, shift) pairs per clip);
  * out_dev [B, frames_pad, 512] half (rows >= frames are zero).  The other six conv layers are strided-row
  * avexhip_gemm calls (A row t of clip b = frames s*t .. s*t+k-1 of the previous layer: lda = s * 512, K = k * 512). */
 int avexhip_wavconv0_frames(int64_t T);

@@ -737,6 +737,33 @@ def test_wavconv0_matches_oracle(built_lib):
     assert np.all(got[:, F:] == 0)
 
 
+def test_wavconv0_statistics_survive_a_dc_offset_and_a_long_clip(built_lib):
+    """The layer's GroupNorm statistics come from 65 second-order moments of the clip (the layer is linear in the waveform).  The hard case for
+    that route: filters that cancel most of their input -- every channel's taps sum to zero -- on a clip that is almost all offset, so a
+    channel's sum of squares is ~1e-7 of the moments it is computed from; 10 s of audio so that the moments run over 32 k frames."""
+    from avex_amd import kernels as K
+    rng = np.random.default_rng(8)
+    T = 160000
+    x = (0.5 + 1e-3 * rng.standard_normal((2, T))).astype(np.float32)
+    x[1] *= -1.0
+    w = rng.standard_normal((512, 10)).astype(np.float32)
+    w -= w.mean(axis=1, keepdims=True)                                          # zero DC gain, up to fp32 rounding of the taps
+    g = (1.0 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    F = (T - 10) // 5 + 1
+    idx = 5 * np.arange(F)[:, None] + np.arange(10)[None, :]
+    y = x.astype(np.float64)[:, idx] @ w.astype(np.float64).T                    # [2, F, 512]
+    mean, var = y.mean(axis=1, keepdims=True), y.var(axis=1, keepdims=True)
+    assert np.sqrt(var).max() < 1e-2                                            # the outputs really are tiny beside the 0.5 offset
+    z = (y - mean) / np.sqrt(var + 1e-5) * g + b
+    from scipy.special import erf
+    ref = 0.5 * z * (1.0 + erf(z / np.sqrt(2.0)))
+    out = K.wavconv0(_dev(x), _dev(w), _dev(g), _dev(b), frames_pad=F + 3)
+    got = out[:2 * (F + 3)].view(2, F + 3, 512).float().cpu().numpy()
+    assert rel_l2(got[:, :F], ref) < 6e-4
+    assert np.abs(got[:, :F] - ref).max() < 4e-3                               # f16 rounding of values up to ~4
+
+
 @pytest.mark.parametrize("samples", [16000, 40000])
 def test_aves_encoder_matches_oracle(built_lib, samples):
     """Conv feature extractor as strided-row GEMMs + the transformer on the shared kernels vs the NumPy restatement
