@@ -42,7 +42,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         # Two timeouts.  The rendezvous and the first barrier get a short one: a rank that never arrives fails the job instead of hanging it.
         # The working group gets a long one (torch's own default is 10 minutes): its timeout applies to EVERY collective, and a rank may
         # legitimately spend minutes between two gathers (a first-use build of the extension, a slow dataloader).
-        t_rdv = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "180")))
+        t_rdv = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "300")))
         t_run = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_COLLECTIVE_TIMEOUT_S", "1800")))
         if backend == "nccl":
             torch.cuda.set_device(local_rank)

@@ -424,7 +424,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_DEBUG", "WARN")                   # RCCL's warnings go to stderr: the launcher keeps the tail of every rank's
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts
-        timeout = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "180")))
+        timeout = datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_TIMEOUT_S", "300")))
         try:
             if dry:
                 dist.init_process_group(backend="gloo", timeout=timeout)
