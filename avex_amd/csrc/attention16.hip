@@ -59,6 +59,9 @@ constexpr float A3_THR = 8.f;                             // deferred reference:
 constexpr float A3_SUM_HI = 4096.f;                       // a half-row sum below 2^12 proves every numerator of the lane is below 2^12
 constexpr float A3_SUM_LO = 0.015625f;                    // first tile: a sum above 2^-6 means the row's numerators are not all deep in the subnormals
 
+#ifndef ATT3_DMA_NT
+#define ATT3_DMA_NT 0    // 1: the K / V LDS-DMA with the nt policy (every byte is read by one workgroup, once).  MEASURED: level (256-clip step 24.910 vs 24.903 ms in one process)
+#endif
 #ifndef ATT3_PRIO
 #define ATT3_PRIO 1      // 1: waves 4-7 at s_setprio 1 (one static raise); 2: waves 0-3 instead; 0: none
 #endif
@@ -103,7 +106,11 @@ static __device__ __forceinline__ float a3_rows_max(float x) {
 static __device__ __forceinline__ void a3_dma16(const void* src, const char* lds_dst) {
     // (inline assembly on purpose: see a2_dma16 in attention.hip -- behind the builtin the compiler drains vmcnt in front of every LDS read)
     const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)lds_dst;
+#if ATT3_DMA_NT
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(src), "s"(lds) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+#endif
 }
 
 template <typename T, bool BIAS, bool XT = false>
