@@ -737,6 +737,36 @@ def test_wavconv0_matches_oracle(built_lib):
     assert np.all(got[:, F:] == 0)
 
 
+def _wavconv0_reference(x, w, g, b):
+    """Conv1d(1, 512, 10, stride 5) -> GroupNorm over time per (clip, channel), eps 1e-5 -> erf GELU, in fp64."""
+    from scipy.special import erf
+    F = (x.shape[1] - 10) // 5 + 1
+    idx = 5 * np.arange(F)[:, None] + np.arange(10)[None, :]
+    y = x.astype(np.float64)[:, idx] @ w.astype(np.float64).T
+    z = (y - y.mean(axis=1, keepdims=True)) / np.sqrt(y.var(axis=1, keepdims=True) + 1e-5) * g + b
+    return 0.5 * z * (1.0 + erf(z / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("T", [10, 14, 15, 5125, 5130, 10250])      # 1, 1, 2 frames; 1 024 frames (one block), 1 025; two blocks and one frame
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_wavconv0_block_edges(built_lib, T, dtype):
+    from avex_amd import kernels as K
+    rng = np.random.default_rng(T)
+    x = (0.1 * rng.standard_normal((3, T)) + 0.01).astype(np.float32)
+    w = (0.3 * rng.standard_normal((512, 10))).astype(np.float32)
+    g = (1.0 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    ref = _wavconv0_reference(x, w, g, b)
+    F = ref.shape[1]
+    out = K.wavconv0(_dev(x), _dev(w), _dev(g), _dev(b), frames_pad=F + 5, dtype=dtype)
+    got = out[:3 * (F + 5)].view(3, F + 5, 512).float().cpu().numpy()
+    tol = 6e-4 if dtype == "f16" else 5e-3
+    assert np.abs(got[:, :F] - ref).max() <= tol * max(1.0, np.abs(ref).max()) * 4
+    if F > 1:
+        assert rel_l2(got[:, :F], ref) < tol
+    assert np.all(got[:, F:] == 0)
+
+
 def test_wavconv0_statistics_survive_a_dc_offset_and_a_long_clip(built_lib):
     """The layer's GroupNorm statistics come from 65 second-order moments of the clip (the layer is linear in the waveform).  The hard case for
     that route: filters that cancel most of their input -- every channel's taps sum to zero -- on a clip that is almost all offset, so a
