@@ -229,11 +229,47 @@ __device__ __forceinline__ void stockham_pass_ct(const float2* __restrict__ in, 
     }
 }
 
+// The same pass IN PLACE (round 5): a wave's LDS instructions execute in order and this form issues every read of the pass before its first
+// write, so one N-point buffer per wave is enough -- the ping-pong partner was 25 KB of the workgroup's 79 KB and held the kernel to two
+// workgroups (two waves per SIMD) per CU for a chain of dependent LDS round trips.  Same operations in the same order: the same bits.
+template <int R, int N, int Ns>
+__device__ __forceinline__ void stockham_pass_ip(float2* buf, const float2* __restrict__ tw, int lane) {
+    constexpr int M = N / R, step = N / (Ns * R), NIT = (M + 63) / 64;
+    float2 v[NIT][R];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j = lane + 64 * it;
+        if (M % 64 == 0 || j < M) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[it][t] = buf[j + t * M];
+        }
+    }
+    asm volatile("" ::: "memory");                       // (compiler) no read of the buffer moves below this line
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j = lane + 64 * it;
+        if (M % 64 == 0 || j < M) {
+            const int k = j % Ns;
+            if (Ns > 1) {
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[it][t] = c_mul(v[it][t], tw[t * k * step]);
+            }
+            if (R == 2) dft2(v[it]); else if (R == 3) dft3(v[it]); else if (R == 4) dft4(v[it]); else dft5(v[it]);
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) buf[j0 + t * Ns] = v[it][t];
+        }
+    }
+}
+
 // STFT power spectra by FFT: every wave transforms frame PAIRS packed as one complex sequence (x_a + i x_b), 4 pairs per wave,
 // FB = 8 * waves frames per workgroup.  A wave finishes its two frames on its own -- power spectra into the idle half of its
 // ping-pong buffer, mel (CSR) / log into a [bin][frame] staging tile -- so the only workgroup-wide step is the final coalesced store
 // of that tile (128-byte rows of [clip][bin][frame]) with the per-clip min / max.  LDS: twiddles 8 N + 16 N per wave + the staging
-// tile (n_out x (FB + 1) floats): 74 KB for the EfficientNet setting (800 points, 128 mels), two workgroups per CU.
+// tile (n_out x (FB + 1) floats): 74 KB for the EfficientNet setting (800 points, 128 mels), two workgroups per CU -- with the run-time
+// passes.  The compiled-in 800-point passes run IN PLACE (stockham_pass_ip, round 5): 8 N per wave, 49 + 5 KB with the mel bank, THREE
+// workgroups (three waves per SIMD; the kernel takes 153 registers) per CU for what is a chain of dependent LDS round trips:
+// 0.80 -> 0.61 ms per 256 clips, the same bits.
 #ifndef STFT_KNOCK
 #define STFT_KNOCK 0      // diagnostic builds: bit 0 no FFT passes, bit 1 no spectrum split, bit 2 no mel / log stage, bit 3 no sample loads (timing only, wrong results)
 #endif
@@ -246,8 +282,10 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
     const int N = md.n_fft, nf = N / 2 + 1;
     const int b = blockIdx.y, f0 = blockIdx.x * FB;
     float2* tw = (float2*)smem;                                   // [N]
-    float2* buf = tw + N + (size_t)wave * 2 * N;                  // this wave's ping-pong buffers
-    float* stage = (float*)(tw + N + (size_t)NW * 2 * N);         // [n_out][FB + 1]
+    constexpr bool INPL = NF == 800;                              // compiled-in passes run in place: one buffer per wave
+    constexpr int NBUF = INPL ? 1 : 2;
+    float2* buf = tw + N + (size_t)wave * NBUF * N;               // this wave's buffer(s): ping-pong for the run-time passes
+    float* stage = (float*)(tw + N + (size_t)NW * NBUF * N);      // [n_out][FB + 1]
     for (int i = tid; i < ((STFT_KNOCK & 16) ? 0 : N); i += FB * 8) tw[i] = md.tw[i];
     // mel bank in LDS (planner: mel_lds): [n_out] start, [n_out] length, [n_out] offset, [nnz] weights
     int* lb = (int*)(stage + (size_t)md.n_out * SLD);
@@ -263,7 +301,7 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
     for (int pr = 0; pr < 4; ++pr) {
         const int fl = wave * 8 + 2 * pr, fa = f0 + fl;           // frames fa, fa + 1 (block-local fl, fl + 1)
         float2* A = buf;
-        float2* Bf = buf + N;
+        float2* Bf = INPL ? buf : buf + N;
         // window, reflect padding (torch.stft center=True), pack
         const int64_t base = (int64_t)fa * md.hop - (md.center ? N / 2 : 0);
         bool nza = false, nzb = false;                            // an all-zero frame beside a loud partner: see fbank.hip
@@ -312,17 +350,16 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
         const bool live_a = __any(nza), live_b = __any(nzb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private buffers: a wave's LDS operations execute in order
         if constexpr (NF == 800 && !(STFT_KNOCK & 1)) {
-            stockham_pass_ct<5, 800, 1>(A, Bf, tw, lane);
+            stockham_pass_ip<5, 800, 1>(A, tw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stockham_pass_ct<5, 800, 5>(Bf, A, tw, lane);
+            stockham_pass_ip<5, 800, 5>(A, tw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stockham_pass_ct<4, 800, 25>(A, Bf, tw, lane);
+            stockham_pass_ip<4, 800, 25>(A, tw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stockham_pass_ct<4, 800, 100>(Bf, A, tw, lane);
+            stockham_pass_ip<4, 800, 100>(A, tw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stockham_pass_ct<2, 800, 400>(A, Bf, tw, lane);
+            stockham_pass_ip<2, 800, 400>(A, tw, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            float2* t_ = A; A = Bf; Bf = t_;             // five passes: the spectrum is in the second buffer
         }
         int Ns = 1;
         for (int p = 0; p < (NF ? 0 : md.n_pass); ++p) {
@@ -335,9 +372,30 @@ __global__ __launch_bounds__(FB * 8) void stft_fft_kernel(MelDev md, const float
             float2* t_ = A; A = Bf; Bf = t_;
             Ns *= R;
         }
-        // split the two real spectra (conjugate symmetry); their power goes to the idle buffer (2 N floats >= 2 (N/2 + 2))
+        // split the two real spectra (conjugate symmetry); their power goes to the idle buffer (2 N floats >= 2 (N/2 + 2)) -- in place: over
+        // the spectrum itself, every bin pair of the lane read before the first power is written (the same in-order argument as the passes)
         float* pa = (float*)Bf;
         float* pb = pa + nf + 1;
+        if constexpr (INPL) {
+            constexpr int NKI = (800 / 2 + 1 + 63) / 64;
+            float2 zk[NKI], zn[NKI];
+#pragma unroll
+            for (int i = 0; i < NKI; ++i) {
+                const int k = lane + 64 * i;
+                if (k < nf && !(STFT_KNOCK & 2)) { zk[i] = A[k]; zn[i] = A[k == 0 ? 0 : N - k]; }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NKI; ++i) {
+                const int k = lane + 64 * i;
+                if (k < nf && !(STFT_KNOCK & 2)) {
+                    const float ar = 0.5f * (zk[i].x + zn[i].x), ai = 0.5f * (zk[i].y - zn[i].y);
+                    const float br = 0.5f * (zk[i].y + zn[i].y), bi = -0.5f * (zk[i].x - zn[i].x);
+                    pa[k] = live_a ? ar * ar + ai * ai : 0.f;
+                    pb[k] = live_b ? br * br + bi * bi : 0.f;
+                }
+            }
+        } else
         for (int k = lane; k < ((STFT_KNOCK & 2) ? 0 : nf); k += 64) {
             const float2 zk = A[k], zn = A[k == 0 ? 0 : N - k];
             const float ar = 0.5f * (zk.x + zn.x), ai = 0.5f * (zk.y - zn.y);
@@ -422,7 +480,9 @@ struct avexhip_melspec_plan {
     avexhip_melspec_config cfg;
     MelDev dev;
     void* blob = nullptr;
-    size_t lds = 0;
+    size_t lds = 0;          // LDS bytes of the kernel the plan launches by default
+    size_t lds_pp = 0;       // ... of the ping-pong (run-time passes) FFT kernel, when `inplace` selects the in-place one and an A/B run asks for the other
+    bool inplace = false;    // FFT path: the compiled-in 800-point passes, one buffer per wave
     bool fft = false;        // mixed-radix FFT path (n_fft = 2^a 3^b 5^c <= 2048) instead of the dense fp32-MFMA product
 };
 
@@ -524,11 +584,13 @@ extern "C" avexhip_melspec_plan* avexhip_melspec_plan_create(const avexhip_melsp
     const int xs_words = nseg + (md.skew ? nseg / hop + 1 : 0);
     md.mel_nnz = (int)packed.size(); md.mel_lds = 0;
     if (use_fft) {
-        p->lds = sizeof(float2) * ((size_t)N + (size_t)(md.fb / 8) * 2 * N) + sizeof(float) * (size_t)n_out * (md.fb + 1);
+        p->inplace = md.fb == 32 && N == 800 && radices.size() == 5 && radices[0] == 5 && radices[1] == 5 && radices[2] == 4 && radices[3] == 4 && radices[4] == 2;
+        p->lds_pp = sizeof(float2) * ((size_t)N + (size_t)(md.fb / 8) * 2 * N) + sizeof(float) * (size_t)n_out * (md.fb + 1);
+        p->lds = p->inplace ? p->lds_pp - sizeof(float2) * (size_t)(md.fb / 8) * N : p->lds_pp;
         // the mel bank (CSR: start / length / offset per mel + packed weights, ~5 KB at 128 mels over 401 bins) beside them when the
         // workgroups per CU stay the same: its loads in the mel stage are then LDS reads instead of dependent trips to L1 / L2
         const size_t bank = sizeof(int) * 3 * (size_t)n_out + sizeof(float) * packed.size();
-        if (md.use_mel && (160 * 1024) / (p->lds + bank) == (160 * 1024) / p->lds) { md.mel_lds = 1; p->lds += bank; }
+        if (md.use_mel && (160 * 1024) / (p->lds + bank) == (160 * 1024) / p->lds) { md.mel_lds = 1; p->lds += bank; p->lds_pp += bank; }
     }
     else p->lds = sizeof(float) * (((xs_words + 3) & ~3) + 32 * (size_t)(half + 1));
     if (p->lds > 160 * 1024) { avexhip_set_error("melspec_plan_create: hop=%d n_fft=%d need %zu bytes of LDS", hop, N, p->lds); (void)hipFree(d); delete p; return nullptr; }
@@ -567,13 +629,13 @@ extern "C" int avexhip_melspec_forward(const avexhip_melspec_plan* p, const floa
         const dim3 gridf((frames + FB - 1) / FB, B);
         if (FB == 32) {
             static const bool generic = getenv("AVEX_AMD_STFT_GENERIC") && atoi(getenv("AVEX_AMD_STFT_GENERIC")) != 0;      // A/B: the run-time passes for 800 points too
-            const MelDev& d = p->dev;
-            if (d.n_fft == 800 && d.n_pass == 5 && d.radix[0] == 5 && d.radix[1] == 5 && d.radix[2] == 4 && d.radix[3] == 4 && d.radix[4] == 2 && !generic) {
+            if (p->inplace && !generic) {
                 AVX_ENSURE_LDS((stft_fft_kernel<32, 800>), 160 * 1024);
                 hipLaunchKernelGGL((stft_fft_kernel<32, 800>), gridf, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
             } else {
+                AVX_REQUIRE(p->lds_pp <= 160 * 1024, "melspec_forward: the run-time FFT passes need %zu bytes of LDS", p->lds_pp);
                 AVX_ENSURE_LDS(stft_fft_kernel<32>, 160 * 1024);
-                hipLaunchKernelGGL(stft_fft_kernel<32>, gridf, dim3(256), p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
+                hipLaunchKernelGGL(stft_fft_kernel<32>, gridf, dim3(256), p->inplace ? p->lds_pp : p->lds, s, p->dev, wav_dev, T, wav_stride, frames, out_dev, mm, take_log);
             }
         } else {
             AVX_ENSURE_LDS(stft_fft_kernel<16>, 160 * 1024);
