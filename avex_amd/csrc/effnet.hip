@@ -725,8 +725,12 @@ struct DwArgs {
     int tiles_x, chunks_per_wg;
 };
 
-template <typename T, int KS, int ST, int TH, int TW, int PIX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dwconv_lds_kernel(const DwArgs p) {
+// NSLOT 1 (round 5): a workgroup that owns ONE 32-channel chunk (the first block: 32 channels in all) has nothing to request ahead and
+// no use for the second tile buffer (nor for the registers that hold a requested chunk: 114 instead of 190); with nothing pipelined
+// inside a workgroup the other workgroups of the CU are all that covers its loads, and without the second buffer four fit instead of
+// two: the first block's depthwise kernel 333 -> 259 us (three waves per SIMD) -> 230 us (four; five spill) per 256 clips, the same bits.
+template <typename T, int KS, int ST, int TH, int TW, int PIX, int NSLOT = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NSLOT == 1 ? (KS == 3 ? 4 : 3) : 2, NSLOT == 1 ? (KS == 3 ? 4 : 3) : 2))) void dwconv_lds_kernel(const DwArgs p) {
     AVX_F16_SATURATE_ON();
     typedef typename Half<T>::v8 v8;
     typedef MbGeo<KS, ST, 0, TH, TW, 32> G;
@@ -735,9 +739,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int NLD = (NPX * NCG + 255) / 256, NWR = (NWD + 255) / 256;
     static_assert(TW % PIX == 0 && NITEM == 256, "dwconv_lds tile: one item per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_x = smem;                                    // [2][NPX * ESTR]
-    float* s_w = (float*)(smem + 2 * NPX * ESTR);        // [2][NWD]
-    float* s_red = s_w + 2 * NWD;                        // [2][16 * CC]
+    char* s_x = smem;                                    // [NSLOT][NPX * ESTR]
+    float* s_w = (float*)(smem + NSLOT * NPX * ESTR);    // [NSLOT][NWD]
+    float* s_red = s_w + NSLOT * NWD;                    // [NSLOT][16 * CC]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int oy = oy0 + oyl;
     int slot = 0;
     for (int c = c_begin; c < c_end; c += CC, slot ^= 1) {
-        const bool more = c + CC < c_end;
+        const bool more = NSLOT > 1 && c + CC < c_end;
         if (more) request(nx, c + CC);
         float acc[PIX][8];
 #pragma unroll
@@ -873,6 +877,7 @@ int dwl_launch(const DwArgs& a0, int B, int64_t* n_tiles, hipStream_t s) {
     constexpr int TH = ST == 1 ? 8 : 4, TW = ST == 1 ? 32 : 16, PIX = ST == 1 ? 4 : 1;
     typedef MbGeo<KS, ST, 0, TH, TW, 32> G;
     constexpr int LDS = 2 * G::NPX * G::ESTR + 2 * G::NWD * 4 + 2 * 16 * 32 * 4;
+    constexpr int LDS1 = G::NPX * G::ESTR + G::NWD * 4 + 16 * 32 * 4;
     DwArgs a = a0;
     a.tiles_x = (a.Wo + TW - 1) / TW;
     const int64_t tiles = (int64_t)a.tiles_x * ((a.Ho + TH - 1) / TH);
@@ -883,8 +888,15 @@ int dwl_launch(const DwArgs& a0, int B, int64_t* n_tiles, hipStream_t s) {
     split = split < 1 ? 1 : (split > nchunk ? nchunk : split);
     a.chunks_per_wg = (int)((nchunk + split - 1) / split);
     const int gz = (nchunk + a.chunks_per_wg - 1) / a.chunks_per_wg;
-    AVX_ENSURE_LDS((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX>), LDS);
-    hipLaunchKernelGGL((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX>), dim3((unsigned)tiles, B, gz), dim3(256), LDS, s, a);
+    if (a.chunks_per_wg == 1 && ST == 1) {
+        if constexpr (ST == 1) {
+            AVX_ENSURE_LDS((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX, 1>), LDS1);
+            hipLaunchKernelGGL((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX, 1>), dim3((unsigned)tiles, B, gz), dim3(256), LDS1, s, a);
+        }
+    } else {
+        AVX_ENSURE_LDS((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX>), LDS);
+        hipLaunchKernelGGL((dwconv_lds_kernel<T, KS, ST, TH, TW, PIX>), dim3((unsigned)tiles, B, gz), dim3(256), LDS, s, a);
+    }
     AVX_LAUNCH_CHECK();
     return AVEXHIP_OK;
 }
