@@ -729,6 +729,8 @@ struct DwArgs {
 // no use for the second tile buffer (nor for the registers that hold a requested chunk: 114 instead of 190); with nothing pipelined
 // inside a workgroup the other workgroups of the CU are all that covers its loads, and without the second buffer four fit instead of
 // two: the first block's depthwise kernel 333 -> 259 us (three waves per SIMD) -> 230 us (four; five spill) per 256 clips, the same bits.
+// (Workgroups that walk SEVERAL chunks keep the two-buffer form: the one-buffer loop was measured on them too, 8 - 9 % slower --
+// 91 / 90 / 130 / 188 / 190 against 83 / 82 / 115 / 175 / 177 us for the five late depthwise launches.)
 template <typename T, int KS, int ST, int TH, int TW, int PIX, int NSLOT = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NSLOT == 1 ? (KS == 3 ? 4 : 3) : 2, NSLOT == 1 ? (KS == 3 ? 4 : 3) : 2))) void dwconv_lds_kernel(const DwArgs p) {
     AVX_F16_SATURATE_ON();
