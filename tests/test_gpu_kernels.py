@@ -6,6 +6,7 @@ rounded to the operand type, so the CPU side rounds the same inputs first: the r
 difference is fp32 accumulation order (tolerances are written next to each check).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ from avex_amd import synth
 from oracle import beats_oracle as O
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 DTYPES = ["f16", "bf16"]
 
@@ -908,6 +910,29 @@ def test_stft_fft_path_matches_torch_stft(built_lib, n_fft, hop, win, window, ce
     y = K.MelspecPlan(n_fft=n_fft, hop_length=hop, win_length=win, window=window, n_mels=64, center=center, normalize=True)(xd).cpu().numpy()
     ref = O.audio_processor(x, n_fft=n_fft, hop=hop, win_length=win, window=window, n_mels=64, center=center)
     assert y.shape == ref.shape and np.abs(y - ref).max() < 2e-4
+
+
+def test_stft_in_place_passes_give_the_bits_of_the_ping_pong_passes(built_lib, tmp_path):
+    """n_fft 800 (the EfficientNet frontend) runs its compiled-in Stockham passes IN PLACE in one LDS buffer per wave; AVEX_AMD_STFT_GENERIC=1
+    selects the run-time passes with their ping-pong pair.  Same operations in the same order: the log-mel outputs must be bit-identical.
+    (The switch is read once per process: two fresh processes.)"""
+    import subprocess, sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from avex_amd import synth, kernels as K\n"
+        "x = torch.from_numpy(synth.noise_clips(3, 48000, seed=65)).cuda()\n"
+        "y = K.MelspecPlan(n_fft=800, hop_length=320, n_mels=128, normalize=True)(x)\n"
+        "p = K.MelspecPlan(n_fft=800, hop_length=160, mel=False, normalize=False)(x)\n"
+        "np.savez(sys.argv[1], y=y.cpu().numpy(), p=p.cpu().numpy())\n")
+    outs = []
+    for generic in ("0", "1"):
+        o = str(tmp_path / f"g{generic}.npz")
+        r = subprocess.run([sys.executable, "-c", code, o], capture_output=True, text=True, timeout=600, env=dict(os.environ, AVEX_AMD_STFT_GENERIC=generic))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs.append(np.load(o))
+    for k in ("y", "p"):
+        assert np.isfinite(outs[0][k]).all() and np.array_equal(outs[0][k], outs[1][k]), k
 
 
 def test_stft_fft_and_dense_paths_agree(built_lib, monkeypatch):
