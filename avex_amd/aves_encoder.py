@@ -56,8 +56,15 @@ class AvesEncoder:
     and the workspace."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, np.ndarray], operand_dtype: str = "f16", prefix: str = "model.",
-                 max_chunk_clips: int = 0, residual: str = "half", batch_invariant: bool = False) -> None:
+                 max_chunk_clips: int = 0, residual: str = "auto", batch_invariant: bool = False) -> None:
+        """``residual``: ``"half"`` (operand-type residual stream), ``"f32"`` or ``"auto"`` (default; BEATs' policy, beats_model.py here):
+        the fp32 stream for calls that hand back un-averaged rows (features, un-pooled taps: what the reference wrapper's ``forward`` and
+        hooks return, aves_model.py:129-150), the operand-type stream for token-mean outputs only.  Two library handles then, each built
+        on first use."""
         _capi.require_gpu()
+        self.residual = str(residual or "auto").lower()
+        if self.residual != "auto":
+            K.residual_code(self.residual)      # validates
         self.cfg = dict(cfg)
         self.dtype = operand_dtype
         self.convs = [tuple(int(v) for v in c) for c in cfg["extractor_conv_layer_config"]]
@@ -75,16 +82,31 @@ class AvesEncoder:
             c.conv_kernel[i], c.conv_stride[i] = k, st
         c.operand_dtype = _capi.dtype_code(operand_dtype)
         c.max_chunk_clips = int(max_chunk_clips)
-        c.residual_dtype = K.residual_code(residual, batch_invariant)
-        sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
-        arr, n, keep = K.tensor_table(sub)
-        self._h = _capi.lib().avexhip_aves_create(C.byref(c), arr, n)
-        del keep
-        if not self._h:
-            raise K.AvexHipError(f"aves_create failed: {_capi.last_error()}")
+        self._c, self._batch_invariant = c, bool(batch_invariant)
+        self._sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
+        self._handles: Dict[str, int] = {}      # residual mode ("half" / "f32") -> library handle
+        self._profiling = False
+        self._h = self._handle_for(frames=self.residual in ("auto", "f32", "fp32", "float32"))      # a bad checkpoint fails here, not in the first forward
         self._ws: Optional[torch.Tensor] = None
         self._state, self._prefix = state, prefix
         self._conv_weights = None
+
+    def _handle_for(self, frames: bool) -> int:
+        """The handle whose residual stream this call wants (``frames``: it returns un-averaged rows); ``self._h`` = the last one used."""
+        mode = ("f32" if frames else "half") if self.residual == "auto" else ("half" if K.residual_code(self.residual) & 1 else "f32")
+        h = self._handles.get(mode)
+        if h is None:
+            self._c.residual_dtype = K.residual_code(mode, self._batch_invariant)
+            arr, n, keep = K.tensor_table(self._sub)
+            h = _capi.lib().avexhip_aves_create(C.byref(self._c), arr, n)
+            del keep
+            if not h:
+                raise K.AvexHipError(f"aves_create failed: {_capi.last_error()}")
+            self._handles[mode] = h
+            if self._profiling:
+                _capi.check(_capi.lib().avexhip_aves_set_profiling(h, 1), "aves_set_profiling")
+        self._h = h
+        return h
 
     def num_tokens(self, T: int) -> int:
         return conv_frame_plan(T, self.convs)[0][-1]
@@ -128,6 +150,8 @@ class AvesEncoder:
         dev = wav.device
         Tt = self.num_tokens(T)
         E = self.E
+        hook_layers = list(hook_layers)
+        self._handle_for(frames=bool(want_features or (hook_layers and K.pool_code(hook_pooled) != 1)))      # anything but token means
         need = int(_capi.lib().avexhip_aves_workspace_bytes(self._h, B, T))
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = None
@@ -158,20 +182,26 @@ class AvesEncoder:
         return out
 
     def overflow_events(self, sync: bool = True) -> int:
-        n = C.c_uint32(0)
-        _capi.check(_capi.lib().avexhip_aves_overflow_count(self._h, C.byref(n), K._stream(), int(bool(sync))), "aves_overflow_count")
-        return int(n.value)
+        total = 0
+        for h in self._handles.values():
+            n = C.c_uint32(0)
+            _capi.check(_capi.lib().avexhip_aves_overflow_count(h, C.byref(n), K._stream(), int(bool(sync))), "aves_overflow_count")
+            total += int(n.value)
+        return total
 
     def set_profiling(self, enabled: bool) -> None:
-        _capi.check(_capi.lib().avexhip_aves_set_profiling(self._h, int(enabled)), "aves_set_profiling")
+        self._profiling = bool(enabled)
+        for h in self._handles.values():
+            _capi.check(_capi.lib().avexhip_aves_set_profiling(h, int(enabled)), "aves_set_profiling")
 
     def last_profile(self):
         return K.handle_profile(_capi.lib().avexhip_aves_last_profile, self._h)
 
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            _capi.lib().avexhip_aves_destroy(self._h)
-            self._h = None
+        for h in getattr(self, "_handles", {}).values():
+            _capi.lib().avexhip_aves_destroy(h)
+        self._handles = {}
+        self._h = None
         self._ws = None
 
     def __del__(self) -> None:

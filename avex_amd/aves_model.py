@@ -128,8 +128,11 @@ class Model(ModelBase):
 
     def __init__(self, *, num_classes: Optional[int] = None, pretrained: bool = False, device: str = "cuda",
                  audio_config: Optional[Union[AudioConfig, Dict[str, Any]]] = None, operand_dtype: str = "f16",
-                 init_config: Optional[Dict[str, Any]] = None, batch_invariant: Optional[bool] = None) -> None:
+                 init_config: Optional[Dict[str, Any]] = None, batch_invariant: Optional[bool] = None, residual: Optional[str] = None) -> None:
         super().__init__(device=device, audio_config=audio_config)
+        # inter-kernel residual stream, BEATs' policy: "auto" (default) = fp32 stream for calls that hand frames back (every call of this
+        # wrapper does: forward() features and un-pooled taps, aves_model.py:129-150), "half" / "f32" force one (AvesEncoder)
+        self.residual = (residual or os.environ.get("AVEX_AMD_RESIDUAL") or "auto").lower()
         # a clip's outputs bit-identical whatever batch it arrives in (kernels.residual_code; environment: AVEX_AMD_BATCH_INVARIANT=1)
         self.batch_invariant = bool(batch_invariant) if batch_invariant is not None else os.environ.get("AVEX_AMD_BATCH_INVARIANT", "0") not in ("", "0")
         if pretrained:
@@ -168,7 +171,7 @@ class Model(ModelBase):
                 raise AvexHipError(f"AVES parameters live on {p.device}; the avex_amd path runs on a GPU only (no CPU fallback)")
             with torch.cuda.device(p.device):
                 state = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
-                self._encoder = AvesEncoder(self.config.to_dict(), state, operand_dtype=self.operand_dtype, batch_invariant=self.batch_invariant)
+                self._encoder = AvesEncoder(self.config.to_dict(), state, operand_dtype=self.operand_dtype, batch_invariant=self.batch_invariant, residual=self.residual)
             self._weights_dirty = False
         return self._encoder
 

@@ -34,6 +34,17 @@ EXTRA_FLAGS = {"fbank.hip": ["-fno-slp-vectorize"], "wavconv.hip": ["-fno-slp-ve
                "lstm.hip": ["-fno-slp-vectorize"]}
 
 
+def kernel_source_sha16(files=("gemm.hip", "common.h")) -> str:
+    """First 16 hex digits of the SHA-256 over the named csrc files: the identity of a kernel's source, recorded by the PMC summaries
+    under profiles/ so that bench.py can tell whether a committed counter file describes the kernel it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):

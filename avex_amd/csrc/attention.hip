@@ -1183,7 +1183,6 @@ __global__ __launch_bounds__(256) void attention_tail_kernel(const T* __restrict
 template <typename T>
 int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const float* grep_w, const float* grep_b,
            const float* grep_a, const uint8_t* key_pad, void* out, int q_log2e, hipStream_t s) {
-    AVX_ENSURE_LDS(attention_kernel<T>, ATT_LDS);
     static const int dbg = getenv("AVEX_AMD_ATT_DEBUG") ? atoi(getenv("AVEX_AMD_ATT_DEBUG")) : 0;
     // 1 = stage-then-compute, 2 = persistent streamed (32x32x16 MFMAs), 3 = persistent streamed on 16x16x32 MFMAs (attention16.hip; default up to 512 tokens)
     int variant = getenv("AVEX_AMD_ATT_VARIANT") ? atoi(getenv("AVEX_AMD_ATT_VARIANT")) : 3;
@@ -1258,6 +1257,7 @@ int launch(const void* qkv, int B, int Tn, int H, const float* bias_tab, const f
         AVX_LAUNCH_CHECK();
         return AVEXHIP_OK;
     }
+    AVX_ENSURE_LDS(attention_kernel<T>, ATT_LDS);      // (variant 1 only: behind the dispatch)
     hipLaunchKernelGGL(attention_kernel<T>, dim3(B * H), dim3(1024), ATT_LDS, s, (const T*)qkv, Tn, H, bias_tab, grep_w,
                        grep_b, grep_a, key_pad, (T*)out, q_log2e, dbg);
     AVX_LAUNCH_CHECK();

@@ -55,7 +55,14 @@ template <> struct Half<__bf16> {
 #define AVX_MODE_FP16_OVFL_HWREG 1473      // hwreg(HW_REG_MODE = 1, offset 23, size 1): id | offset << 6 | (size - 1) << 11
 #define AVX_MODE_DX10_CLAMP_HWREG 513      // hwreg(HW_REG_MODE, offset 8, size 1)
 #define AVX_F16_SAT_BEGIN() do { __builtin_amdgcn_s_setreg(AVX_MODE_DX10_CLAMP_HWREG, 0); __builtin_amdgcn_s_setreg(AVX_MODE_FP16_OVFL_HWREG, 1); asm volatile("" ::: "memory"); } while (0)
-#define AVX_F16_SAT_END() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_setreg(AVX_MODE_FP16_OVFL_HWREG, 0); } while (0)
+#define AVX_F16_SAT_END() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_setreg(AVX_MODE_FP16_OVFL_HWREG, 0); __builtin_amdgcn_s_setreg(AVX_MODE_DX10_CLAMP_HWREG, 1); } while (0)
+// (SAT_END also puts MODE.DX10_CLAMP back to the value the kernel was compiled for: whatever clamp folds the compiler made in the code that
+// follows -- the K loop of a persistent kernel -- see the mode they assume.)
+// The code that RELIES on DX10_CLAMP being clear (gelu_clamp_t below: a `clamp` output modifier that must pass a NaN through) is tied to the
+// mode write by DATA: its multiplier arrives in a scalar register that a volatile asm defines BEHIND the mode write (volatile asm and the
+// s_setreg builtin both have side effects: the compiler keeps their order), so no scheduler can lift the multiply above the s_setreg --
+// a register-only, non-volatile asm with no such operand may move freely.  One s_mov_b32 per epilogue.
+#define AVX_CLAMP_TOKEN(name) float name; asm volatile("s_mov_b32 %0, 0x3e33a62d" : "=s"(name))      /* 1 / 5.7 (AVX_GELUH_INVA) */
 
 // Range alarm of the f16 outputs (Half<_Float16>::from saturates silently): a kernel keeps the running max of |value| over
 // everything a lane rounds to f16 (v_max3_f32 with |.| modifiers: half a VALU slot per element) and commits once at its end.
@@ -182,14 +189,15 @@ static __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 #define AVX_GELUH_T3 -8.163202285766602f
 #define AVX_GELUH_T4 4.081258773803711f
 #define AVX_GELUH_INVA 0.17543859779834747f
-static __device__ __forceinline__ float gelu_clamp_t(float x) {
+// `inva`: an AVX_CLAMP_TOKEN of the calling kernel (1 / 5.7 in a scalar register defined behind the write that clears MODE.DX10_CLAMP)
+static __device__ __forceinline__ float gelu_clamp_t(float x, float inva) {
     float t;
-    asm("v_mul_f32_e64 %0, |%1|, %2 clamp" : "=v"(t) : "v"(x), "v"(AVX_GELUH_INVA));
+    asm("v_mul_f32_e64 %0, |%1|, %2 clamp" : "=v"(t) : "v"(x), "s"(inva));
     return t;
 }
-static __device__ __forceinline__ f32x2 gelu_erf2_h(f32x2 x) {
+static __device__ __forceinline__ f32x2 gelu_erf2_h(f32x2 x, float inva) {
 #if AVX_GELUH_RELU
-    const f32x2 t = {gelu_clamp_t(x[0]), gelu_clamp_t(x[1])};
+    const f32x2 t = {gelu_clamp_t(x[0], inva), gelu_clamp_t(x[1], inva)};
     f32x2 p = __builtin_elementwise_fma((f32x2)(AVX_GELUH_T4), t, (f32x2)(AVX_GELUH_T3));
     p = __builtin_elementwise_fma(p, t, (f32x2)(AVX_GELUH_T2));
     p = __builtin_elementwise_fma(p, t, (f32x2)(AVX_GELUH_T1));
@@ -213,8 +221,8 @@ static __device__ __forceinline__ f32x2 gelu_erf2_h(f32x2 x) {
     return __builtin_elementwise_fma(ax, u, x * (f32x2)(0.5f));
 #endif
 }
-static __device__ __forceinline__ f32x4 gelu_erf4_h(f32x4 v) {
-    const f32x2 a = gelu_erf2_h((f32x2){v[0], v[1]}), b = gelu_erf2_h((f32x2){v[2], v[3]});
+static __device__ __forceinline__ f32x4 gelu_erf4_h(f32x4 v, float inva) {
+    const f32x2 a = gelu_erf2_h((f32x2){v[0], v[1]}, inva), b = gelu_erf2_h((f32x2){v[2], v[3]}, inva);
     return (f32x4){a[0], a[1], b[0], b[1]};
 }
 // The same GELU over N pairs at once, written step by step ACROSS the pairs: N independent chains side by side in program order (the
@@ -273,8 +281,8 @@ static __device__ __forceinline__ float tanh_fast(float x) {      // 1 - 2 / (1 
 }
 // 6 = exact-erf GELU of a product whose ONLY output is in the operand type: the degree-4 fit (gelu_erf4_h).  avx::gemm turns 1 into 6 for such
 // products, so that every kernel and epilogue form rounds the same value (the fast epilogue of the streaming kernel is one of them).
-static __device__ __forceinline__ f32x4 act4_any(f32x4 v, int act) {
-    if (act == 6) return gelu_erf4_h(v);
+static __device__ __forceinline__ f32x4 act4_any(f32x4 v, int act, float inva) {
+    if (act == 6) return gelu_erf4_h(v, inva);
     if (act <= 2) return act4(v, act);
     f32x4 r;
 #pragma unroll

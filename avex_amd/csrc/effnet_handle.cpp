@@ -320,7 +320,8 @@ extern "C" avexhip_effnet* avexhip_effnet_create(const avexhip_effnet_config* cf
     h->dtype = c.operand_dtype;
     h->c0 = c.stem_channels; h->cp0 = ((c.stem_channels + 63) / 64) * 64; h->head = c.head_channels;      // (effnet_build narrows cp0 to 32 for B0 / B1: the stem's output and the first depthwise run at the real width)
     h->chunk = c.max_chunk_clips > 0 ? c.max_chunk_clips : 256;
-    if (h->init_alarm() != AVEXHIP_OK || effnet_build(h, tensors, n_tensors) != AVEXHIP_OK) { delete h; return nullptr; }
+    if (h->init_alarm() != AVEXHIP_OK || effnet_build(h, tensors, n_tensors) != AVEXHIP_OK || h->weights_fit() != AVEXHIP_OK) {      // (BN-folded weights that leave the f16 range: refused here, like the other four create paths)
+    delete h; return nullptr; }
     return h;
 }
 

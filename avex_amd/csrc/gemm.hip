@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_epi.h"
 
 #ifndef GEMM_PEEL
 #define GEMM_PEEL 1       // 1: K-tile 0 of every output tile is a copy of the loop body whose first MFMA per accumulator has C = 0 (no zeroing pass); 0: A/B
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
         return;
     }
     if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();      // every MFMA of this workgroup has been issued: the f16 conversions below saturate in hardware (common.h)
+    AVX_CLAMP_TOKEN(inva);
     const float alpha = p.alpha;
     float ovf_mx = 0.f;
 #pragma unroll
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
                 const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v = r * alpha + v;
             }
-            if (p.gelu) v = act4_any(v, p.gelu);
+            if (p.gelu) v = act4_any(v, p.gelu, inva);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
                 if (p.half_scale != 0.f) v = v * p.half_scale;      // (GemmArgs::half_scale; wave-uniform)
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(avx::GemmArgs p) {
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, int S) {
     if (GEMM_HW_SAT) AVX_F16_SATURATE_ON();
+    AVX_CLAMP_TOKEN(inva);
     typedef typename Half<T>::v4 v4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int nq = p.N >> 2;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(avx::GemmArgs p, i
                 const f32x4 r = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v = r * p.alpha + v;
             }
-            if (p.gelu) v = act4_any(v, p.gelu);
+            if (p.gelu) v = act4_any(v, p.gelu, inva);
             if (p.out_f32) *(f32x4*)(p.out_f32 + (int64_t)m * p.ldo + n) = v;
             if (p.out_half) {
                 if (p.half_scale != 0.f) v = v * p.half_scale;
@@ -484,53 +487,7 @@ static int gemm_nt_mode(const avx::GemmArgs& a) {
     __builtin_amdgcn_sched_barrier(0);
 
 
-// Sum over the 8 consecutive lanes that share (lane >> 3), valid in the lane with (lane & 7) == 0: three DPP steps
-// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shl:4), no LDS traffic (a __shfl_xor becomes a ds_bpermute round trip).
-static __device__ __forceinline__ float seg8_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
-    return v;
-}
-// The same reduction for TWO values at once with the DPP operand INSIDE the add (v_add_f32_dpp): six adds and three one-cycle nops.  From
-// the builtin hipcc makes, per step, two v_mov_b32 0 (the `old` operand), two v_mov_b32_dpp and one packed add -- fifteen instructions per
-// row segment, 13 % of the residual epilogue's vector instructions.  Written as one asm block because the hazard recogniser does not look
-// inside inline assembly: a DPP read needs two wait states after the VALU write of its source (the partner chain's add is one, s_nop 0 the
-// other; s_nop 1 covers whatever wrote the inputs).  a + dpp(a) either way: the same bits.
-#ifndef GEMM_DPP_ADD
-#define GEMM_DPP_ADD 1
-#endif
-static __device__ __forceinline__ void seg8_sum2(float& s1, float& s2) {
-#if GEMM_DPP_ADD
-    float a, b;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 0"
-        : "=&v"(a), "=&v"(b) : "v"(s1), "v"(s2));
-    s1 = a; s2 = b;
-#else
-    s1 = seg8_sum(s1); s2 = seg8_sum(s2);
-#endif
-}
-
-// Sum and sum of squares of a lane's 8 values x[0..3], y[0..3] (a row segment's share of the LayerNorm statistics), as PACKED operations down
-// the register pairs -- (x.01 + x.23) + (y.01 + y.23), the two halves added last -- 9 instructions.  (Written as a chain of scalar adds the
-// compiler packed it anyway, with two register moves per packed add to line the pairs up: ~500 v_mov per tile and wave in the residual
-// epilogue.)  Both epilogues that write statistics use this one function, so they agree bit for bit.
-static __device__ __forceinline__ void stats8(const f32x4& x, const f32x4& y, float& s1, float& s2) {
-    const f32x2 xl = {x[0], x[1]}, xh = {x[2], x[3]}, yl = {y[0], y[1]}, yh = {y[2], y[3]};
-    const f32x2 t = (xl + xh) + (yl + yh);
-    const f32x2 q = __builtin_elementwise_fma(yh, yh, __builtin_elementwise_fma(yl, yl, __builtin_elementwise_fma(xh, xh, xl * xl)));
-    s1 = hsum2(t);
-    s2 = hsum2(q);
-}
+// (seg8_sum, seg8_sum2, stats8 -- the row-statistics helpers both residual epilogues use -- live in gemm_epi.h: gemm_row.hip shares them)
 
 // ---------------------------------------------------------------------------------------------
 // The 256-tile kernel: the half-tile pipeline above as ONE CONTINUOUS K STREAM over a persistent workgroup's tiles (one
@@ -843,6 +800,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
         const int er = le >> 3, ec = le & 7, lc = le & 15, lg = le >> 4;
         float ovf_mx = 0.f;
         if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();      // MODE.FP16_OVFL for the epilogue's conversions only: set, the MFMAs drop NaN operands (common.h)
+        AVX_CLAMP_TOKEN(inva);
 
         if constexpr (GEMM_NOEPI && (EPI == 1 || EPI == 2)) {
             // diagnostic build: NO epilogue at all (the accumulators are only kept alive) -- the upper bound of what any scheme that hides
@@ -986,7 +944,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                         } else {
                             v = acc[4 * ih + i][j] + bv[i];
                         }
-                        if constexpr (ACT == 1) v = GEMM_GELU_H ? gelu_erf4_h(v) : gelu_erf4(v);      // half output: the degree-4 fit (common.h)
+                        if constexpr (ACT == 1) v = GEMM_GELU_H ? gelu_erf4_h(v, inva) : gelu_erf4(v);      // half output: the degree-4 fit (common.h)
                         else if constexpr (ACT == 2) v = silu4(v);
                         ovf_see4<T>(ovf_mx, v);
                         v4 h;
@@ -1195,7 +1153,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(avx::GemmArgs p) {
                                     v1[e] = __builtin_fmaf(__builtin_fmaf((float)rh[4 + e], st.x, st.y), lg1[e], lb1[e]) + a1[e];
                                 }
                             }
-                            if (p.gelu) { v0 = act4_any(v0, p.gelu); v1 = act4_any(v1, p.gelu); }
+                            if (p.gelu) { v0 = act4_any(v0, p.gelu, inva); v1 = act4_any(v1, p.gelu, inva); }
                             if (p.out_f32) {
                                 st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb), v0, p.nt);
                                 st_out((f32x4*)(p.out_f32 + (int64_t)m * p.ldo + nb + 4), v1, p.nt);
@@ -1373,6 +1331,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
                 }
             }
             if (GEMM_HW_SAT) AVX_F16_SAT_BEGIN();
+            AVX_CLAMP_TOKEN(inva);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int64_t m = r0 + rt * 16 + lr;
@@ -1396,7 +1355,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const avx::GemmArgs p)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = (float)rh[q >> 1][4 * (q & 1) + e] * alpha + v[e];
                         }
-                        if (p.gelu) v = act4_any(v, p.gelu);
+                        if (p.gelu) v = act4_any(v, p.gelu, inva);
                         ovf_see4<T>(ovf_mx, v);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) h[q >> 1][4 * (q & 1) + e] = HFROM(v[e]);

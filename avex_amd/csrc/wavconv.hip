@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void wavconv0_kernel(const float* __restrict__
     T* orow = out + ((int64_t)b * frames_pad + f0) * WC_C + c0;
     typedef T v2 __attribute__((ext_vector_type(2)));
     AVX_F16_SATURATE_ON();                                                // no MFMA in this kernel: the conversions saturate in hardware (NaN and inf pass)
+    AVX_CLAMP_TOKEN(inva);
     T* op = orow;
     for (int t = 0; t < nf; ++t, op += WC_C) {
         const float* x = xs + t * WC_S;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void wavconv0_kernel(const float* __restrict__
             yb = __builtin_elementwise_fma(wb[q], xp, yb);
         }
         const f32x2 y = {ya[0] + ya[1], yb[0] + yb[1]};
-        const f32x2 g = gelu_erf2_h(__builtin_elementwise_fma(y, sc, sh));      // the output is rounded to the operand type: the GELU sized for it
+        const f32x2 g = gelu_erf2_h(__builtin_elementwise_fma(y, sc, sh), inva);      // the output is rounded to the operand type: the GELU sized for it
         v2 h; h[0] = Half<T>::from_hw(g[0]); h[1] = Half<T>::from_hw(g[1]);
         *(v2*)op = h;
     }

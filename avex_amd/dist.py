@@ -16,11 +16,29 @@ import torch.distributed as dist
 
 
 _WORK_GROUP = None      # the group the gathers run on by default: every rank, long collective timeout (init_distributed)
+_WORK_WORLD = None      # the default process group _WORK_GROUP was made in: a group of a destroyed world must never be used again
 
 
 def work_group():
-    """The process group ``init_distributed`` made for the data path (``None`` = the default group: single process, or initialised elsewhere)."""
+    """The process group ``init_distributed`` made for the data path (``None`` = the default group: single process, initialised elsewhere,
+    or torch.distributed was destroyed and re-initialised since -- a group of the old world is dropped, not used)."""
+    global _WORK_GROUP, _WORK_WORLD
+    if _WORK_GROUP is not None:
+        alive = dist.is_initialized() and dist.distributed_c10d._get_default_group() is _WORK_WORLD
+        if not alive:
+            _WORK_GROUP = _WORK_WORLD = None
     return _WORK_GROUP
+
+
+def shutdown() -> None:
+    """Destroy what ``init_distributed`` made (the working group, then the default group) and forget it, so that a later
+    ``init_distributed`` -- or an initialisation done elsewhere -- starts clean."""
+    global _WORK_GROUP, _WORK_WORLD
+    if dist.is_initialized():
+        if work_group() is not None:
+            dist.destroy_process_group(_WORK_GROUP)
+        dist.destroy_process_group()
+    _WORK_GROUP = _WORK_WORLD = None
 
 
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -29,6 +47,15 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and dist.is_initialized() and work_group() is None:
+        # initialised elsewhere (or re-initialised after a destroy): the data path still gets its own group with the long collective
+        # timeout, behind a barrier on the default group
+        import datetime
+        dist.barrier()
+        global _WORK_GROUP, _WORK_WORLD
+        _WORK_GROUP = dist.new_group(ranks=list(range(world)), backend=dist.get_backend(),
+                                     timeout=datetime.timedelta(seconds=int(os.environ.get("AVEX_AMD_DIST_COLLECTIVE_TIMEOUT_S", "1800"))))
+        _WORK_WORLD = dist.distributed_c10d._get_default_group()
     if world > 1 and not dist.is_initialized():
         # dmabuf IPC only on these hosts (RCCL across processes).  ROCr reads the flag when the runtime starts, so it goes in BEFORE the first
         # call that initialises HIP in this process -- torch.cuda.is_available() below is one.  (A process that touched the GPU earlier must
@@ -50,8 +77,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         else:
             dist.init_process_group(backend=backend, timeout=t_rdv)
         dist.barrier()                                       # everyone is here (under the short timeout)
-        global _WORK_GROUP
         _WORK_GROUP = dist.new_group(ranks=list(range(world)), timeout=t_run, backend=backend)
+        _WORK_WORLD = dist.distributed_c10d._get_default_group()
     return rank, world, local_rank
 
 
@@ -64,7 +91,7 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Gather ``[n_local, D]`` shards (possibly ragged) into ``[n_total, D]`` in rank order."""
-    group = group if group is not None else _WORK_GROUP
+    group = group if group is not None else work_group()
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
@@ -97,7 +124,7 @@ class PipelinedGather:
     """
 
     def __init__(self, group=None, force: bool = False, measure: bool = False) -> None:
-        self.group = group if group is not None else _WORK_GROUP
+        self.group = group if group is not None else work_group()
         # measure: time what the consumer actually WAITED for each gather (``exposed_ms``): on a GPU two events on the compute stream
         # around the stream dependency (0 when the collective had finished under the next batch's kernels), on the CPU the blocking wait
         self.measure = bool(measure)

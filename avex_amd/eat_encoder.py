@@ -35,8 +35,16 @@ class EatEncoder:
     and the workspace."""
 
     def __init__(self, cfg: Mapping[str, object], state: Mapping[str, object], operand_dtype: str = "f16", prefix: str = "backbone.model.",
-                 norm_mean: float = -4.268, norm_std: float = 4.569, max_chunk_clips: int = 0, residual: str = "half", batch_invariant: bool = False) -> None:
+                 norm_mean: float = -4.268, norm_std: float = 4.569, max_chunk_clips: int = 0, residual: str = "auto", batch_invariant: bool = False) -> None:
+        """``residual``: the inter-kernel residual stream.  ``"half"`` = operand type (LayerNorms folded into the GEMMs), ``"f32"`` = fp32
+        stream (un-averaged rows 3 x closer to the fp32 arithmetic, ~20 % more time), ``"auto"`` (default) = per call, BEATs' policy
+        (beats_model.py here): ``"f32"`` whenever the call hands back un-averaged rows -- features, un-pooled taps, the class token
+        (``pooling="cls"``, the reference wrapper's default: eat_hf.py:149,281-282) -- and ``"half"`` for token-mean outputs only
+        (config C3's path).  Two library handles then, each built on first use."""
         _capi.require_gpu()
+        self.residual = str(residual or "auto").lower()
+        if self.residual != "auto":
+            K.residual_code(self.residual)      # validates
         self.cfg = dict(cfg)
         self.dtype = operand_dtype
         self.E = int(cfg["embed_dim"]); self.H = int(cfg["num_heads"]); self.L = int(cfg["depth"]); self.P = int(cfg["patch_size"])
@@ -52,16 +60,31 @@ class EatEncoder:
         c.norm_eps, c.norm_mean, c.norm_std = self.eps, float(norm_mean), float(norm_std)
         c.operand_dtype = _capi.dtype_code(operand_dtype)
         c.max_chunk_clips = int(max_chunk_clips)
-        c.residual_dtype = K.residual_code(residual, batch_invariant)
-        sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
-        arr, n, keep = K.tensor_table(sub)
-        self._h = _capi.lib().avexhip_eat_create(C.byref(c), arr, n)
-        del keep
-        if not self._h:
-            raise K.AvexHipError(f"eat_create failed: {_capi.last_error()}")
+        self._c, self._batch_invariant = c, bool(batch_invariant)
+        self._sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else dict(state)
+        self._handles: Dict[str, int] = {}      # residual mode ("half" / "f32") -> library handle
+        self._profiling = False
+        self._h = self._handle_for(frames=self.residual in ("auto", "f32", "fp32", "float32"))      # a bad checkpoint fails here, not in the first forward
         self._ws: Optional[torch.Tensor] = None
         self._norm = (float(norm_mean), float(norm_std))
         self._plan = None
+
+    def _handle_for(self, frames: bool) -> int:
+        """The handle whose residual stream this call wants (``frames``: it returns un-averaged rows); ``self._h`` = the last one used."""
+        mode = ("f32" if frames else "half") if self.residual == "auto" else ("half" if K.residual_code(self.residual) & 1 else "f32")
+        h = self._handles.get(mode)
+        if h is None:
+            self._c.residual_dtype = K.residual_code(mode, self._batch_invariant)
+            arr, n, keep = K.tensor_table(self._sub)
+            h = _capi.lib().avexhip_eat_create(C.byref(self._c), arr, n)
+            del keep
+            if not h:
+                raise K.AvexHipError(f"eat_create failed: {_capi.last_error()}")
+            self._handles[mode] = h
+            if self._profiling:
+                _capi.check(_capi.lib().avexhip_eat_set_profiling(h, 1), "eat_set_profiling")
+        self._h = h
+        return h
 
     @property
     def num_tokens(self) -> int:
@@ -106,6 +129,9 @@ class EatEncoder:
                 raise ValueError(f"spec must be a [B, {self.target_length}, {self.n_mels}] CUDA tensor")
             spec = spec.float().contiguous()
             B, T, dev = spec.shape[0], 0, spec.device
+        hook_layers = list(hook_layers)
+        frames = bool(want_features or pooling == "cls" or (hook_layers and K.pool_code(hook_pooled) != 1))      # anything but token means
+        self._handle_for(frames)
         E, Tt = self.E, self.num_tokens
         need = int(_capi.lib().avexhip_eat_workspace_bytes(self._h, B))
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
@@ -133,20 +159,26 @@ class EatEncoder:
         return out
 
     def overflow_events(self, sync: bool = True) -> int:
-        n = C.c_uint32(0)
-        _capi.check(_capi.lib().avexhip_eat_overflow_count(self._h, C.byref(n), K._stream(), int(bool(sync))), "eat_overflow_count")
-        return int(n.value)
+        total = 0
+        for h in self._handles.values():
+            n = C.c_uint32(0)
+            _capi.check(_capi.lib().avexhip_eat_overflow_count(h, C.byref(n), K._stream(), int(bool(sync))), "eat_overflow_count")
+            total += int(n.value)
+        return total
 
     def set_profiling(self, enabled: bool) -> None:
-        _capi.check(_capi.lib().avexhip_eat_set_profiling(self._h, int(enabled)), "eat_set_profiling")
+        self._profiling = bool(enabled)
+        for h in self._handles.values():
+            _capi.check(_capi.lib().avexhip_eat_set_profiling(h, int(enabled)), "eat_set_profiling")
 
     def last_profile(self):
         return K.handle_profile(_capi.lib().avexhip_eat_last_profile, self._h)
 
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            _capi.lib().avexhip_eat_destroy(self._h)
-            self._h = None
+        for h in getattr(self, "_handles", {}).values():
+            _capi.lib().avexhip_eat_destroy(h)
+        self._handles = {}
+        self._h = None
         self._ws = None
 
     def __del__(self) -> None:

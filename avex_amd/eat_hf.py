@@ -105,10 +105,14 @@ class EATHFModel(ModelBase):
                  audio_config: Optional[Dict[str, Any]] = None, target_length: int = 1024, pooling: str = "cls",
                  fairseq_weights_path: Optional[str] = None, norm_mean: float = -4.268, norm_std: float = 4.569,
                  return_features_only: bool = False, operand_dtype: str = "f16", init_config: Optional[Dict[str, Any]] = None,
-                 batch_invariant: Optional[bool] = None) -> None:
+                 batch_invariant: Optional[bool] = None, residual: Optional[str] = None) -> None:
         super().__init__(device=device, audio_config=audio_config)
         if num_classes is None:
             num_classes = 0
+        # inter-kernel residual stream, BEATs' policy (beats_model.py here): "auto" (default) = fp32 stream for every call that hands back
+        # un-averaged rows -- features, taps, the class token (this wrapper's default pooling, eat_hf.py:149,281-282) -- and the operand
+        # type for token means only; "half" / "f32" force one (EatEncoder)
+        self.residual = (residual or os.environ.get("AVEX_AMD_RESIDUAL") or "auto").lower()
         if not return_features_only and num_classes == 0:                        # eat_hf.py:175-176
             raise ValueError("num_classes must be > 0 when return_features_only=False")
         self.pooling = pooling
@@ -176,7 +180,7 @@ class EATHFModel(ModelBase):
             with torch.cuda.device(p.device):
                 state = {"backbone." + k: v for k, v in self.backbone.state_dict().items()}
                 self._encoder = EatEncoder(self.config, state, operand_dtype=self.operand_dtype, norm_mean=self.norm_mean, norm_std=self.norm_std,
-                                           batch_invariant=self.batch_invariant)
+                                           batch_invariant=self.batch_invariant, residual=self.residual)
             self._weights_dirty = False
         return self._encoder
 

@@ -784,6 +784,15 @@ class BeatsEncoder:
     #   2./3. the same + hidden activations stored x 2^-8 / 2^-14 with the inverse folded into fc2's weights (exact powers of two:
     #      ``hidden_shift``, avexhip_beats_config): fc1 outputs up to 1.6e7 / 1e9 fit;
     #   4. bf16 operands + fp32 residual stream: fp32's exponent range everywhere.
+    # Precision of the shifted rungs: a stored hidden activation h x 2^-k is an f16 NORMAL (11 significant bits, exact scaling) for
+    # |h| >= 2^(k-14) and an f16 SUBNORMAL below that, where the absolute step is 2^(k-24): rung 2 (k = 8) rounds |h| < 2^-6 to multiples of
+    # 2^-16, rung 3 (k = 14) rounds every |h| < 1 to multiples of 2^-10 (the modes rely on f16 denormals not being flushed: MODE.FP_DENORM
+    # keeps them on gfx950, and the MFMA reads them).  GELU outputs below 1 then carry up to 5e-4 absolute error each -- measured on the
+    # clean checkpoint the pooled embedding stays at the default mode's 3e-4 (tests/test_gpu_overflow.py::test_hidden_shift_is_exact_
+    # scaling_on_a_clean_checkpoint), because fc2 averages 3072 of them -- but rung 3 is "holds 1e9" first and "exact" second; the
+    # ladder tries it only after rung 2 alarmed.
+    # A checkpoint whose WEIGHTS do not fit f16 (weights_fit, csrc/handle_core.h) cannot be served by any f16 rung: with on_overflow="retry"
+    # the constructor then builds rung 4 as the serving handle (``served_by`` names it) instead of raising.
     RETRY_LADDER = (("f16 operands, fp32 residual stream", dict(operand_dtype="f16", residual="f32", hidden_shift=0)),
                     ("f16 operands, fp32 residual stream, hidden activations x 2^-8", dict(operand_dtype="f16", residual="f32", hidden_shift=8)),
                     ("f16 operands, fp32 residual stream, hidden activations x 2^-14", dict(operand_dtype="f16", residual="f32", hidden_shift=14)),
@@ -814,6 +823,17 @@ class BeatsEncoder:
         self.L = int(cfg["encoder_layers"])
         arr, n, keep = tensor_table(state)
         self._h = lib().avexhip_beats_create(C.byref(self.ccfg), arr, n)
+        self.served_by: Optional[str] = None      # set when the constructor itself had to climb the ladder (weights outside the f16 range)
+        if not self._h and self.on_overflow == "retry" and dtype_code(operand_dtype) == _capi.F16 and "do not fit the f16 range" in _capi.last_error():
+            # the retry contract is "a result is always returned": no f16 rung can hold these weights (the shifted ones scale fc2's up), so the
+            # handle that serves every batch is the ladder's last rung
+            name, mode = self.RETRY_LADDER[-1]
+            logger.warning("avex_amd: %s  on_overflow='retry': serving with '%s'.", _capi.last_error(), name)
+            self.ccfg = make_beats_config(cfg, mode["operand_dtype"], max_chunk_clips, mode["residual"], self.batch_invariant, mode["hidden_shift"])
+            self._mode = (dtype_code(mode["operand_dtype"]), residual_code(mode["residual"]) & 1, mode["hidden_shift"])
+            self._fallback_args = None      # nothing wider exists
+            self.served_by = name
+            self._h = lib().avexhip_beats_create(C.byref(self.ccfg), arr, n)
         del keep
         if not self._h:
             raise AvexHipError(f"beats_create failed: {_capi.last_error()}")

@@ -245,7 +245,11 @@ def other_configs(steps: int = 5):
                          "roofline": {"bound": "mfma", "achieved": round(B * fl / dt / 1e12, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": round(B * fl / dt / 1e12 / PEAK_TFLOPS, 4), "gflop_per_clip": round(fl / 1e9, 2)},
                          "parity": {"reference": "tests/golden/family_small.npz:eat.pooled_mean (oracle/eat_oracle.py, UNPINNED: EAT's remote code is absent from the reference tree)",
-                                    "how": "2 clips x 5 s", "pooled_rel_l2_f16": rel(p, gold["eat.pooled_mean"]), "tolerance": 1e-3}}
+                                    "how": "2 clips x 5 s; the token mean on the operand-type residual stream (the timed path), the class token -- the reference wrapper's "
+                                           "default pooling, eat_hf.py:149,281-282 -- on the fp32 stream EatEncoder(residual='auto') takes for un-averaged rows",
+                                    "pooled_rel_l2_f16": rel(p, gold["eat.pooled_mean"]),
+                                    "cls_token_rel_l2_f16": rel(enc.forward(small, want_features=False, pooling="cls")["pooled"].cpu().numpy(), gold["eat.cls"]),
+                                    "tolerance": 1e-3}}
         enc.close()
         del wav, enc
     except Exception as e:  # noqa: BLE001
@@ -616,7 +620,11 @@ def main():
             try:
                 sj = json.load(open(sfiles[-1]))
                 tw = sj["layer_gemms_time_weighted"]
-                sq = {"mfma_busy_frac": tw["mfma_busy_frac"], "effective_clock_mhz": tw["effective_clock_mhz"],
+                # do these counters describe the kernel this run executes?  (the summary records the hash of gemm.hip + common.h it was collected on)
+                from avex_amd.build import kernel_source_sha16
+                here = kernel_source_sha16(("gemm.hip", "common.h"))
+                sq = {"sq_same_kernel_source": sj.get("gemm_source_sha16") == here, "sq_kernel_source_sha16": {"counters": sj.get("gemm_source_sha16"), "this_run": here},
+                      "mfma_busy_frac": tw["mfma_busy_frac"], "effective_clock_mhz": tw["effective_clock_mhz"],
                       "mfma_busy_by_shape": {k: {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_mhz": v["effective_clock_mhz"]}
                                              for k, v in sj.items() if k in ("qkv", "out", "fc1", "fc2")},
                       "sq_source": "profiles/" + os.path.basename(sfiles[-1]) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE ...; busy = matrix-pipe busy cycles / "

@@ -70,4 +70,8 @@ if out:
                                         "effective_clock_mhz": round(sum(out[s]["effective_clock_mhz"] * w[s] for s in w)),
                                         "how": "the four shapes weighted by their share of a step's GEMM time (12 launches each)"}
     print("time-weighted:", out["layer_gemms_time_weighted"])
+# which kernel source these counters describe: bench.py quotes the file only next to the same hash (or says that it is stale)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from avex_amd.build import kernel_source_sha16  # noqa: E402
+out["gemm_source_sha16"] = kernel_source_sha16(("gemm.hip", "common.h"))
 json.dump(out, open(os.path.join(root, f"{tag}_gemm_sq.json"), "w"), indent=1)

@@ -26,6 +26,7 @@ def main() -> None:
     ref, _ = EO.eat_forward(wav, synth.eat_state_dict(cfg), cfg)
     out["eat.seed"] = np.array([12]); out["eat.samples"] = np.array([80000])
     out["eat.pooled_mean"] = ref.mean(1).astype(np.float32)              # [2, 768]: mean over the 513 tokens (eat_hf.py:283-288 "mean")
+    out["eat.cls"] = ref[:, 0].astype(np.float32)                        # [2, 768]: the class token, the wrapper's DEFAULT pooling (eat_hf.py:149,281-282)
     print(f"EAT 2 x 5 s: {time.time() - t0:.1f} s", flush=True)
     t0 = time.time()
     sd = synth.effnet_b0_state_dict()

@@ -52,6 +52,44 @@ def test_two_rank_gloo_all_gather(tmp_path, n_clips):
         assert got.shape == ref.shape and np.array_equal(got, ref)       # every rank holds every row, in clip order
 
 
+def _reinit_worker(rank, world, port, out_dir):
+    """init_distributed -> gather -> torch.distributed destroyed and re-initialised OUTSIDE init_distributed -> gather again: the second
+    gather must not run on the first world's group (_WORK_GROUP was never cleared); then shutdown() and a clean third start."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    adist.init_distributed(backend="gloo")
+    g1 = adist.work_group()
+    assert g1 is not None
+    wav = torch.randn(6, 1000, generator=torch.Generator().manual_seed(1))
+    a = adist.extract_embeddings_sharded(_embed, wav)
+    dist.barrier()
+    dist.destroy_process_group()                      # the caller tears the world down itself ...
+    assert adist.work_group() is None                 # ... and the stale group is dropped, not handed out
+    os.environ["MASTER_PORT"] = str(port + 1)
+    dist.init_process_group(backend="gloo")           # ... and brings up a new one without init_distributed
+    b = adist.extract_embeddings_sharded(_embed, wav)  # default group of the new world
+    adist.init_distributed(backend="gloo")            # gives the data path its own group in the new world
+    g2 = adist.work_group()
+    assert g2 is not None and g2 is not g1
+    c = adist.extract_embeddings_sharded(_embed, wav)
+    dist.barrier()
+    adist.shutdown()
+    assert not dist.is_initialized() and adist.work_group() is None
+    os.environ["MASTER_PORT"] = str(port + 2)
+    adist.init_distributed(backend="gloo")
+    d = adist.extract_embeddings_sharded(_embed, wav)
+    dist.barrier()
+    adist.shutdown()
+    ref = _embed(wav)
+    assert all(torch.equal(x, ref) for x in (a, b, c, d))
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_work_group_does_not_outlive_its_world(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_reinit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
 def test_single_process_is_a_no_op():
     wav = torch.randn(3, 100)
     assert torch.equal(adist.extract_embeddings_sharded(_embed, wav), _embed(wav))

@@ -109,7 +109,7 @@ def test_c_abi_eat_handle_consumer(built_lib, tmp_path):
     arr = np.frombuffer(raw, np.float32, offset=12)
     n = B * Tt * E
     feat, pool, hook = arr[:n].reshape(B, Tt, E), arr[n:n + B * E].reshape(B, E), arr[n + B * E:].reshape(B, Tt, E)
-    enc = EatEncoder(cfg, sd, operand_dtype="f16")
+    enc = EatEncoder(cfg, sd, operand_dtype="f16", residual="half")      # the consumer's residual_dtype = 1
     py = enc.forward(torch.from_numpy(x).cuda(), hook_layers=[1], want_features=True, pooling="cls")
     assert np.array_equal(py["features"].cpu().numpy(), feat) and np.array_equal(py["pooled"].cpu().numpy(), pool)
     assert np.array_equal(py["hooks"][1].cpu().numpy(), hook)

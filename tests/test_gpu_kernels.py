@@ -502,6 +502,39 @@ def test_attention_without_a_bias_table(built_lib, T, grid, dtype, monkeypatch):
     assert rel_l2(outs["3"][0], outs["2"][0]) < tol and rel_l2(outs["3"][1], outs["2"][1]) < tol
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_default_kernel_cross_checked_against_variant_2(built_lib, dtype, monkeypatch):
+    """The CI cross-check of the default kernel (variant 3: hand-counted vmcnt waits, inline-asm Q loads, deferred softmax reference; default
+    up to 512 tokens and, without a bias table, for the main block of 513 .. 544) against the kernel it replaced (variant 2, compiler-
+    scheduled waits) over RAGGED lengths -- every tile boundary of either kernel -- with the gated bias, a key padding mask whose padded
+    range covers whole key tiles, and a clip with every key padded (both kernels must treat the all-masked rows the same way)."""
+    from avex_amd import kernels as K
+    B, H = 3, 4
+    E = H * 64
+    table = synth.normal("relx", (320, H), 0.5)
+    gw = synth.normal("gwx", (8, 64), 0.1); gb = synth.normal("gbx", (8,), 0.1); ga = 1.0 + synth.normal("gax", (H,), 0.2)
+    tol = 1.5e-3 if dtype == "f16" else 1.2e-2
+    worst = 0.0
+    for T in (1, 2, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 479, 480, 481, 495, 496, 497, 511, 512, 513, 514, 520, 543, 544):
+        qkv = _dev(round_half(synth.normal(f"qkvx{T}", (B * T, 3 * E), 1.0), dtype), _tdt(dtype))
+        pad = np.zeros((B, T), bool); pad[1, max(1, T // 3):] = True; pad[2, :] = True      # clip 1: a padded tail (whole key tiles of it), clip 2: every key padded
+        padd = _dev(pad.astype(np.uint8), torch.uint8)
+        tab = _dev(_toeplitz(table, T, 320, 800)) if T <= 512 else None      # beyond 512 tokens only the bias-free form runs on variant 3
+        gate = (_dev(gw), _dev(gb), _dev(ga)) if tab is not None else (None, None, None)
+        outs = {}
+        for variant in ("3", "2"):
+            monkeypatch.setenv("AVEX_AMD_ATT_VARIANT", variant)
+            outs[variant] = (K.attention(qkv, B, T, H, tab, *gate).float().cpu().numpy(),
+                             K.attention(qkv, B, T, H, tab, *gate, key_pad=padd).float().cpu().numpy().reshape(B, T, E))
+        assert np.isfinite(outs["3"][0]).all() and rel_l2(outs["3"][0], outs["2"][0]) < tol, T
+        a, b = outs["3"][1], outs["2"][1]
+        assert np.isfinite(a[:2]).all() and rel_l2(a[:2], b[:2]) < tol, T
+        assert np.array_equal(np.isnan(a[2]), np.isnan(b[2])), T                      # the all-masked clip: NaN where the other kernel has NaN ...
+        assert np.allclose(np.nan_to_num(a[2]), np.nan_to_num(b[2]), atol=2e-2), T   # ... and the same numbers elsewhere
+        worst = max(worst, rel_l2(outs["3"][0], outs["2"][0]))
+    print(f"variant 3 vs variant 2, {dtype}: worst rel-L2 over the ragged lengths {worst:.2e}")
+
+
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("T,grid", [(496, 7), (200, 5), (300, 60), (512, 1)])
 def test_attention_persistent_items(built_lib, T, grid, variant, monkeypatch):

@@ -252,6 +252,12 @@ def test_weights_outside_the_f16_range_are_refused(built_lib, clips):
     p = enc.forward(torch.from_numpy(clips).cuda(), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
     enc.close()
     assert rel_l2(p, f_ref.mean(1)) < 8e-3
+    # on_overflow="retry" promises a result: the constructor climbs to the one rung that can hold such weights and serves with it
+    enc = K.BeatsEncoder(CFG, sd, operand_dtype="f16", on_overflow="retry")
+    assert enc.served_by == "bf16 operands, fp32 residual stream"
+    p2 = enc.forward(torch.from_numpy(clips).cuda(), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
+    enc.close()
+    assert np.array_equal(p2, p)
 
 
 def test_hidden_shift_is_refused_where_it_cannot_hold(built_lib):
@@ -305,6 +311,22 @@ def test_effnet_fused_block_front_keeps_the_alarm(built_lib, monkeypatch):
     key = "model.features.2.0.block.0.0.weight"                  # the first expansion (16 -> 96), a block the fused kernel takes
     assert key in hot
     hot[key] = (hot[key] * np.float32(1e6)).astype(np.float32)
+    # weights that leave the f16 range themselves are refused when the handle is created (round 6: effnet_create calls weights_fit like the
+    # other four create paths; before, they surfaced as a sticky alarm that blamed the first forward)
+    from avex_amd._capi import AvexHipError
+    with pytest.raises(AvexHipError, match="do not fit the f16 range"):
+        EfficientNetB0Encoder(hot)
+    # ... so the activations are driven out of range with weights that still fit: the largest folded weight of that layer at a quarter of the range
+    probe = None
+    for scale in (3e4, 1e4, 3e3, 1e3):
+        hot[key] = (sd[key] * np.float32(scale)).astype(np.float32)
+        try:
+            probe = EfficientNetB0Encoder(hot)
+            break
+        except AvexHipError:
+            continue
+    assert probe is not None
+    del probe
     counts = {}
     for form in ("fused", "unfused"):
         if form == "unfused":

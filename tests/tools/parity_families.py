@@ -49,12 +49,17 @@ def eat():
     wav = synth.noise_clips(2, 80000, seed=12)
     ref, taps = EO.eat_forward(wav, sd, cfg)
     out = {"reference": "oracle/eat_oracle.py (parity unpinned), EAT-base, 2 clips x 5 s, 513 tokens"}
+    out["policy"] = ("residual='auto' (the default): calls that return un-averaged rows -- features, the class token, un-pooled taps -- run on the fp32 "
+                     "residual stream, token-mean-only calls (config C3's timed path: pooled_mean_only) on the operand-type stream")
     for dt in ("f16", "bf16"):
-        enc = EatEncoder(cfg, sd, operand_dtype=dt)
-        r = enc.forward(torch.from_numpy(wav).cuda(), hook_layers=list(range(12)), pooling="mean")
-        f = r["features"].cpu().numpy()
-        out[dt] = {"pooled_mean": rel(f.mean(1), ref.mean(1)), "cls_token": rel(f[:, 0], ref[:, 0]), "frame_level": rel(f, ref),
-                   "taps_mean_worst": max(rel(r["hooks"][i].cpu().numpy().mean(1), taps[f"backbone.model.blocks.{i}.attn.proj"].mean(1)) for i in range(12))}
+        for res in ("auto", "half", "f32"):
+            enc = EatEncoder(cfg, sd, operand_dtype=dt, residual=res)
+            r = enc.forward(torch.from_numpy(wav).cuda(), hook_layers=list(range(12)), pooling="mean")
+            f = r["features"].cpu().numpy()
+            pm = enc.forward(torch.from_numpy(wav).cuda(), want_features=False, pooling="mean")["pooled"].cpu().numpy()
+            out[f"{dt}.residual_{res}"] = {"pooled_mean": rel(f.mean(1), ref.mean(1)), "pooled_mean_only": rel(pm, ref.mean(1)), "cls_token": rel(f[:, 0], ref[:, 0]), "frame_level": rel(f, ref),
+                       "taps_mean_worst": max(rel(r["hooks"][i].cpu().numpy().mean(1), taps[f"backbone.model.blocks.{i}.attn.proj"].mean(1)) for i in range(12))}
+            enc.close()
     return out
 
 
@@ -82,12 +87,17 @@ def aves():
     sd = synth.aves_state_dict(cfg)
     x = synth.noise_clips(2, 32000, seed=44)
     ref, taps = AO.aves_forward(x, sd, cfg)
-    enc = AvesEncoder(cfg, sd)
-    r = enc.forward(torch.from_numpy(x).cuda(), hook_layers=list(range(12)), want_features=True, want_pooled=True)
     name = "model.encoder.transformer.layers.{}.feed_forward.output_dense"
-    return {"reference": "oracle/aves_oracle.py (parity unpinned), wav2vec2-base, 2 clips x 2 s, 12 layers",
-            "f16": {"pooled": rel(r["pooled"].cpu().numpy(), ref.mean(1)), "frame_level": rel(r["features"].cpu().numpy(), ref),
-                    "taps_mean_worst": max(rel(r["hooks"][i].cpu().numpy().mean(1), taps[name.format(i)].mean(1)) for i in range(12))}}
+    out = {"reference": "oracle/aves_oracle.py (parity unpinned), wav2vec2-base, 2 clips x 2 s, 12 layers",
+           "policy": "residual='auto' (the default): fp32 residual stream for calls that return frames or un-pooled taps, operand type for token means only (pooled_only)"}
+    for res in ("auto", "half", "f32"):
+        enc = AvesEncoder(cfg, sd, residual=res)
+        r = enc.forward(torch.from_numpy(x).cuda(), hook_layers=list(range(12)), want_features=True, want_pooled=True)
+        po = enc.forward(torch.from_numpy(x).cuda(), want_features=False, want_pooled=True)["pooled"].cpu().numpy()
+        out[f"f16.residual_{res}"] = {"pooled": rel(r["pooled"].cpu().numpy(), ref.mean(1)), "pooled_only": rel(po, ref.mean(1)), "frame_level": rel(r["features"].cpu().numpy(), ref),
+                                      "taps_mean_worst": max(rel(r["hooks"][i].cpu().numpy().mean(1), taps[name.format(i)].mean(1)) for i in range(12))}
+        enc.close()
+    return out
 
 
 def main():
