@@ -42,7 +42,7 @@ class GemmArgs(C.Structure):
                 ("lnr_y", C.c_void_p), ("ldy", C.c_int64), ("lnr_rows", C.c_void_p),
                 ("lnr_gamma", C.c_void_p), ("lnr_beta", C.c_void_p), ("stats_out", C.c_void_p),
                 ("overflow_count", C.c_void_p), ("pool_part", C.c_void_p), ("pool_rows", C.c_int32), ("pool_mode", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_bytes", C.c_size_t)]
+                ("splitk_ws", C.c_void_p), ("splitk_bytes", C.c_size_t), ("rows_out", C.c_void_p), ("rows_eps", C.c_float)]
 
 
 class BeatsConfig(C.Structure):

@@ -60,6 +60,7 @@ extern "C" int avexhip_gemm(const avexhip_gemm_args* a, int dtype, void* stream)
     g.out_raw = a->out_raw; g.ldraw = a->ldraw; g.row_zero = nullptr; g.variant = a->variant;
     g.pool_part = a->pool_part; g.pool_T = a->pool_rows; g.pool_mode = a->pool_mode;
     g.splitk_ws = a->splitk_ws; g.splitk_bytes = a->splitk_bytes;
+    g.rows_out = a->rows_out; g.rows_eps = a->rows_eps;
     return avx::gemm(g, dtype, (hipStream_t)stream);
 }
 extern "C" int avexhip_pool_reduce(const float* part, int B, int T, int N, float* out, int64_t ldo, void* stream) {

@@ -400,6 +400,11 @@ struct GemmArgs {
     int lnr_prefolded;        // lnr_gamma holds alpha * gamma and lnr_beta holds alpha * beta + bias (what the kernel takes; avx::lnr_fold makes them).
                               // avx::gemm folds per launch when the flag is clear; callers that launch the same fold repeatedly keep the vectors
     float* stats_out;         // [M][N/64][2] or NULL
+    // The finished row statistics instead of (or beside) the partial ones: rows_out[m] = (rstd, -mu rstd) of output row m with rows_eps inside
+    // the root -- what avx::ln_rowstats makes of stats_out, same bits.  The full-row kernel (gemm_row.hip, N = 768) writes them from its
+    // epilogue; when another kernel runs the product, avx::gemm writes the partials to stats_out (required then, as scratch) and launches
+    // ln_rowstats itself.  Readable / writable up to M rounded up to even.
+    float* rows_out; float rows_eps;
     // Mean-pooled hook tap without the tap: the rows are clips of pool_T (>= 64) consecutive rows; each 64-row block writes the column
     // sums of acc + bias (what out_raw would hold) over its rows, split at the one clip boundary it can contain:
     // pool_part[block][slot][N], slot 0 = the clip of the block's first row, slot 1 = the next clip.  avx::pool_reduce adds a clip's
@@ -429,6 +434,9 @@ struct GemmArgs {
     int nt;                   // set by the launcher: bit 0 non-temporal output stores (256-tile kernels)
 };
 int gemm(const GemmArgs& a, int dtype, hipStream_t s);
+// the full-row residual kernel (gemm_row.hip): N = 768, one workgroup per 128 rows x all columns; avx::gemm dispatches to it (variant 8, or auto)
+bool gemm_row_ok(const GemmArgs& a);
+int gemm_row(const GemmArgs& a, int dtype, hipStream_t s);
 // fp32 NHWC rows [B * HW, ld] -> NCHW [B, C, HW], optionally undoing a folded BatchNorm: (x - shift[c]) / scale[c] (effnet.hip)
 int nhwc_to_nchw(const float* in, int64_t ld, int B, int HW, int C, const float* scale, const float* shift, float* out, hipStream_t s);
 // MBConv front in one kernel: 1x1 expansion (kin = 32 | 64 input channels) + BN + SiLU + depthwise k x k + BN + SiLU + squeeze sums (effnet.hip)

@@ -431,36 +431,7 @@ static __device__ __forceinline__ void st_out(V* ptr, const V& v, int nt) {
     if (GEMM_NT && (nt & 1)) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(__builtin_bit_cast(i32x4_st, v)) : "memory");   // s_nop 1: the hazard recogniser does not see a store in an asm block; on gfx940+/gfx950 a VMEM store of more than 64 bits followed by a VALU write of its data registers needs TWO wait states
     else *ptr = v;
 }
-// Raw-buffer access for the fast epilogues (EPI 1 / 2): the wave's 64 output rows are ONE buffer whose size ends with the last valid row,
-// so rows past M are dropped (stores) or read as zero (loads) by the hardware's bounds check -- no exec masking, no row clamp -- and an
-// address is a 32-bit lane offset (made once per tile) + a scalar offset per store instead of a 64-bit multiply-add per row.  (As
-// global_store with a per-row "m < M" the epilogue was ~30 basic blocks of 64-bit address arithmetic: v_mul_lo_u32 / v_mad_u64_u32 are
-// quarter-rate instructions.)  AUX 2 = the non-temporal hint (GEMM_NT above).
-typedef int i32x4_buf __attribute__((ext_vector_type(4)));
-typedef int i32x2_buf __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, unsigned bytes) {
-    // the inputs ARE wave-uniform (kernel arguments, tile and wave indices); the readfirstlanes make that provable, or every buffer
-    // instruction is wrapped in a "waterfall" loop (4 x v_readfirstlane + compares + exec juggling per store)
-    const uint64_t a = (uint64_t)base;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-    const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
-}
-// The scalar-offset operand of these instructions stays 0, and constant parts of an offset are added to the lane offset (the compiler
-// folds them into the instruction's 12-bit immediate).  With a REGISTER there, hipcc's hazard recogniser assumes that a 128-bit store
-// needs no wait states before a VALU instruction overwrites its data registers (LLVM: "this hazard only exists if the instruction is not
-// using a register in the soffset field") -- on gfx950 it does: `buffer_store_dwordx4 v[48:51], v120, s[28:31], s65 offen nt` directly
-// followed by `v_pk_mul_f32 v[48:49], ...` stored the NEW second dword for lanes 12-15 of every 16 (profiles/r04d_store_hazard.txt).
-template <int AUX, typename V>
-static __device__ __forceinline__ void buf_st16(const V& v, __amdgpu_buffer_rsrc_t r, int voff) {
-    static_assert(sizeof(V) == 16, "16-byte stores only");
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_buf, v), r, voff, 0, AUX);
-}
-template <typename V>
-static __device__ __forceinline__ V buf_ld16(__amdgpu_buffer_rsrc_t r, int voff) {
-    static_assert(sizeof(V) == 16, "16-byte loads only");
-    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
-}
+// (buf_rsrc, buf_st16, buf_ld16 -- raw-buffer access of the fast epilogues -- live in gemm_epi.h)
 // AVEX_AMD_GEMM_NT: 0 no hints, 1 (default) non-temporal output stores, 5 = only for outputs wider than 768 columns (diagnostics)
 static int gemm_nt_mode(const avx::GemmArgs& a) {
     static const int mode = getenv("AVEX_AMD_GEMM_NT") ? atoi(getenv("AVEX_AMD_GEMM_NT")) : 1;
@@ -1424,10 +1395,32 @@ int launch(const avx::GemmArgs& a, hipStream_t s) {
     if (a.variant == 0 && a.M >= 32768 && a.K % 64 == 0 && (a.N == 64 || a.N % 128 == 0) && !a.out_raw && skinny_ok(a) &&
         (a.N % BN != 0 || (!(getenv("AVEX_AMD_GEMM_SKINNY") && atoi(getenv("AVEX_AMD_GEMM_SKINNY")) == 0) && !getenv("AVEX_AMD_GEMM_VARIANT"))))
         return launch_skinny_any<T>(a, s);
+    // variant 8: the full-row residual kernel (gemm_row.hip), bit-identical to the streaming kernel.  NOT chosen automatically: measured on the
+    // attention output projection (126 976 rows, K = 768) it takes 228 us against 206 for the streaming kernel + ln_rowstats, on fc2's shape 25 %
+    // longer (profiles/r06b_gemm_row.txt: its 48 KiB of weights per 32-deep k-step arrive at the CU's L2 -> LDS rate, not at the MFMA rate).
+    // AVEX_AMD_GEMM_ROW=1 selects it for N = 768 products from 32 768 rows (A/B inside one process), AVEX_AMD_GEMM_ROW_KMAX bounds K.
+    if (a.variant == 8) {
+        AVX_REQUIRE(avx::gemm_row_ok(a), "gemm: variant 8 (full-row kernel) takes N = 768, K %% 32 == 0, K >= 128, a half output with bias and a half or LayerNorm-folded residual only (N=%d K=%d)", a.N, a.K);
+        return avx::gemm_row(a, __is_same(T, _Float16) ? AVEXHIP_F16 : AVEXHIP_BF16, s);
+    }
+    if (a.variant == 0 && a.N == 768 && a.M >= 32768 && avx::gemm_row_ok(a) && !getenv("AVEX_AMD_GEMM_VARIANT") && !getenv("AVEX_AMD_GEMM_GENERIC")) {
+        const char* er = getenv("AVEX_AMD_GEMM_ROW");      // read per launch: A/B runs switch it inside one process
+        const char* ek = getenv("AVEX_AMD_GEMM_ROW_KMAX");
+        if (er && atoi(er) != 0 && a.K <= (ek ? atoi(ek) : 1024)) return avx::gemm_row(a, __is_same(T, _Float16) ? AVEXHIP_F16 : AVEXHIP_BF16, s);
+    }
+    if (a.rows_out) {
+        // no kernel below finishes the row statistics: partials to stats_out, then ln_rowstats
+        AVX_REQUIRE(a.stats_out, "gemm: rows_out without the full-row kernel needs stats_out as scratch");
+        avx::GemmArgs b = a;
+        b.rows_out = nullptr;
+        const int rc = launch<T>(b, s);
+        if (rc != AVEXHIP_OK) return rc;
+        return avx::ln_rowstats(a.stats_out, a.M, a.N / 64, a.rows_eps, a.rows_out, s);
+    }
     // variant: 0 = auto, 1 = 128-tile register staging, 3 = 128-tile LDS-DMA, 5 (or 2, its tile-per-workgroup ancestor's number) =
     // the 256-tile streaming kernel
     int variant = a.variant;
-    const bool ln_fold = a.ln_rows || a.lnr_y || a.stats_out;
+    const bool ln_fold = a.ln_rows || a.lnr_y || a.stats_out;      // (rows_out was turned into stats_out + ln_rowstats above)
     if (ln_fold) {
         // folded LayerNorm exists in the 256-tile kernel only
         AVX_REQUIRE(a.N % T2 == 0 && a.K >= 2 * BK && (!a.out_half || a.ldh % 8 == 0), "gemm: folded LayerNorm needs N %% 256 == 0 and K >= 128 (N=%d K=%d)", a.N, a.K);

@@ -658,6 +658,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
         else { g.resid = x32; g.ldr = E; g.out_f32 = pre32; g.ldo = E; }
         if (fold) {
             g.stats_out = w.st1;
+            g.rows_out = w.r1; g.rows_eps = c.eps;      // the product finishes LN1's row statistics itself (gemm_row.hip at N = 768; otherwise avx::gemm runs ln_rowstats behind it)
             if (raw_in) {
                 g.resid_half = nullptr; g.ldrh = 0;
                 g.lnr_y = w.xh; g.ldy = E; g.lnr_rows = w.r2; g.lnr_gamma = ly.ga_o; g.lnr_beta = ly.bb_o; g.lnr_prefolded = 1;
@@ -697,9 +698,7 @@ inline int run_layers(HandleBase* h, const CoreCfg& c, const std::vector<Layer>&
             continue;
         }
         if (fold) {
-            prof.begin("ln_rowstats", 0.0);
-            RC(avx::ln_rowstats(w.st1, M, nseg, c.eps, w.r1, cs));
-            prof.end();
+            // (w.r1 = LN1's (rstd, -mu rstd) came out of the product: GemmArgs::rows_out)
         } else if (!ln1_fused) {
             prof.begin("layernorm", 0.0);
             RC(avx::layernorm(pre32, preh, E, ly.ln1_w, ly.ln1_b, c.eps, M, E, fast ? nullptr : x32, E, w.xh, E, dt, cs));

@@ -412,14 +412,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
          lnr_y: Optional[torch.Tensor] = None, lnr_rows: Optional[torch.Tensor] = None,
          lnr_gamma: Optional[torch.Tensor] = None, lnr_beta: Optional[torch.Tensor] = None, stats_out: bool = False,
          lda: Optional[int] = None, rows: Optional[int] = None, kdim: Optional[int] = None, slack_rows: int = 0,
-         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0, pool_mode: str = "mean", splitk: bool = False) -> Dict[str, torch.Tensor]:
+         overflow: Optional[torch.Tensor] = None, pool_rows: int = 0, pool_mode: str = "mean", splitk: bool = False,
+         rows_eps: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """``epi(a @ w.T)`` with ``a [M,K]`` and ``w [N,K]`` half tensors (see avexhip_gemm).  ``ln_rows``/``ln_s`` fold a
     LayerNorm of the A rows into the epilogue, ``lnr_*`` apply LayerNorm(lnr_y) as the residual (the ``*_rows`` tensors come from
     :func:`ln_rowstats`), ``stats_out`` returns the per-row partial statistics ``[M, N/64, 2]`` of the output under ``"stats"``;
     ``overflow`` is an optional ``uint32``/``int32`` device scalar the f16 range alarm adds to (include/avexhip.h); ``pool_rows`` = T
     treats the rows as clips of T rows and returns under ``"pooled"`` the per-clip mean of the raw output (bias added, before residual /
     activation) without materialising it (``pool_part`` + ``avexhip_pool_reduce``); ``pool_mode`` "max" / "cls_token" return the per-clip
-    maximum / first row instead."""
+    maximum / first row instead; ``rows_eps`` returns under ``"rows"`` the finished row statistics ``[M (+1 if odd), 2]`` = (rstd, -mean rstd)
+    of the output (what :func:`ln_rowstats` makes of ``"stats"``, same bits; the full-row kernel -- ``variant=8``, N = 768 -- writes them
+    from its epilogue)."""
     _need_cuda(a, w)
     if a.dtype != w.dtype or a.dtype not in (torch.float16, torch.bfloat16):
         raise ValueError("a and w must both be float16 or bfloat16")
@@ -484,6 +487,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     if stats_out:
         res["stats"] = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=a.device)
         args.stats_out = _ptr(res["stats"])
+    if rows_eps is not None:
+        res["rows"] = torch.zeros((M + (M & 1), 2), dtype=torch.float32, device=a.device)
+        args.rows_out, args.rows_eps = _ptr(res["rows"]), float(rows_eps)
+        if not stats_out:      # scratch for the kernels that cannot finish the statistics themselves
+            scratch = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+            args.stats_out = _ptr(scratch)
     check(lib().avexhip_gemm(C.byref(args), code, _stream()), "gemm")
     if part is not None and args.pool_mode == 2:
         res["pooled"] = part

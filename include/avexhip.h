@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AVEXHIP_ABI_VERSION 8
+#define AVEXHIP_ABI_VERSION 9
 
 enum { AVEXHIP_F16 = 0, AVEXHIP_BF16 = 1 };
 
@@ -242,7 +242,10 @@ typedef struct {
                                           (needs N % 256 == 0, K >= 128); 7 = skinny streaming kernel for long thin
                                           products (K, N in {64, 128, 256}, N K <= 32768, half output, bias / activation /
                                           half residual only; auto from 32 768 rows): the whole W in LDS, A rows straight
-                                          into MFMA operands */
+                                          into MFMA operands; 8 = the full-row residual kernel (N = 768, K % 32 == 0,
+                                          K >= 128; half output = half or LayerNorm-folded residual * alpha + acc + bias only):
+                                          128 rows x all 768 columns per workgroup, A read once, row statistics finished in the
+                                          tile; bit-identical to variant 5 */
     /* LayerNorm folded into the GEMMs around it (all NULL/0 = off; the 256-tile kernel only: N % 256 == 0, K >= 128).
      * A tensor y that is only consumed through LayerNorm (backbone.py:363,374: x = LN(residual * alpha + sublayer))
      * stays raw in the operand type.  The GEMM that produces it writes per-row partial statistics
@@ -271,6 +274,12 @@ typedef struct {
      * K >= 1024 (one clip's fc2) is split up to 8 ways along K -- fp32 partials [S][M][N] -- and finished by a second kernel that
      * adds the partials in order and applies the epilogue. */
     float* splitk_ws; size_t splitk_bytes;
+    /* ABI 9.  The finished row statistics of the output: rows_out[m] = (rstd, -mean * rstd), rstd = 1 / sqrt(var + rows_eps) -- what
+     * avexhip_ln_rowstats makes of stats_out, bit for bit -- written by the product itself.  The full-row kernel (variant 8: N = 768, built for the attention
+     * output projection, backbone.py:572 + :360-362; never chosen automatically) owns all 768 columns of its 128 rows and finishes the
+     * statistics in its epilogue; any other kernel needs stats_out as scratch and avexhip_gemm runs
+     * avexhip_ln_rowstats behind it.  `rows_out` must be writable up to M rounded up to even.  NULL = off. */
+    float* rows_out; float rows_eps;
 } avexhip_gemm_args;
 int avexhip_gemm(const avexhip_gemm_args* args, int dtype, void* stream);
 /* pool_part as written through avexhip_gemm_args.pool_part -> out[b, n] = mean over clip b's T rows of the raw GEMM output (bit-reproducible). */

@@ -503,6 +503,59 @@ def test_attention_without_a_bias_table(built_lib, T, grid, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd,grid", [(1000, 768, 0), (128, 768, 0), (129, 128, 0), (5000, 768, 3), (2050, 3072, 5), (40000, 768, 0), (126976, 768, 0)])
+def test_gemm_full_row_kernel_is_bit_identical(built_lib, dtype, M, Kd, grid, monkeypatch):
+    """gemm_row.hip (variant 8: one workgroup = 128 rows x all 768 columns; the attention output projection, backbone.py:572 + :360-362)
+    against the streaming kernel's residual epilogue (variant 5) on the same inputs: outputs, partial statistics and the finished row
+    statistics BIT FOR BIT (same MFMA chain over k, same epilogue operations, ln_rowstats_kernel's additions), in both residual forms
+    (plain half residual, LayerNorm(lnr_y) on the fly), ragged last tiles, several tiles per workgroup, K = 128 / 768 / 3072; and the
+    streaming kernel's result against fp64 (its own tests do that in depth)."""
+    from avex_amd import kernels as K
+    if M > 60000 and dtype == "bf16":
+        pytest.skip("the full-size case runs once")
+    if grid:
+        monkeypatch.setenv("AVEX_AMD_GEMM_GRID", str(8 * grid))      # (the streaming kernel's grid is a multiple of 8; the row kernel takes min(grid, tiles))
+    E = 768
+    td = _tdt(dtype)
+    g = torch.Generator().manual_seed(M + Kd)
+    a = (torch.randn(M, Kd, generator=g)).to(td).cuda()
+    w = (torch.randn(E, Kd, generator=g) * Kd ** -0.5).to(td).cuda()
+    x = torch.randn(M, E, generator=g).to(td).cuda()
+    bias = torch.randn(E, generator=g).cuda()
+    gamma = (1.0 + 0.2 * torch.randn(E, generator=g)).cuda(); beta = (0.2 * torch.randn(E, generator=g)).cuda()
+    alpha = 2.2133638
+    # (rstd, -mu rstd) of the residual rows, as a producer would have left them
+    xf = x.float()
+    rstd = 1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5)
+    lrows = torch.zeros(M + (M & 1), 2, device="cuda"); lrows[:M, 0] = rstd; lrows[:M, 1] = -xf.mean(1) * rstd
+    forms = {"plain": dict(resid_half=x), "lnr": dict(lnr_y=x, lnr_rows=lrows, lnr_gamma=gamma, lnr_beta=beta)}
+    for name, kw in forms.items():
+        out = {}
+        for v in (5, 8):
+            out[v] = K.gemm(a, w, bias=bias, alpha=alpha, out_f32=False, out_half=True, stats_out=True, rows_eps=1e-5, variant=v, **kw)
+        assert torch.equal(out[8]["half"], out[5]["half"]), (name, "output")
+        assert torch.equal(out[8]["stats"], out[5]["stats"]), (name, "partial statistics")
+        assert torch.equal(out[8]["rows"][:M], out[5]["rows"][:M]), (name, "row statistics")
+        assert torch.equal(out[5]["rows"][:M], K.ln_rowstats(out[5]["stats"], 1e-5)[:M])
+        # without the partial statistics (what the encoder asks for) and without any
+        r8 = K.gemm(a, w, bias=bias, alpha=alpha, out_f32=False, out_half=True, rows_eps=1e-5, variant=8, **kw)
+        assert torch.equal(r8["half"], out[5]["half"]) and torch.equal(r8["rows"][:M], out[5]["rows"][:M])
+        r8 = K.gemm(a, w, bias=bias, alpha=alpha, out_f32=False, out_half=True, variant=8, **kw)
+        assert torch.equal(r8["half"], out[5]["half"])
+        if M <= 5000:
+            res = xf.double() * alpha if name == "plain" else alpha * (torch.nn.functional.layer_norm(xf, (E,), gamma, beta, 1e-5)).double()
+            ref = (res + a.double() @ w.double().T + bias.double()).cpu().numpy()
+            assert rel_l2(out[8]["half"].float().cpu().numpy(), ref) < (6e-4 if dtype == "f16" else 5e-3), name
+    # the automatic choice (variant 0) with AVEX_AMD_GEMM_ROW=1 takes the row kernel from 32 768 rows at K <= 1024: same bits either way, so only the plumbing shows
+    if M >= 32768:
+        monkeypatch.setenv("AVEX_AMD_GEMM_ROW", "1")
+        r0 = K.gemm(a, w, bias=bias, alpha=alpha, out_f32=False, out_half=True, rows_eps=1e-5, **forms["lnr"])
+        assert torch.equal(r0["half"], out[5]["half"]) and torch.equal(r0["rows"][:M], out[5]["rows"][:M])
+    with pytest.raises(K.AvexHipError, match="variant 8"):
+        K.gemm(a, w, bias=bias, out_f32=True, out_half=True, resid_half=x, variant=8)          # an fp32 output is not its business
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_default_kernel_cross_checked_against_variant_2(built_lib, dtype, monkeypatch):
     """The CI cross-check of the default kernel (variant 3: hand-counted vmcnt waits, inline-asm Q loads, deferred softmax reference; default
     up to 512 tokens and, without a bias table, for the main block of 513 .. 544) against the kernel it replaced (variant 2, compiler-
