@@ -185,10 +185,10 @@ __global__ __launch_bounds__(512) void il_kernel(const _Float16* __restrict__ A,
                 x23 = (f32x2){a[2], a[3]} + (f32x2){bq[2], bq[3]};
             } else if constexpr (u == 2) {
                 pin(x01);
-                t01 = (f32x2){gelu_clamp_t(x01[0]), gelu_clamp_t(x01[1])};
+                t01 = (f32x2){gelu_clamp_t(x01[0], AVX_GELUH_INVA), gelu_clamp_t(x01[1], AVX_GELUH_INVA)};
             } else if constexpr (u == 3) {
                 pin(x23);
-                t23 = (f32x2){gelu_clamp_t(x23[0]), gelu_clamp_t(x23[1])};
+                t23 = (f32x2){gelu_clamp_t(x23[0], AVX_GELUH_INVA), gelu_clamp_t(x23[1], AVX_GELUH_INVA)};
             } else if constexpr (u == 4) {
                 pin(t01); pin(t23);
                 p01 = __builtin_elementwise_fma((f32x2)(AVX_GELUH_T4), t01, (f32x2)(AVX_GELUH_T3));

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void w4_kernel(const _Float16* __restrict__ A,
                 for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
         } else {
             __builtin_amdgcn_s_setreg(AVX_MODE_DX10_CLAMP_HWREG, 0);
+            AVX_CLAMP_TOKEN(inva);                                 // (common.h, round 6: the clamp's multiplier is defined behind the mode write)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {                 // 64 features at a time: the lane-swap transpose works on four 16-feature groups
                 const uint64_t a = (uint64_t)(out + (int64_t)(cur.m0 + 128 * wn) * N + cur.n0 + 128 * wm + 64 * half);
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(256) void w4_kernel(const _Float16* __restrict__ A,
                     for (int ii = 0; ii < 4; ++ii) {
                         const int i = 4 * half + ii;
                         const f32x4 bq = *(const f32x4*)(bias_lane + cur.n0 + 16 * i);
-                        const f32x2 y01 = gelu_erf2_h((f32x2){acc[i][j][0] + bq[0], acc[i][j][1] + bq[1]});
-                        const f32x2 y23 = gelu_erf2_h((f32x2){acc[i][j][2] + bq[2], acc[i][j][3] + bq[3]});
+                        const f32x2 y01 = gelu_erf2_h((f32x2){acc[i][j][0] + bq[0], acc[i][j][1] + bq[1]}, inva);
+                        const f32x2 y23 = gelu_erf2_h((f32x2){acc[i][j][2] + bq[2], acc[i][j][3] + bq[3]}, inva);
                         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                         __builtin_amdgcn_s_setreg(AVX_MODE_FP16_OVFL_HWREG, 1);
                         hA[ii] = __builtin_bit_cast(unsigned, (h2){(_Float16)y01[0], (_Float16)y01[1]});
