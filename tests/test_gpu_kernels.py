@@ -502,8 +502,10 @@ def test_attention_without_a_bias_table(built_lib, T, grid, dtype, monkeypatch):
     assert rel_l2(outs["3"][0], outs["2"][0]) < tol and rel_l2(outs["3"][1], outs["2"][1]) < tol
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,Kd,grid", [(1000, 768, 0), (128, 768, 0), (129, 128, 0), (5000, 768, 3), (2050, 3072, 5), (40000, 768, 0), (126976, 768, 0)])
+_ROW_CASES = [(1000, 768, 0), (128, 768, 0), (129, 128, 0), (5000, 768, 3), (2050, 3072, 5), (40000, 768, 0)]
+
+
+@pytest.mark.parametrize("dtype,M,Kd,grid", [(d,) + c for d in DTYPES for c in _ROW_CASES] + [("f16", 126976, 768, 0)])      # (the full size once)
 def test_gemm_full_row_kernel_is_bit_identical(built_lib, dtype, M, Kd, grid, monkeypatch):
     """gemm_row.hip (variant 8: one workgroup = 128 rows x all 768 columns; the attention output projection, backbone.py:572 + :360-362)
     against the streaming kernel's residual epilogue (variant 5) on the same inputs: outputs, partial statistics and the finished row
@@ -511,8 +513,6 @@ def test_gemm_full_row_kernel_is_bit_identical(built_lib, dtype, M, Kd, grid, mo
     (plain half residual, LayerNorm(lnr_y) on the fly), ragged last tiles, several tiles per workgroup, K = 128 / 768 / 3072; and the
     streaming kernel's result against fp64 (its own tests do that in depth)."""
     from avex_amd import kernels as K
-    if M > 60000 and dtype == "bf16":
-        pytest.skip("the full-size case runs once")
     if grid:
         monkeypatch.setenv("AVEX_AMD_GEMM_GRID", str(8 * grid))      # (the streaming kernel's grid is a multiple of 8; the row kernel takes min(grid, tiles))
     E = 768
