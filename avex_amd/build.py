@@ -34,7 +34,7 @@ EXTRA_FLAGS = {"fbank.hip": ["-fno-slp-vectorize"], "wavconv.hip": ["-fno-slp-ve
                "lstm.hip": ["-fno-slp-vectorize"]}
 
 
-def kernel_source_sha16(files=("gemm.hip", "common.h")) -> str:
+def kernel_source_sha16(files=("gemm.hip", "gemm_epi.h", "common.h")) -> str:
     """First 16 hex digits of the SHA-256 over the named csrc files: the identity of a kernel's source, recorded by the PMC summaries
     under profiles/ so that bench.py can tell whether a committed counter file describes the kernel it is running."""
     import hashlib

@@ -10,7 +10,7 @@
 //     statistics helpers): outputs and statistics are BIT-IDENTICAL to gemm256p_kernel<T, 2, LN> + ln_rowstats_kernel (tests).
 //
 // Shape of the work (gfx950): 512 threads = 8 waves; wave w owns columns [96 w, 96 w + 96) of all 128 rows: 6 x 8 tiles of
-// v_mfma_f32_16x16x32 = 192 accumulator registers (AGPRs), weights as the MFMA A operand (a lane ends up with 4 consecutive columns of one
+// v_mfma_f32_16x16x32 = 192 accumulator registers (of the 256 a wave has at two waves per SIMD), weights as the MFMA A operand (a lane ends up with 4 consecutive columns of one
 // row).  K advances in steps of 32: a step's operands are W [768 x 32] = 48 KiB and X [128 x 32] = 8 KiB, 64-byte LDS rows, 16-byte chunk c
 // of row r in slot c ^ (3 * ((r >> 2) & 1)) (applied on the LDS-DMA source address and on the ds_read_b128 address: every fragment read is
 // conflict-free for the b128 lane groups).  A wave's W rows are PRIVATE to it -- it DMAs them and only it reads them -- so the two W slots
@@ -19,7 +19,11 @@
 //     L: wait (counted vmcnt) for my W(k) and X(k+1) - 6 + 4 fragment reads - issue W(k+2)          M: issue X(k+3) - 48 MFMAs, the other
 //        four X fragments read into the first four's registers under them
 // separated by raw s_barriers; waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in M while its partner is in L.
-// LDS: 2 x 48 + 4 x 8 = 128 KiB of stages; the epilogue's transpose slabs alias them (the pipeline is drained at a tile's end).
+// LDS: 2 x 48 + 4 x 8 = 128 KiB of stages; the epilogue's transpose slab aliases them (the pipeline is drained at a tile's end).
+//
+// MEASURED (profiles/r06b_gemm_row.txt): 224 - 227 us on the attention output projection against 197 - 208 for the streaming kernel + ln_rowstats;
+// per tile 3.0 us prologue + 34.5 us K loop (MFMA floor 18.4; the operand stream alone 26.6 = 50 GB/s per CU) + 17.1 us epilogue.  Not the
+// default: avexhip_gemm variant 8, or AVEX_AMD_GEMM_ROW=1.
 #include <stdlib.h>
 
 #include "common.h"

@@ -622,7 +622,7 @@ def main():
                 tw = sj["layer_gemms_time_weighted"]
                 # do these counters describe the kernel this run executes?  (the summary records the hash of gemm.hip + common.h it was collected on)
                 from avex_amd.build import kernel_source_sha16
-                here = kernel_source_sha16(("gemm.hip", "common.h"))
+                here = kernel_source_sha16(("gemm.hip", "gemm_epi.h", "common.h"))
                 sq = {"sq_same_kernel_source": sj.get("gemm_source_sha16") == here, "sq_kernel_source_sha16": {"counters": sj.get("gemm_source_sha16"), "this_run": here},
                       "mfma_busy_frac": tw["mfma_busy_frac"], "effective_clock_mhz": tw["effective_clock_mhz"],
                       "mfma_busy_by_shape": {k: {"mfma_busy_frac": v["mfma_busy_frac"], "effective_clock_mhz": v["effective_clock_mhz"]}

@@ -73,5 +73,5 @@ if out:
 # which kernel source these counters describe: bench.py quotes the file only next to the same hash (or says that it is stale)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avex_amd.build import kernel_source_sha16  # noqa: E402
-out["gemm_source_sha16"] = kernel_source_sha16(("gemm.hip", "common.h"))
+out["gemm_source_sha16"] = kernel_source_sha16(("gemm.hip", "gemm_epi.h", "common.h"))
 json.dump(out, open(os.path.join(root, f"{tag}_gemm_sq.json"), "w"), indent=1)
