@@ -4,6 +4,8 @@ Goldens (tests/golden/base_api.npz) were produced by the real reference on the s
 checkpoint of avex_amd.synth; the bar is BASELINE.json's: pooled 768-d embedding within 1e-3
 relative (||a-b||2/||b||2) of the reference's fp32 CPU path.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -370,6 +372,14 @@ def test_config_c5_full_size_efficientnet(built_lib):
         # bit-identical since the squeeze-excitation pool became ordered per-workgroup partial sums (round 3; it was fp32 atomics before,
         # 4e-5 apart from run to run): every kernel of this family works clip by clip in a fixed order (profiles/r04_parity.json)
         assert torch.equal(one, full[r:r + 1])
+    # ... and at full size against the ORACLE, not only against itself: the two clips of tests/golden/family_small.npz (oracle/effnet_oracle.py on the
+    # synthetic checkpoint; UNPINNED: torchvision is absent from the reference tree) at rows 0 and 1023 of the 1024-clip batch
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "family_small.npz"))
+    g = torch.from_numpy(synth.noise_clips(2, int(gold["effnet.samples"][0]), seed=int(gold["effnet.seed"][0]))).cuda()
+    wav[0] = g[0]; wav[1023] = g[1]
+    full = enc.forward(plan(wav), want_features=False, want_pooled=True)["pooled"]
+    got = torch.stack([full[0], full[1023]]).cpu().numpy()
+    assert rel_l2(got, gold["effnet.pooled"]) < 1e-3
 
 
 def test_config_c5_nan_stays_in_its_clip(built_lib):

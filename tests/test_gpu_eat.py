@@ -134,6 +134,19 @@ def test_config_c3_full_size(built_lib, monkeypatch):
         assert full.shape == (512, 768) and torch.isfinite(full).all()
         small = enc.forward(wav[rows].contiguous(), want_features=False, pooling="mean")["pooled"]
         assert rel_l2(small.cpu().numpy(), full[rows].cpu().numpy()) < bar, fold
+        if fold is None:
+            # ... and at full size against the ORACLE, not only against itself: the two clips of tests/golden/family_small.npz (oracle/eat_oracle.py on
+            # the synthetic checkpoint; UNPINNED: EAT's remote code is absent from the reference tree) at rows 0 and 511 of the 512-clip batch -- token
+            # mean on the operand-type stream (the timed path of config C3), class token on the fp32 stream
+            import os
+            gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "family_small.npz"))
+            g = torch.from_numpy(synth.noise_clips(2, int(gold["eat.samples"][0]), seed=int(gold["eat.seed"][0]))).cuda()
+            w2 = wav.clone(); w2[0] = g[0]; w2[511] = g[1]
+            pm = enc.forward(w2, want_features=False, pooling="mean")["pooled"]
+            assert rel_l2(torch.stack([pm[0], pm[511]]).cpu().numpy(), gold["eat.pooled_mean"]) < 1e-3
+            pc = enc.forward(w2, want_features=False, pooling="cls")["pooled"]
+            assert rel_l2(torch.stack([pc[0], pc[511]]).cpu().numpy(), gold["eat.cls"]) < 1e-3
+            del w2
         del enc
 
 
