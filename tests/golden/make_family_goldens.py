@@ -1,8 +1,8 @@
-"""Small-batch known answers for BASELINE configs C3 (EAT 5 s clips) and C5 (EfficientNet-B0 10 s clips), from the NumPy oracles on the
+"""Small-batch known answers for BASELINE configs C3 (EAT 5 s clips) and C5 (EfficientNet-B0 10 s clips) and for AVES (10 s clips), from the NumPy oracles on the
 synthetic checkpoints (``avex_amd.synth``):  python tests/golden/make_family_goldens.py  ->  tests/golden/family_small.npz
 
 PARITY UNPINNED: both oracles restate third-party arithmetic that is absent from /root/reference (EAT's remote code, torchvision's
-EfficientNet), so these vectors pin the HIP path to the ORACLE, not to the reference.  ``bench.py`` compares its C3 /
+EfficientNet, torchaudio's wav2vec2), so these vectors pin the HIP path to the ORACLE, not to the reference.  ``bench.py`` compares its C3 /
 C5 legs with them after the timed region (it may not import ``oracle/`` outside its cpu_baseline leg) and says "unpinned" in the line."""
 import os
 import sys
@@ -16,6 +16,7 @@ from avex_amd import synth  # noqa: E402
 from oracle import beats_oracle as BO  # noqa: E402
 from oracle import eat_oracle as EO  # noqa: E402
 from oracle import effnet_oracle as FO  # noqa: E402
+from oracle import aves_oracle as AO  # noqa: E402
 
 
 def main() -> None:
@@ -36,6 +37,14 @@ def main() -> None:
     out["effnet.seed"] = np.array([71]); out["effnet.samples"] = np.array([160000])
     out["effnet.pooled"] = feats.mean((2, 3)).astype(np.float32)         # [2, 1280]: global average pool of the feature map
     print(f"EfficientNet-B0 2 x 10 s: {time.time() - t0:.1f} s, features {feats.shape}", flush=True)
+    t0 = time.time()
+    acfg = synth.AVES_BASE_CFG
+    ax = synth.noise_clips(2, 160000, seed=33)
+    aref, _ = AO.aves_forward(ax, synth.aves_state_dict(acfg), acfg)
+    out["aves.seed"] = np.array([33]); out["aves.samples"] = np.array([160000])
+    out["aves.pooled"] = aref.mean(1).astype(np.float32)                 # [2, 768]: mean over the 499 frames of the last layer (aves_model.py:129-150 features, mean-aggregated)
+    out["aves.frame0"] = aref[:, 0].astype(np.float32)                   # [2, 768]: one un-averaged row per clip
+    print(f"AVES 2 x 10 s: {time.time() - t0:.1f} s, features {aref.shape}", flush=True)
     np.savez(os.path.join(ROOT, "tests", "golden", "family_small.npz"), **out)
 
 

@@ -933,6 +933,28 @@ def test_aves_full_depth_and_long_clip(built_lib):
     assert rel_l2(rl["pooled"].cpu().numpy(), refl.mean(1)) < 2e-3
 
 
+def test_aves_at_bench_size_against_the_oracle_vectors(built_lib):
+    """AVES (wav2vec2-base, 12 layers) at the size scripts/aves_bench.py times -- 128 clips x 10 s, 499 frames each -- with the two clips of
+    tests/golden/family_small.npz (oracle/aves_oracle.py on the synthetic checkpoint; UNPINNED: torchaudio is absent from the reference tree) at rows
+    0 and 127: token mean on the operand-type residual stream, an un-averaged frame on the fp32 stream (residual="auto"); and clips are independent."""
+    import os
+    from avex_amd.aves_encoder import AvesEncoder
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "family_small.npz"))
+    cfg = synth.AVES_BASE_CFG
+    enc = AvesEncoder(cfg, synth.aves_state_dict(cfg))
+    n = int(gold["aves.samples"][0])
+    wav = torch.from_numpy(synth.noise_clips(128, n, seed=4)).cuda()
+    g = torch.from_numpy(synth.noise_clips(2, n, seed=int(gold["aves.seed"][0]))).cuda()
+    wav[0] = g[0]; wav[127] = g[1]
+    pooled = enc.forward(wav, want_features=False, want_pooled=True)["pooled"]
+    assert pooled.shape == (128, 768) and torch.isfinite(pooled).all()
+    assert rel_l2(torch.stack([pooled[0], pooled[127]]).cpu().numpy(), gold["aves.pooled"]) < 1e-3
+    two = enc.forward(g, want_features=False, want_pooled=True)["pooled"]
+    assert rel_l2(two.cpu().numpy(), torch.stack([pooled[0], pooled[127]]).cpu().numpy()) < 5e-4      # (small batches take other kernels: other roundings of the same arithmetic)
+    feats = enc.forward(g, want_features=True)["features"]
+    assert rel_l2(feats[:, 0].cpu().numpy(), gold["aves.frame0"]) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # Spectrogram / mel frontend of the reference's AudioProcessor (SURVEY.md section 8 a16)
 # ------------------------------------------------------------------------------------------------------------------------
